@@ -1,0 +1,155 @@
+"""Pins the numpy oracle against outputs of the reference's own modules (tests/golden/*.npz,
+made by tests/golden/make_golden.py in the build container).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from hipt_abmil_atec23_amd import synth
+from oracle import hipt_oracle as O
+
+TOL = 1e-4  # BASELINE.json north_star: "within 1e-4 fp32"
+ROWS = [0, 1, 128, 256]
+
+
+def maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def P(specs, base):
+    return synth.make_params_np(specs, base)
+
+
+def test_hash_numpy_equals_torch():
+    import torch
+    a = synth.hash_uniform_np((3, 1000), 5, 0.3, 0.7)
+    b = synth.hash_uniform_torch((3, 1000), 5, 0.3, 0.7).numpy()
+    assert np.array_equal(a, b)
+    assert a.dtype == np.float32 and abs(float(a.mean()) - 0.7) < 0.02
+    assert synth.hash_uniform_np((10,), 1).min() >= -1.0 and synth.hash_uniform_np((10,), 1).max() < 1.0
+
+
+def test_vit256_full_config():
+    g = golden("vit256_full")
+    p = P(synth.vit_param_specs("vit256"), 256)
+    x = synth.hash_uniform_np((2, 3, 256, 256), 2)
+    tok = O.vit256_prepare_tokens(x, p)
+    assert maxdiff(tok[:, ROWS], g["tokens_rows"]) < TOL
+    assert maxdiff(O.interpolate_pos_encoding(p["pos_embed"], 256, 256, 256, 16), g["pos"]) < 1e-5
+    t = tok
+    for i in range(12):
+        t = O.block(t, p, i, 6)
+        if i in (0, 5, 11):
+            assert maxdiff(t[:, ROWS], g[f"blk{i}_rows"]) < TOL, i
+    out = O.layer_norm(t, p["norm.weight"], p["norm.bias"])[:, 0]
+    assert maxdiff(out, g["out"]) < TOL
+    attn = O.vit_last_selfattention(tok, p, 6)
+    assert maxdiff(attn[:, :, 0], g["attn_cls"]) < 1e-5
+    assert maxdiff(attn[:, :, 200], g["attn_row200"]) < 1e-5
+    # the synthetic weights must give a softmax that is far from uniform (1/257 = 0.0039)
+    assert g["attn_cls"].max() > 0.02
+
+
+def test_vit_reduced_nonsquare():
+    g = golden("vit_small_cfg")
+    p = P(synth.vit_param_specs("vit256", embed_dim=64, depth=2, num_heads=2), 64)
+    x = synth.hash_uniform_np((2, 3, 64, 96), 22)
+    tok = O.vit256_prepare_tokens(x, p)
+    assert maxdiff(tok, g["tokens"]) < 1e-5
+    assert maxdiff(O.interpolate_pos_encoding(p["pos_embed"], 24, 64, 96, 16), g["pos"]) < 1e-6
+    assert maxdiff(O.vit256_forward(x, p, 2), g["out"]) < 1e-5
+    assert maxdiff(O.vit_last_selfattention(tok, p, 2), g["attn"]) < 1e-6
+    assert maxdiff(np.stack(O.vit_intermediate_layers(tok, p, 2, n=2)), g["inter"]) < 1e-5
+
+
+def test_vit4k():
+    g = golden("vit4k")
+    p = P(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096)
+    g16 = synth.hash_uniform_np((1, 384, 16, 16), 4)
+    g34 = synth.hash_uniform_np((2, 384, 3, 4), 44)
+    tok = O.vit4k_prepare_tokens(g16, p)
+    assert maxdiff(tok[:, ROWS], g["tokens16_rows"]) < 1e-5
+    assert maxdiff(O.interpolate_pos_encoding(p["pos_embed"], 256, 16, 16, 1), g["pos16"]) < 1e-6
+    assert maxdiff(O.interpolate_pos_encoding(p["pos_embed"], 12, 3, 4, 1), g["pos34"]) < 1e-6
+    assert maxdiff(O.vit4k_forward(g16, p), g["out16"]) < TOL
+    assert maxdiff(O.vit4k_forward(g34, p), g["out34"]) < TOL
+    assert maxdiff(O.vit_last_selfattention(tok, p, 6)[:, :, 0], g["attn_cls16"]) < 1e-5
+
+
+def test_hipt4k_composite_small_region():
+    g = golden("hipt4k_1024x768")
+    p256 = P(synth.vit_param_specs("vit256"), 256)
+    p4k = P(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096)
+    x = synth.hash_uniform_np((1, 3, 1024, 768), 3)
+    out, f = O.hipt4k_forward(x, p256, p4k, return_cls256=True)
+    assert maxdiff(f, g["cls256"]) < TOL
+    assert maxdiff(out, g["out"]) < TOL
+
+
+def test_patchify_and_grid_order_bit_exact():
+    """Index work is bit-exact: patch k = p1*h_256 + p2 and grid[0,:,i,j] = f[i*h_256+j]."""
+    img = np.arange(1 * 2 * 512 * 768, dtype=np.float32).reshape(1, 2, 512, 768)
+    b = O.patchify_256(img, 2, 3)
+    assert b.shape == (6, 2, 256, 256)
+    for p1 in range(2):
+        for p2 in range(3):
+            assert np.array_equal(b[p1 * 3 + p2], img[0, :, p1 * 256:(p1 + 1) * 256, p2 * 256:(p2 + 1) * 256])
+    f = np.arange(6 * 5, dtype=np.float32).reshape(6, 5)
+    grid = O.cls_grid(f, 2, 3)
+    assert grid.shape == (1, 5, 2, 3)
+    for i in range(2):
+        for j in range(3):
+            assert np.array_equal(grid[0, :, i, j], f[i * 3 + j])
+    crop, w, h = O.prepare_img_tensor(np.zeros((1, 3, 600, 1000), np.float32))
+    assert crop.shape == (1, 3, 512, 768) and (w, h) == (2, 3)
+
+
+CLAM_CASES = [
+    ("clam_384_n2000", (384, 128, 64), 384, (2000, 384), 1, 1, 8, False, False),
+    ("clam_384_n777", (384, 128, 64), 384, (777, 384), 11, 0, 8, False, False),
+    ("clam_384_n1", (384, 128, 64), 384, (1, 384), 12, None, 8, False, False),
+    ("clam_hipt_big_n500", (192, 128, 64), 192, (500, 192), 5, 1, 8, False, False),
+    ("clam_hipt_smallest_n100", (192, 8, 4), 8, (100, 192), 6, 0, 4, True, False),
+    ("clam_small_dropout_n300", (1024, 512, 256), 1024, (300, 1024), 7, None, 8, False, True),
+]
+
+
+@pytest.mark.parametrize("name,size,base,shape,seed,label,k,subtyping,dropout", CLAM_CASES)
+def test_clam_sb(name, size, base, shape, seed, label, k, subtyping, dropout):
+    g = golden(name)
+    p = P(synth.clam_param_specs(size, dropout=dropout), base)
+    h = synth.hash_uniform_np(shape, seed)
+    r = O.clam_sb_forward(h, p, k_sample=k, label=label, instance_eval=label is not None, subtyping=subtyping)
+    assert maxdiff(r["A_raw"], g["A_raw"]) < TOL
+    assert maxdiff(r["logits"], g["logits"]) < TOL
+    assert maxdiff(r["Y_prob"], g["Y_prob"]) < TOL
+    assert maxdiff(r["M"], g["M"]) < TOL
+    assert np.array_equal(r["Y_hat"], g["Y_hat"])  # int64, bit-exact
+    assert maxdiff(O.clam_sb_forward(h, p, attention_only=True), g["attention_only"]) < TOL
+    if label is not None:
+        ids = r["inst_ids"][0]
+        assert np.array_equal(ids[:k], g["top_p"])  # indices bit-exact
+        if len(ids) > k:
+            assert np.array_equal(ids[k:], g["top_n"])
+        assert abs(r["instance_loss"] - float(g["instance_loss"])) < TOL
+        preds = np.concatenate([np.argmax(l, axis=1) for l in r["inst_logits"]])
+        assert np.array_equal(preds, g["inst_preds"])
+
+
+def test_attn_net_gated():
+    g = golden("attn_net_gated_384_256")
+    spec = {"attention_a.0.weight": ((256, 384), 0.09, 0.0), "attention_a.0.bias": ((256,), 0.02, 0.0),
+            "attention_b.0.weight": ((256, 384), 0.09, 0.0), "attention_b.0.bias": ((256,), 0.02, 0.0),
+            "attention_c.weight": ((1, 256), 0.3, 0.0), "attention_c.bias": ((1,), 0.02, 0.0)}
+    p = P(spec, 9)
+    h = synth.hash_uniform_np((2000, 384), 1)
+    A, x = O.attn_net_gated(h, p)
+    assert x is h
+    assert maxdiff(A, g["A"]) < TOL
+
+
+def test_fp64_oracle_agrees_with_fp32_reference():
+    """fp64 evaluation of the oracle stays within the fp32 tolerance of the reference output."""
+    g = golden("vit4k")
+    p = {k: v.astype(np.float64) for k, v in P(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096).items()}
+    out = O.vit4k_forward(synth.hash_uniform_np((1, 384, 16, 16), 4).astype(np.float64), p)
+    assert maxdiff(out, g["out16"]) < TOL
