@@ -1,0 +1,154 @@
+"""ctypes binding of libhipt_abmil.so (C ABI: include/hipt_abmil.h).
+
+There is NO fallback: every product forward goes through this library, and anything that
+needs it raises ``RuntimeError`` if the shared object is missing or a call fails.  PyTorch is
+used only for device memory (tensors, ``data_ptr``) and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhipt_abmil.so")
+CSRC = os.path.join(HERE, "csrc")
+
+HIPT_F32, HIPT_BF16 = 0, 1
+EPI_GELU, EPI_RESID, EPI_OUT_F32, EPI_RELU = 1, 2, 4, 16
+ABI_VERSION = 1
+
+c_f32p = C.c_void_p  # device pointers travel as integers
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("dim", C.c_int32), ("depth", C.c_int32), ("heads", C.c_int32),
+                ("hidden", C.c_int32), ("ntok", C.c_int32), ("embed_k", C.c_int32), ("ln_eps", C.c_float),
+                ("embed_w", C.c_void_p), ("embed_b", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
+                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("blocks", C.POINTER(BlockWeights))]
+
+
+class ImageLayout(C.Structure):
+    _fields_ = [("grid_w", C.c_int32), ("grid_h", C.c_int32), ("patch_h", C.c_int32), ("patch_w", C.c_int32),
+                ("row_stride", C.c_int64), ("chan_stride", C.c_int64), ("batch_stride", C.c_int64)]
+
+
+class ClamWeights(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("s0", C.c_int32), ("s1", C.c_int32), ("s2", C.c_int32),
+                ("n_classes", C.c_int32), ("reserved", C.c_int32),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("wab", C.c_void_p), ("bab", C.c_void_p),
+                ("wc", C.c_void_p), ("bc", C.c_void_p), ("wcls", C.c_void_p), ("bcls", C.c_void_p)]
+
+
+_VW, _IL, _CW = C.POINTER(VitWeights), C.POINTER(ImageLayout), C.POINTER(ClamWeights)
+_i, _i64, _p, _sz, _f = C.c_int, C.c_int64, C.c_void_p, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes); mirrors include/hipt_abmil.h one to one
+SIGNATURES = {
+    "hipt_abi_version": (_i, []),
+    "hipt_last_error": (C.c_char_p, []),
+    "hipt_layernorm": (_i, [_p, _i64, _p, _p, _p, _i, _i64, _i, _i, _f, _p]),
+    "hipt_linear": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
+    "hipt_attention": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
+    "hipt_vit_workspace_bytes": (_sz, [_VW, _i]),
+    "hipt_vit256_forward_workspace_bytes": (_sz, [_VW, _IL, _i, _i]),
+    "hipt_vit4k_forward_workspace_bytes": (_sz, [_VW, _i]),
+    "hipt_vit256_prepare_tokens": (_i, [_VW, _p, _IL, _i, _i, _p, _p, _sz, _p]),
+    "hipt_vit4k_prepare_tokens": (_i, [_VW, _p, _i, _p, _p, _sz, _p]),
+    "hipt_vit_blocks": (_i, [_VW, _p, _i, _i, _i, _p, _p, _sz, _p]),
+    "hipt_vit_head": (_i, [_VW, _p, _i, _i, _p, _p]),
+    "hipt_vit256_forward": (_i, [_VW, _p, _IL, _i, _i, _p, _p, _sz, _p]),
+    "hipt_vit4k_forward": (_i, [_VW, _p, _i, _p, _p, _sz, _p]),
+    "hipt_hipt4k_workspace_bytes": (_sz, [_VW, _VW, _i, _i, _i]),
+    "hipt_hipt4k_forward": (_i, [_VW, _VW, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "hipt_clam_workspace_bytes": (_sz, [_CW, _i]),
+    "hipt_clam_sb_forward": (_i, [_CW, _p, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "hipt_attn_net_gated": (_i, [_CW, _p, _i, _p, _p, _sz, _p]),
+    "hipt_clam_gather_h1": (_i, [_CW, _p, _p, _i, _p, _p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+calls = 0  # number of native entry-point invocations (tests use it to prove the HIP path ran)
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libhipt_abmil.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))],
+                       capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode or not os.path.isfile(LIB_PATH):
+        raise NativeLibraryError(f"building {LIB_PATH} failed (make exit {r.returncode})")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it is not there (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.isfile(LIB_PATH):
+                raise NativeLibraryError(
+                    f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                    f"(or `make -C {CSRC}`).  This package has no non-HIP execution path.")
+            h = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(h, name)  # AttributeError if the .so does not export a declared symbol
+                fn.restype, fn.argtypes = res, args
+            if h.hipt_abi_version() != ABI_VERSION:
+                raise NativeLibraryError(f"ABI mismatch: library {h.hipt_abi_version()} != binding {ABI_VERSION}")
+            _lib = h
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().hipt_last_error().decode(errors="replace")
+        raise RuntimeError(f"libhipt_abmil: {what} failed with code {rc}: {msg}")
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    global calls
+    calls += 1
+    check(getattr(lib(), name)(*args), name)
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def dtype_code(name: str) -> int:
+    if name in ("fp32", "float32", "f32"):
+        return HIPT_F32
+    if name in ("bf16", "bfloat16"):
+        return HIPT_BF16
+    raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {name!r}")
+
+
+def require_cuda(t, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what}: input is on {t.device}; hipt_abmil_atec23_amd runs only on a HIP device "
+            f"(there is deliberately no CPU path — move the module and its inputs to 'cuda').")

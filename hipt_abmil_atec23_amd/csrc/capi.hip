@@ -1,0 +1,475 @@
+// extern "C" entry points of libhipt_abmil.so (include/hipt_abmil.h): argument validation, scratch
+// carving and the launch sequences.  Host code only: nothing here synchronises or allocates, so a
+// caller may capture any call into a hipGraph.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+
+void hipt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+inline size_t al256(size_t n) { return (n + 255) & ~(size_t)255; }
+inline int esz(int dtype) { return dtype == HIPT_F32 ? 4 : 2; }
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+struct Carver {
+    char* base;
+    size_t cap, used = 0;
+    Carver(void* b, size_t c) : base((char*)b), cap(c) {}
+    void* take(size_t n) {
+        void* p = base + used;
+        used += al256(n);
+        return p;
+    }
+    bool ok() const { return used <= cap && (((uintptr_t)base & 255) == 0 || used == 0); }
+};
+
+int check_vit(const hipt_vit_weights* w) {
+    HIPT_CHECK_ARG(w != nullptr && w->blocks != nullptr, "vit: null weights");
+    HIPT_CHECK_ARG(w->dtype == HIPT_F32 || w->dtype == HIPT_BF16, "vit: bad dtype %d", w->dtype);
+    HIPT_CHECK_ARG(w->dim > 0 && w->dim % 64 == 0, "vit: dim=%d must be a multiple of 64", w->dim);
+    HIPT_CHECK_ARG(w->heads > 0 && w->dim % w->heads == 0, "vit: dim %d not divisible by heads %d", w->dim, w->heads);
+    const int dh = w->dim / w->heads;
+    HIPT_CHECK_ARG(dh == 32 || dh == 64, "vit: head dim %d not in {32,64}", dh);
+    HIPT_CHECK_ARG(w->hidden % 64 == 0, "vit: hidden=%d must be a multiple of 64", w->hidden);
+    HIPT_CHECK_ARG(w->ln_eps > 0.f && w->ln_eps < 1.f, "vit: ln_eps=%g looks uninitialised", (double)w->ln_eps);
+    if (w->ntok < 1 || w->ntok > 288) {
+        hipt_set_error("vit: ntok=%d outside the on-chip attention envelope [1, 288]", w->ntok);
+        return HIPT_E_UNSUPPORTED;
+    }
+    return HIPT_OK;
+}
+
+struct BlockScratch {
+    void *xn, *qkv, *att, *hid;
+};
+
+size_t block_scratch_bytes(const hipt_vit_weights* w, int nseq) {
+    const size_t rows = (size_t)nseq * w->ntok, e = esz(w->dtype);
+    return al256(rows * w->dim * e) * 2 + al256(rows * 3 * w->dim * e) + al256(rows * w->hidden * e);
+}
+
+BlockScratch carve_blocks(Carver& c, const hipt_vit_weights* w, int nseq) {
+    const size_t rows = (size_t)nseq * w->ntok, e = esz(w->dtype);
+    BlockScratch s;
+    s.xn = c.take(rows * w->dim * e);
+    s.qkv = c.take(rows * 3 * w->dim * e);
+    s.att = c.take(rows * w->dim * e);
+    s.hid = c.take(rows * w->hidden * e);
+    return s;
+}
+
+int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, void* out,
+           int64_t ldc, int M, int N, int K, int dtype, int flags, hipStream_t st) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A;
+    p.lda = lda;
+    p.W = W;
+    p.ldw = ldw;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.bias = bias;
+    p.resid = resid;
+    p.out = out;
+    p.ldc = ldc;
+    return hipt_gemm_launch(p, dtype, ALOAD_PLAIN, flags, st);
+}
+
+int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, float* probs, const BlockScratch& s,
+               hipStream_t st) {
+    const int D = w->dim, M = nseq * w->ntok, dt = w->dtype, dh = D / w->heads;
+    const float scale = 1.0f / sqrtf((float)dh);  // head_dim ** -0.5 (vision_transformer.py:112)
+    int rc;
+    for (int i = b0; i < b1; ++i) {
+        const hipt_block_weights& b = w->blocks[i];
+        const bool last_probs = probs != nullptr && i == b1 - 1;
+        if ((rc = hipt_layernorm_launch(x, D, b.ln1_w, b.ln1_b, s.xn, dt, D, M, D, w->ln_eps, st))) return rc;
+        if ((rc = linear(s.xn, D, b.qkv_w, D, b.qkv_b, nullptr, s.qkv, 3 * D, M, 3 * D, D, dt, 0, st))) return rc;
+        if ((rc = hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st)))
+            return rc;
+        if (last_probs) break;  // Block.forward(return_attention=True) returns before the residual (:148-149)
+        if ((rc = linear(s.att, D, b.proj_w, D, b.proj_b, x, x, D, M, D, D, dt, HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st)))
+            return rc;
+        if ((rc = hipt_layernorm_launch(x, D, b.ln2_w, b.ln2_b, s.xn, dt, D, M, D, w->ln_eps, st))) return rc;
+        if ((rc = linear(s.xn, D, b.fc1_w, D, b.fc1_b, nullptr, s.hid, w->hidden, M, w->hidden, D, dt, HIPT_EPI_GELU, st)))
+            return rc;
+        if ((rc = linear(s.hid, w->hidden, b.fc2_w, w->hidden, b.fc2_b, x, x, D, M, D, w->hidden, dt,
+                         HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st)))
+            return rc;
+    }
+    return HIPT_OK;
+}
+
+int64_t image_elems(const hipt_image_layout* lay, int nseq_total) {
+    const int per = lay->grid_w * lay->grid_h;
+    return (int64_t)((nseq_total + per - 1) / per) * lay->batch_stride;
+}
+
+// tokens of sequences [seq0, seq0+nseq) from an image tensor already in the compute dtype
+int embed256(const hipt_vit_weights* w, const void* img, const hipt_image_layout* lay, int seq0, int nseq, float* x,
+             hipStream_t st) {
+    HIPT_CHECK_ARG(lay->patch_h % 16 == 0 && lay->patch_w % 16 == 0, "vit256: patch %dx%d not a multiple of 16", lay->patch_h,
+                   lay->patch_w);
+    const int nty = lay->patch_h / 16, ntx = lay->patch_w / 16;
+    HIPT_CHECK_ARG(nty * ntx + 1 == w->ntok, "vit256: image gives %d tokens, weights expect %d", nty * ntx + 1, w->ntok);
+    HIPT_CHECK_ARG(w->embed_k == 768, "vit256: embed_k must be 768 (3x16x16)");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = img;
+    p.W = w->embed_w;
+    p.ldw = w->embed_k;
+    p.M = nseq * nty * ntx;
+    p.N = w->dim;
+    p.K = w->embed_k;
+    p.bias = w->embed_b;
+    p.out = x;
+    p.ldc = w->dim;
+    p.pos = w->pos;
+    p.rows_per_seq = nty * ntx;
+    p.im = *lay;
+    p.im_nty = nty;
+    p.im_ntx = ntx;
+    p.im_seq0 = seq0;
+    int rc = hipt_gemm_launch(p, w->dtype, ALOAD_IM2COL, HIPT_EPI_OUT_F32 | EPI_ROWMAP, st);
+    if (rc) return rc;
+    return hipt_cls_init_launch(x, w->cls, w->pos, nseq, w->ntok, w->dim, st);
+}
+
+int embed4k(const hipt_vit_weights* w, const void* tokens, int nseq, float* x, hipStream_t st) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = tokens;
+    p.lda = w->embed_k;
+    p.W = w->embed_w;
+    p.ldw = w->embed_k;
+    p.M = nseq * (w->ntok - 1);
+    p.N = w->dim;
+    p.K = w->embed_k;
+    p.bias = w->embed_b;
+    p.out = x;
+    p.ldc = w->dim;
+    p.pos = w->pos;
+    p.rows_per_seq = w->ntok - 1;
+    int rc = HIPT_OK;
+    if (p.M > 0) rc = hipt_gemm_launch(p, w->dtype, ALOAD_PLAIN, HIPT_EPI_GELU | HIPT_EPI_OUT_F32 | EPI_ROWMAP, st);
+    if (rc) return rc;
+    return hipt_cls_init_launch(x, w->cls, w->pos, nseq, w->ntok, w->dim, st);
+}
+
+int default_chunk(int nseq) { return nseq < 256 ? nseq : 256; }
+
+}  // namespace
+
+extern "C" {
+
+int hipt_abi_version(void) { return HIPT_ABI_VERSION; }
+const char* hipt_last_error(void) { return g_err; }
+
+int hipt_layernorm(const float* x, int64_t x_stride, const float* w, const float* b, void* out, int out_dtype,
+                   int64_t out_stride, int rows, int D, float eps, void* stream) {
+    return hipt_layernorm_launch(x, x_stride, w, b, out, out_dtype, out_stride, rows, D, eps, S(stream));
+}
+
+int hipt_linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, void* out,
+                int64_t ldc, int M, int N, int K, int dtype, int flags, void* stream) {
+    HIPT_CHECK_ARG((flags & ~(HIPT_EPI_GELU | HIPT_EPI_RESID | HIPT_EPI_OUT_F32 | HIPT_EPI_RELU)) == 0, "linear: bad flags %d",
+                   flags);
+    HIPT_CHECK_ARG(!(flags & HIPT_EPI_RESID) || resid != nullptr, "linear: RESID without a residual pointer");
+    return linear(A, lda, W, ldw, bias, resid, out, ldc, M, N, K, dtype, flags, S(stream));
+}
+
+int hipt_attention(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale, int dtype,
+                   void* stream) {
+    return hipt_attention_launch(qkv, out, probs, B, ntok, heads, dh, scale, dtype, S(stream));
+}
+
+size_t hipt_vit_workspace_bytes(const hipt_vit_weights* w, int nseq) {
+    // block scratch; the 4K token conversion buffer is the only extra of the prepare_tokens calls
+    return block_scratch_bytes(w, nseq) + al256((size_t)nseq * w->ntok * w->embed_k * 2);
+}
+
+size_t hipt_vit256_forward_workspace_bytes(const hipt_vit_weights* w, const hipt_image_layout* lay, int nseq, int chunk) {
+    if (chunk <= 0) chunk = default_chunk(nseq);
+    if (chunk > nseq) chunk = nseq;
+    size_t n = al256((size_t)chunk * w->ntok * w->dim * 4) + block_scratch_bytes(w, chunk);
+    if (w->dtype == HIPT_BF16) n += al256((size_t)image_elems(lay, nseq) * 2);
+    return n;
+}
+
+size_t hipt_vit4k_forward_workspace_bytes(const hipt_vit_weights* w, int nseq) {
+    return al256((size_t)nseq * w->ntok * w->dim * 4) + hipt_vit_workspace_bytes(w, nseq);
+}
+
+int hipt_vit256_prepare_tokens(const hipt_vit_weights* w, const float* images, const hipt_image_layout* lay, int seq0,
+                               int nseq, float* x, void* workspace, size_t ws_bytes, void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(images && lay && x && nseq > 0 && seq0 >= 0, "vit256_prepare_tokens: null/empty argument");
+    const void* img = images;
+    if (w->dtype == HIPT_BF16) {
+        const int64_t n = image_elems(lay, seq0 + nseq);
+        if (ws_bytes < al256((size_t)n * 2) || ((uintptr_t)workspace & 255)) {
+            hipt_set_error("vit256_prepare_tokens: workspace %zu B too small / unaligned (need %zu)", ws_bytes, al256((size_t)n * 2));
+            return HIPT_E_WORKSPACE;
+        }
+        if ((rc = hipt_f32_to_bf16_launch(images, workspace, n, S(stream)))) return rc;
+        img = workspace;
+    }
+    return embed256(w, img, lay, seq0, nseq, x, S(stream));
+}
+
+int hipt_vit4k_prepare_tokens(const hipt_vit_weights* w, const float* tokens_in, int nseq, float* x, void* workspace,
+                              size_t ws_bytes, void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(x && nseq > 0 && (tokens_in || w->ntok == 1), "vit4k_prepare_tokens: null/empty argument");
+    const void* tok = tokens_in;
+    const int64_t n = (int64_t)nseq * (w->ntok - 1) * w->embed_k;
+    if (w->dtype == HIPT_BF16 && n > 0) {
+        if (ws_bytes < al256((size_t)n * 2) || ((uintptr_t)workspace & 255)) {
+            hipt_set_error("vit4k_prepare_tokens: workspace %zu B too small / unaligned (need %zu)", ws_bytes, al256((size_t)n * 2));
+            return HIPT_E_WORKSPACE;
+        }
+        if ((rc = hipt_f32_to_bf16_launch(tokens_in, workspace, n, S(stream)))) return rc;
+        tok = workspace;
+    }
+    return embed4k(w, tok, nseq, x, S(stream));
+}
+
+int hipt_vit_blocks(const hipt_vit_weights* w, float* x, int nseq, int blk_begin, int blk_end, float* probs, void* workspace,
+                    size_t ws_bytes, void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(x && nseq > 0 && blk_begin >= 0 && blk_end <= w->depth && blk_begin <= blk_end, "vit_blocks: bad range [%d,%d)",
+                   blk_begin, blk_end);
+    Carver c(workspace, ws_bytes);
+    BlockScratch s = carve_blocks(c, w, nseq);
+    if (!c.ok()) {
+        hipt_set_error("vit_blocks: workspace %zu B too small / unaligned (need %zu)", ws_bytes, c.used);
+        return HIPT_E_WORKSPACE;
+    }
+    return run_blocks(w, x, nseq, blk_begin, blk_end, probs, s, S(stream));
+}
+
+int hipt_vit_head(const hipt_vit_weights* w, const float* x, int nseq, int cls_only, float* out, void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    const int D = w->dim;
+    if (cls_only)
+        return hipt_layernorm_launch(x, (int64_t)w->ntok * D, w->norm_w, w->norm_b, out, HIPT_F32, D, nseq, D, w->ln_eps, S(stream));
+    return hipt_layernorm_launch(x, D, w->norm_w, w->norm_b, out, HIPT_F32, D, nseq * w->ntok, D, w->ln_eps, S(stream));
+}
+
+int hipt_vit256_forward(const hipt_vit_weights* w, const float* images, const hipt_image_layout* lay, int nseq, int chunk,
+                        float* out, void* workspace, size_t ws_bytes, void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(images && lay && out && nseq > 0, "vit256_forward: null/empty argument");
+    if (chunk <= 0) chunk = default_chunk(nseq);
+    if (chunk > nseq) chunk = nseq;
+    hipStream_t st = S(stream);
+    Carver c(workspace, ws_bytes);
+    float* x = (float*)c.take((size_t)chunk * w->ntok * w->dim * 4);
+    BlockScratch s = carve_blocks(c, w, chunk);
+    const void* img = images;
+    void* imgT = nullptr;
+    const int64_t n_img = image_elems(lay, nseq);
+    if (w->dtype == HIPT_BF16) imgT = c.take((size_t)n_img * 2);
+    if (!c.ok()) {
+        hipt_set_error("vit256_forward: workspace %zu B too small / unaligned (need %zu)", ws_bytes, c.used);
+        return HIPT_E_WORKSPACE;
+    }
+    if (imgT) {
+        if ((rc = hipt_f32_to_bf16_launch(images, imgT, n_img, st))) return rc;
+        img = imgT;
+    }
+    for (int s0 = 0; s0 < nseq; s0 += chunk) {
+        const int n = nseq - s0 < chunk ? nseq - s0 : chunk;
+        if ((rc = embed256(w, img, lay, s0, n, x, st))) return rc;
+        if ((rc = run_blocks(w, x, n, 0, w->depth, nullptr, s, st))) return rc;
+        if ((rc = hipt_layernorm_launch(x, (int64_t)w->ntok * w->dim, w->norm_w, w->norm_b, out + (size_t)s0 * w->dim, HIPT_F32,
+                                        w->dim, n, w->dim, w->ln_eps, st)))
+            return rc;
+    }
+    return HIPT_OK;
+}
+
+int hipt_vit4k_forward(const hipt_vit_weights* w, const float* tokens_in, int nseq, float* out, void* workspace,
+                       size_t ws_bytes, void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(out && nseq > 0, "vit4k_forward: null/empty argument");
+    hipStream_t st = S(stream);
+    Carver c(workspace, ws_bytes);
+    float* x = (float*)c.take((size_t)nseq * w->ntok * w->dim * 4);
+    BlockScratch s = carve_blocks(c, w, nseq);
+    void* tokT = c.take((size_t)nseq * w->ntok * w->embed_k * 2);
+    if (!c.ok()) {
+        hipt_set_error("vit4k_forward: workspace %zu B too small / unaligned (need %zu)", ws_bytes, c.used);
+        return HIPT_E_WORKSPACE;
+    }
+    const void* tok = tokens_in;
+    const int64_t n = (int64_t)nseq * (w->ntok - 1) * w->embed_k;
+    if (w->dtype == HIPT_BF16 && n > 0) {
+        if ((rc = hipt_f32_to_bf16_launch(tokens_in, tokT, n, st))) return rc;
+        tok = tokT;
+    }
+    if ((rc = embed4k(w, tok, nseq, x, st))) return rc;
+    if ((rc = run_blocks(w, x, nseq, 0, w->depth, nullptr, s, st))) return rc;
+    return hipt_layernorm_launch(x, (int64_t)w->ntok * w->dim, w->norm_w, w->norm_b, out, HIPT_F32, w->dim, nseq, w->dim, w->ln_eps, st);
+}
+
+size_t hipt_hipt4k_workspace_bytes(const hipt_vit_weights* w256, const hipt_vit_weights* w4k, int w_256, int h_256,
+                                   int chunk) {
+    hipt_image_layout lay;
+    lay.grid_w = w_256;
+    lay.grid_h = h_256;
+    lay.patch_h = lay.patch_w = 256;
+    lay.row_stride = (int64_t)h_256 * 256;
+    lay.chan_stride = (int64_t)w_256 * 256 * lay.row_stride;
+    lay.batch_stride = 3 * lay.chan_stride;
+    const int nseq = w_256 * h_256;
+    return hipt_vit256_forward_workspace_bytes(w256, &lay, nseq, chunk) + hipt_vit4k_forward_workspace_bytes(w4k, 1) +
+           al256((size_t)nseq * w256->dim * 4);
+}
+
+int hipt_hipt4k_forward(const hipt_vit_weights* w256, const hipt_vit_weights* w4k, const float* region, int W, int H, int chunk,
+                        float* cls256_out, float* out, void* workspace, size_t ws_bytes, void* stream) {
+    HIPT_CHECK_ARG(w256 && w4k && region && out, "hipt4k_forward: null argument");
+    HIPT_CHECK_ARG(W > 0 && H > 0 && W % 256 == 0 && H % 256 == 0, "hipt4k_forward: region %dx%d must be cropped to multiples of 256",
+                   W, H);
+    const int w_256 = W / 256, h_256 = H / 256, nseq = w_256 * h_256;
+    HIPT_CHECK_ARG(w4k->ntok == nseq + 1, "hipt4k_forward: ViT-4K weights prepared for %d tokens, region has %d", w4k->ntok, nseq + 1);
+    HIPT_CHECK_ARG(w4k->embed_k == w256->dim, "hipt4k_forward: ViT-4K input width %d != ViT-256 width %d", w4k->embed_k, w256->dim);
+    hipt_image_layout lay;
+    lay.grid_w = w_256;
+    lay.grid_h = h_256;
+    lay.patch_h = lay.patch_w = 256;
+    lay.row_stride = H;
+    lay.chan_stride = (int64_t)W * H;
+    lay.batch_stride = 3 * lay.chan_stride;
+    const size_t n256 = hipt_vit256_forward_workspace_bytes(w256, &lay, nseq, chunk);
+    const size_t n4k = hipt_vit4k_forward_workspace_bytes(w4k, 1);
+    const size_t ncls = al256((size_t)nseq * w256->dim * 4);
+    if (ws_bytes < n256 + n4k + ncls || ((uintptr_t)workspace & 255)) {
+        hipt_set_error("hipt4k_forward: workspace %zu B too small / unaligned (need %zu)", ws_bytes, n256 + n4k + ncls);
+        return HIPT_E_WORKSPACE;
+    }
+    char* ws = (char*)workspace;
+    float* cls = cls256_out ? cls256_out : (float*)ws;  // [nseq, 384] token-major: exactly phi's input (hipt_4k.py:72-74)
+    int rc = hipt_vit256_forward(w256, region, &lay, nseq, chunk, cls, ws + ncls, n256, stream);
+    if (rc) return rc;
+    return hipt_vit4k_forward(w4k, cls, 1, out, ws + ncls + n256, n4k, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CLAM_SB / ABMIL
+// ------------------------------------------------------------------------------------------------
+static int check_clam(const hipt_clam_weights* w) {
+    HIPT_CHECK_ARG(w != nullptr, "clam: null weights");
+    HIPT_CHECK_ARG(w->dtype == HIPT_F32 || w->dtype == HIPT_BF16, "clam: bad dtype %d", w->dtype);
+    HIPT_CHECK_ARG(w->s1 > 0 && w->s2 > 0, "clam: bad widths [%d,%d,%d]", w->s0, w->s1, w->s2);
+    return HIPT_OK;
+}
+
+static size_t clam_partials_bytes(const hipt_clam_weights* w, int N) {
+    const size_t g = (size_t)(N / 256 + 2) > 512 ? (size_t)(N / 256 + 2) : 512;
+    return al256(g * (2 + w->s1) * 4);
+}
+
+size_t hipt_clam_workspace_bytes(const hipt_clam_weights* w, int N) {
+    // partials | gmax | h1 fp32 | ab fp32 | h1 in dtype (generic path)
+    return clam_partials_bytes(w, N) + 256 + al256((size_t)N * w->s1 * 4) + al256((size_t)N * 2 * w->s2 * 4) +
+           al256((size_t)N * w->s1 * 2);
+}
+
+static int gated_scores(const hipt_clam_weights* w, const void* x, int xdtype, int N, float* ab, void* xT, float* A,
+                        hipStream_t st) {
+    // ab = x @ [Wa;Wb]^T + [ba;bb]  (x: [N,S1] in xdtype), then the gate
+    const int kb = w->dtype == HIPT_F32 ? 32 : 64, n2 = 2 * w->s2;
+    int rc;
+    if (w->s1 % kb == 0 && n2 % 4 == 0) {
+        const void* a = x;
+        if (xdtype != w->dtype) {  // fp32 h1 -> bf16 operand
+            if ((rc = hipt_f32_to_bf16_launch((const float*)x, xT, (int64_t)N * w->s1, st))) return rc;
+            a = xT;
+        }
+        rc = linear(a, w->s1, w->wab, w->s1, w->bab, nullptr, ab, n2, N, n2, w->s1, w->dtype, HIPT_EPI_OUT_F32, st);
+    } else {
+        rc = hipt_small_ab_launch(x, xdtype, N, w->s1, n2, w->wab, w->dtype, w->bab, ab, st);
+    }
+    if (rc) return rc;
+    return hipt_gate_launch(ab, n2, N, w->s2, w->wc, w->bc, A, st);
+}
+
+int hipt_clam_sb_forward(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, float* M,
+                         float* logits, float* Y_prob, int64_t* Y_hat, void* workspace, size_t ws_bytes, void* stream) {
+    int rc = check_clam(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(bag && A_raw && N > 0, "clam_sb_forward: null/empty bag (N=%d)", N);
+    HIPT_CHECK_ARG(attention_only || (M && logits && Y_prob && Y_hat), "clam_sb_forward: null output");
+    HIPT_CHECK_ARG(((uintptr_t)bag & 15) == 0, "clam_sb_forward: bag must be 16-byte aligned");
+    const int kb = w->dtype == HIPT_F32 ? 32 : 64;
+    if (w->s0 % kb != 0 || w->s1 % 4 != 0) {
+        hipt_set_error("clam_sb_forward: S0=%d must be a multiple of %d and S1=%d of 4", w->s0, kb, w->s1);
+        return HIPT_E_UNSUPPORTED;
+    }
+    if (ws_bytes < hipt_clam_workspace_bytes(w, N) || ((uintptr_t)workspace & 255)) {
+        hipt_set_error("clam_sb_forward: workspace %zu B too small / unaligned (need %zu)", ws_bytes, hipt_clam_workspace_bytes(w, N));
+        return HIPT_E_WORKSPACE;
+    }
+    hipStream_t st = S(stream);
+    Carver c(workspace, ws_bytes);
+    float* partials = (float*)c.take(clam_partials_bytes(w, N));
+    float* gmax = (float*)c.take(256);
+    int G = 0;
+    if (hipt_clam_fused_supported(w)) {
+        if ((rc = hipt_clam_fused_launch(w, bag, N, attention_only, A_raw, partials, &G, st))) return rc;
+    } else {
+        float* h1 = (float*)c.take((size_t)N * w->s1 * 4);
+        float* ab = (float*)c.take((size_t)N * 2 * w->s2 * 4);
+        void* h1T = c.take((size_t)N * w->s1 * 2);
+        if ((rc = linear(bag, w->s0, w->w1, w->s0, w->b1, nullptr, h1, w->s1, N, w->s1, w->s0, w->dtype,
+                         HIPT_EPI_RELU | HIPT_EPI_OUT_F32, st)))
+            return rc;
+        if ((rc = gated_scores(w, h1, HIPT_F32, N, ab, h1T, A_raw, st))) return rc;
+        if (!attention_only && (rc = hipt_pool_launch(A_raw, h1, N, w->s1, gmax, partials, &G, st))) return rc;
+    }
+    if (attention_only) return HIPT_OK;
+    return hipt_clam_combine_launch(partials, G, w, M, logits, Y_prob, Y_hat, st);
+}
+
+int hipt_attn_net_gated(const hipt_clam_weights* w, const void* x, int N, float* A, void* workspace, size_t ws_bytes,
+                        void* stream) {
+    int rc = check_clam(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(x && A && N > 0, "attn_net_gated: null/empty input");
+    const size_t need = al256((size_t)N * 2 * w->s2 * 4);
+    if (ws_bytes < need || ((uintptr_t)workspace & 255)) {
+        hipt_set_error("attn_net_gated: workspace %zu B too small / unaligned (need %zu)", ws_bytes, need);
+        return HIPT_E_WORKSPACE;
+    }
+    return gated_scores(w, x, w->dtype, N, (float*)workspace, nullptr, A, S(stream));
+}
+
+int hipt_clam_gather_h1(const hipt_clam_weights* w, const void* bag, const int64_t* idx, int n_idx, float* out, void* stream) {
+    int rc = check_clam(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(bag && idx && out && n_idx > 0, "clam_gather_h1: null/empty argument");
+    return hipt_gather_h1_launch(w, bag, idx, n_idx, out, S(stream));
+}
+
+}  // extern "C"

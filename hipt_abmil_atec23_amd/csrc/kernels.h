@@ -1,0 +1,55 @@
+// Internal (library-private) launch interface between capi.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hipt_abmil.h"
+
+enum { ALOAD_PLAIN = 0, ALOAD_IM2COL = 1 };
+enum { EPI_ROWMAP = 32 };  // internal epilogue flag: token rows -> [CLS]-skipping rows, + pos table
+
+struct GemmParams {
+    const void* A;
+    int64_t lda;
+    const void* W;
+    int64_t ldw;
+    int M, N, K;
+    const float* bias;
+    const float* resid;
+    void* out;
+    int64_t ldc;
+    // EPI_ROWMAP
+    const float* pos;
+    int rows_per_seq;
+    // ALOAD_IM2COL
+    hipt_image_layout im;
+    int im_nty, im_ntx, im_seq0;
+};
+
+int hipt_gemm_launch(const GemmParams& p, int dtype, int aload, int flags, hipStream_t st);
+
+int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, const float* b, void* out, int out_dtype,
+                          int64_t out_stride, int rows, int D, float eps, hipStream_t st);
+
+int hipt_attention_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale,
+                          int dtype, hipStream_t st);
+
+// x[s, 0, :] = cls + pos[0]  for s in [0, nseq)
+int hipt_cls_init_launch(float* x, const float* cls, const float* pos, int nseq, int ntok, int D, hipStream_t st);
+// fp32 -> bf16 elementwise (n % 8 == 0)
+int hipt_f32_to_bf16_launch(const float* in, void* out, int64_t n, hipStream_t st);
+
+// ---- CLAM / ABMIL ----
+bool hipt_clam_fused_supported(const hipt_clam_weights* w);
+int hipt_clam_fused_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw,
+                           float* partials, int* n_partials, hipStream_t st);
+int hipt_clam_combine_launch(const float* partials, int G, const hipt_clam_weights* w, float* M, float* logits,
+                             float* Y_prob, int64_t* Y_hat, hipStream_t st);
+int hipt_gate_launch(const float* ab, int64_t ld, int N, int S2, const float* wc, const float* bc, float* A,
+                     hipStream_t st);
+int hipt_small_ab_launch(const void* x, int xdtype, int N, int S1, int S2x2, const void* wab, int wdtype,
+                         const float* bab, float* ab, hipStream_t st);
+int hipt_pool_launch(const float* A, const float* h1, int N, int S1, float* gmax, float* partials, int* n_partials,
+                     hipStream_t st);
+int hipt_gather_h1_launch(const hipt_clam_weights* w, const void* bag, const int64_t* idx, int n_idx, float* out,
+                          hipStream_t st);

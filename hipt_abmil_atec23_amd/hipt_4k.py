@@ -1,0 +1,104 @@
+"""HIPT_4K host mirror (reference: ``HIPT_4K/hipt_4k.py:31-118, 308-330``).
+
+``HIPT_4K.forward`` keeps the reference contract — ``x [1,3,W',H'] -> [1,192]`` on ``device4k`` —
+but the whole region is processed by ONE library call when both ViTs share a device: centre crop,
+patchify (fused into the patch-embedding addressing), ViT-256 over all 256x256 patches, the
+[CLS] grid handed to ViT-4K on device (the reference's GPU->CPU->GPU hop of cls256,
+hipt_4k.py:70,74, is gone), ViT-4K.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native as N
+from . import functional as Fn
+from .hipt_model_utils import get_vit256, get_vit4k
+
+
+def center_crop_box(size: int, crop: int) -> int:
+    """torchvision.transforms.CenterCrop offset: int(round((size - crop) / 2.0))."""
+    return int(round((size - crop) / 2.0))
+
+
+class HIPT_4K(torch.nn.Module):
+    """Hierarchical ViT feature extractor for [256x256]-patch regions (hipt_4k.py:31-46)."""
+
+    def __init__(self, model256_path: str = '../Checkpoints/vit256_small_dino.pth',
+                 model4k_path: str = '../Checkpoints/vit4k_xs_dino.pth',
+                 device256=torch.device('cuda:0'), device4k=torch.device('cuda:1'), compute_dtype=None):
+        super().__init__()
+        self.model256 = get_vit256(pretrained_weights=model256_path).to(device256)
+        self.model4k = get_vit4k(pretrained_weights=model4k_path).to(device4k)
+        self.device256 = torch.device(device256)
+        self.device4k = torch.device(device4k)
+        self.chunk = 0  # patches per ViT-256 pass (0 = library default)
+        if compute_dtype is not None:
+            self.set_compute_dtype(compute_dtype)
+
+    def set_compute_dtype(self, name: str):
+        self.model256.set_compute_dtype(name)
+        self.model4k.set_compute_dtype(name)
+        return self
+
+    # ---- hipt_4k.py:308-330 -------------------------------------------------------------
+    def prepare_img_tensor(self, img: torch.Tensor, patch_size=256):
+        b, c, w, h = img.shape
+        W, H = w - w % patch_size, h - h % patch_size
+        if (W, H) != (w, h):
+            t, l = center_crop_box(w, W), center_crop_box(h, H)
+            img = img[:, :, t:t + W, l:l + H]
+        return img, w // patch_size, h // patch_size
+
+    def _same_device(self) -> bool:
+        d256 = next(self.model256.parameters()).device
+        d4k = next(self.model4k.parameters()).device
+        return d256 == d4k
+
+    def _run(self, x: torch.Tensor, want_cls256: bool):
+        batch, w_256, h_256 = self.prepare_img_tensor(x)
+        if batch.shape[0] != 1:
+            raise ValueError("HIPT_4K.forward takes one region at a time ([1,3,W,H]), as the reference does "
+                             "(hipt_4k.py:73 reshapes the patch features to one grid)")
+        if w_256 == 0 or h_256 == 0:
+            raise ValueError(f"region {tuple(x.shape)} is smaller than one 256x256 patch")
+        d256 = next(self.model256.parameters()).device
+        d4k = next(self.model4k.parameters()).device
+        region = batch.to(d256, non_blocking=True).detach().float().contiguous()
+        N.require_cuda(region, "HIPT_4K")
+        nseq = w_256 * h_256
+        W, H = region.shape[2], region.shape[3]
+        if d256 == d4k:
+            m256, m4k = self.model256, self.model4k
+            pk256 = m256._packed_for(m256._pos_for(256, 256, 256))
+            pk4k = m4k._packed_for(m4k._pos_for(nseq, w_256, h_256))
+            out = torch.empty((1, pk4k.w.dim), dtype=torch.float32, device=d4k)
+            cls256 = torch.empty((nseq, pk256.w.dim), dtype=torch.float32, device=d256) if want_cls256 else None
+            need = N.lib().hipt_hipt4k_workspace_bytes(pk256.ref, pk4k.ref, w_256, h_256, self.chunk)
+            ws = Fn.workspace(d256, need)
+            N.call("hipt_hipt4k_forward", pk256.ref, pk4k.ref, N.ptr(region), W, H, self.chunk, N.ptr(cls256), N.ptr(out),
+                   N.ptr(ws), ws.numel(), N.stream_ptr(d256))
+            return out, cls256
+        # two-device placement (hipt_4k.py:39-46): ViT-256 on device256, grid copied to device4k
+        lay = N.ImageLayout(w_256, h_256, 256, 256, H, W * H, 3 * W * H)
+        cls256 = self.model256.forward_features(region, layout=lay, nseq=nseq, chunk=self.chunk)
+        tokens = cls256.to(d4k, non_blocking=True).view(1, nseq, -1)
+        return self.model4k.forward_tokens(tokens, w_256, h_256), cls256
+
+    def forward(self, x):
+        """[1,3,W',H'] -> [1,192] ViT-4K [CLS] feature (hipt_4k.py:48-76)."""
+        return self._run(x, want_cls256=False)[0]
+
+    def forward_asset_dict(self, x: torch.Tensor):
+        """hipt_4k.py:79-118: intermediate features as numpy arrays."""
+        out, cls256 = self._run(x, want_cls256=True)
+        f256 = cls256.detach().cpu()
+        mean256 = f256.mean(dim=0).unsqueeze(dim=0)
+        f4k = out.detach().cpu()
+        return {
+            'features_cls256': f256.numpy(),
+            'features_mean256': mean256.numpy(),
+            'features_cls4k': f4k.numpy(),
+            'features_mean256_cls4k': torch.cat([mean256, f4k], dim=1).numpy(),
+        }

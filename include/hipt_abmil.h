@@ -1,0 +1,216 @@
+/*
+ * hipt_abmil.h — C ABI of libhipt_abmil.so (gfx950 / MI355X).
+ *
+ * The reference (scjjb/HIPT_ABMIL_ATEC23) is pure Python on torch.nn; it has no native
+ * boundary of its own.  This header is the boundary the build introduces UNDER the
+ * reference's Python call surface: each entry point replaces the
+ * stock-PyTorch op sequence of one reference function, cited per declaration as
+ * file:line relative to the reference checkout.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch-allocated); the
+ *     library allocates nothing persistent and keeps no state between calls;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL =
+ *     the default stream) and returns immediately: no host synchronisation, no
+ *     allocation, so calls may be captured into a hipGraph;
+ *   - return value: HIPT_OK (0), or a negative HIPT_E_* code; the library never throws
+ *     or aborts.  hipt_last_error() returns a static message for the calling thread;
+ *   - `dtype` selects the arithmetic type of the GEMM operands: HIPT_F32 (exact fp32 MFMA,
+ *     the reference's numerics, parity 1e-4) or HIPT_BF16 (bf16 operands, fp32 accumulate).
+ *     LayerNorm statistics, softmax, biases, the residual stream and all outputs are fp32
+ *     in both modes;
+ *   - matrices are row-major; Linear weights keep torch's [out_features, in_features] layout.
+ */
+#ifndef HIPT_ABMIL_H
+#define HIPT_ABMIL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPT_ABI_VERSION 1
+
+enum { HIPT_F32 = 0, HIPT_BF16 = 1 };
+
+enum {
+    HIPT_OK = 0,
+    HIPT_E_BADARG = -1,      /* shape / dtype / alignment the kernels do not support */
+    HIPT_E_WORKSPACE = -2,   /* workspace too small */
+    HIPT_E_LAUNCH = -3,      /* hipLaunch / hip runtime error (see hipt_last_error) */
+    HIPT_E_UNSUPPORTED = -4  /* valid request outside the implemented envelope */
+};
+
+int hipt_abi_version(void);
+const char* hipt_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Transformer block weights: Block / Attention / Mlp
+ * (HIPT_4K/vision_transformer.py:88-152, duplicated HIPT_4K/vision_transformer4k.py:94-158).
+ * GEMM matrices are in `dtype`; LayerNorm affine terms and all biases are fp32.
+ * ---------------------------------------------------------------------------------- */
+typedef struct hipt_block_weights {
+    const float* ln1_w;  const float* ln1_b;    /* blocks.i.norm1.{weight,bias}      [D]     */
+    const void*  qkv_w;  const float* qkv_b;    /* blocks.i.attn.qkv.{weight,bias}   [3D,D]  */
+    const void*  proj_w; const float* proj_b;   /* blocks.i.attn.proj.{weight,bias}  [D,D]   */
+    const float* ln2_w;  const float* ln2_b;    /* blocks.i.norm2.{weight,bias}      [D]     */
+    const void*  fc1_w;  const float* fc1_b;    /* blocks.i.mlp.fc1.{weight,bias}    [Dh,D]  */
+    const void*  fc2_w;  const float* fc2_b;    /* blocks.i.mlp.fc2.{weight,bias}    [D,Dh]  */
+} hipt_block_weights;
+
+/* One ViT (ViT-256 `vit_small` or ViT-4K `vit4k_xs`, or any width the classes are built with).
+ * `pos` is the ALREADY INTERPOLATED positional table for this token grid
+ * (interpolate_pos_encoding, vision_transformer.py:213-233): input independent, computed once
+ * on the host side with the reference's exact F.interpolate call and cached. */
+typedef struct hipt_vit_weights {
+    int32_t dtype;        /* HIPT_F32 | HIPT_BF16 (type of embed_w and of the block GEMM matrices) */
+    int32_t dim;          /* D: 384 (ViT-256) / 192 (ViT-4K); multiple of 32                        */
+    int32_t depth;        /* number of blocks                                                     */
+    int32_t heads;        /* D / heads must be 32 or 64                                           */
+    int32_t hidden;       /* MLP hidden width (4*D)                                               */
+    int32_t ntok;         /* tokens per sequence incl. [CLS] (257); <= 288                        */
+    int32_t embed_k;      /* K of the embedding GEMM: 3*16*16 = 768 (ViT-256) / 384 (ViT-4K phi)   */
+    float   ln_eps;       /* eps of every LayerNorm (1e-6 for vit_small / vit4k_xs)                 */
+    const void*  embed_w; /* patch_embed.proj.weight viewed [D, 768]  /  phi.0.weight [D, 384]     */
+    const float* embed_b; /* patch_embed.proj.bias / phi.0.bias                                   */
+    const float* cls;     /* cls_token [D]                                                        */
+    const float* pos;     /* interpolated pos_embed [ntok, D]                                     */
+    const float* norm_w;  const float* norm_b;     /* final norm                                  */
+    const hipt_block_weights* blocks;              /* HOST array of `depth` entries               */
+} hipt_vit_weights;
+
+/* Where the 16x16-pixel tokens of sequence b live inside the input image tensor
+ * (PatchEmbed Conv2d k16 s16, vision_transformer.py:155-170, fused with the
+ * unfold/rearrange patchify of hipt_4k.py:64-65):
+ *   pixel(b, c, y, x) = img[ (b / (grid_w*grid_h)) * batch_stride + c * chan_stride
+ *                            + (((b / grid_h) % grid_w) * patch_h + y) * row_stride
+ *                            + (b % grid_h) * patch_w + x ]
+ * A plain batch [B,3,w,h]: grid 1x1, patch_h=w, patch_w=h, row_stride=h, chan_stride=w*h,
+ * batch_stride=3*w*h.  A region [1,3,W,H] cut into 256x256 patches: grid (W/256)x(H/256),
+ * patch 256x256, row_stride=H, chan_stride=W*H. */
+typedef struct hipt_image_layout {
+    int32_t grid_w, grid_h;      /* patch grid per batch item (w_256, h_256)       */
+    int32_t patch_h, patch_w;    /* pixels per patch along dim2 / dim3 (multiples of 16) */
+    int64_t row_stride, chan_stride, batch_stride; /* in elements                  */
+} hipt_image_layout;
+
+/* ---- fine-grained operators (also the units the parity tests exercise) ---- */
+
+/* nn.LayerNorm(D, eps) over rows (vision_transformer.py:138,142,195).  x fp32 rows of D with
+ * stride x_stride; out rows in out_dtype with stride out_stride.  D % 64 == 0, D <= 2048. */
+int hipt_layernorm(const float* x, int64_t x_stride, const float* w, const float* b,
+                   void* out, int out_dtype, int64_t out_stride, int rows, int D, float eps,
+                   void* stream);
+
+/* out = epilogue(A[M,K] @ W[N,K]^T + bias)  — nn.Linear (vision_transformer.py:93-95,114,116).
+ * flags: bit0 GELU(erf) after bias, bit1 add fp32 residual `resid` (ld = ldc), bit2 output fp32
+ * (else `dtype`), bit4 ReLU after bias.  A and W are `dtype`; K % (HIPT_F32 ? 32 : 64) == 0,
+ * N % 4 == 0, 16-byte aligned rows. */
+enum { HIPT_EPI_GELU = 1, HIPT_EPI_RESID = 2, HIPT_EPI_OUT_F32 = 4, HIPT_EPI_RELU = 16 };
+int hipt_linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                const float* resid, void* out, int64_t ldc, int M, int N, int K, int dtype,
+                int flags, void* stream);
+
+/* Attention core of Attention.forward (vision_transformer.py:119-128): for each (b, head)
+ * softmax(q k^T * scale) v with q,k,v read in place from the qkv projection output
+ * qkv[B, ntok, 3, heads, dh] (`dtype`); out[B, ntok, heads*dh] (`dtype`).  If `probs` is not
+ * NULL the [B, heads, ntok, ntok] fp32 softmax probabilities are also written (the tensor
+ * Block.forward(return_attention=True) returns, :148-149).  dh in {32, 64}; ntok <= 288. */
+int hipt_attention(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh,
+                   float scale, int dtype, void* stream);
+
+/* ---- ViT forward (VisionTransformer.forward :248-253 / VisionTransformer4K.forward :241-246) ---- */
+
+/* Bytes of scratch hipt_vit*_prepare_tokens / hipt_vit_blocks need for `nseq` sequences processed at
+ * once (hipt_vit256_prepare_tokens additionally needs the bf16 copy of the image tensor in
+ * HIPT_BF16 mode: + 2 bytes per image element it addresses). */
+size_t hipt_vit_workspace_bytes(const hipt_vit_weights* w, int nseq);
+/* Scratch of the whole-forward calls below (residual stream + block scratch + bf16 input copy). */
+size_t hipt_vit256_forward_workspace_bytes(const hipt_vit_weights* w, const hipt_image_layout* lay,
+                                           int nseq, int chunk);
+size_t hipt_vit4k_forward_workspace_bytes(const hipt_vit_weights* w, int nseq);
+
+/* prepare_tokens for ViT-256 (vision_transformer.py:235-246): patchify + Conv2d(3,D,16,16) +
+ * [CLS] + positional table.  images: fp32, addressed through `lay`; x: fp32 [nseq, ntok, D]. */
+int hipt_vit256_prepare_tokens(const hipt_vit_weights* w, const float* images,
+                               const hipt_image_layout* lay, int seq0, int nseq, float* x,
+                               void* workspace, size_t ws_bytes, void* stream);
+
+/* prepare_tokens for ViT-4K (vision_transformer4k.py:223-239): phi = Linear(384,D)+GELU, [CLS],
+ * positional table.  tokens_in: fp32 [nseq, ntok-1, embed_k] token-major
+ * (= x.flatten(2,3).transpose(1,2)); x: fp32 [nseq, ntok, D]. */
+int hipt_vit4k_prepare_tokens(const hipt_vit_weights* w, const float* tokens_in, int nseq, float* x,
+                              void* workspace, size_t ws_bytes, void* stream);
+
+/* Run blocks [blk_begin, blk_end) in place on x (Block.forward :146-152).  If probs != NULL the
+ * last block of the range stops after its attention and only writes the probabilities
+ * (get_last_selfattention :255-262); x then holds the input of that block. */
+int hipt_vit_blocks(const hipt_vit_weights* w, float* x, int nseq, int blk_begin, int blk_end,
+                    float* probs, void* workspace, size_t ws_bytes, void* stream);
+
+/* Final LayerNorm; cls_only=1 -> out[nseq, D] = norm(x)[:,0] (:252-253), else out[nseq, ntok, D]
+ * (get_intermediate_layers :264-272). */
+int hipt_vit_head(const hipt_vit_weights* w, const float* x, int nseq, int cls_only, float* out,
+                  void* stream);
+
+/* Whole ViT-256 forward over nseq patches in chunks of `chunk` sequences (chunk <= 0: library
+ * default) -> out[nseq, D] fp32. */
+int hipt_vit256_forward(const hipt_vit_weights* w, const float* images, const hipt_image_layout* lay,
+                        int nseq, int chunk, float* out, void* workspace, size_t ws_bytes, void* stream);
+
+/* Whole ViT-4K forward -> out[nseq, D] fp32. */
+int hipt_vit4k_forward(const hipt_vit_weights* w, const float* tokens_in, int nseq, float* out,
+                       void* workspace, size_t ws_bytes, void* stream);
+
+/* HIPT_4K.forward (HIPT_4K/hipt_4k.py:48-76) for ONE region already cropped to multiples of 256:
+ * region fp32 [1,3,W,H] -> cls256[w_256*h_256, 384] (kept on device, no CPU hop) -> out[1,192].
+ * cls256_out may be NULL.  workspace >= hipt_hipt4k_workspace_bytes(). */
+size_t hipt_hipt4k_workspace_bytes(const hipt_vit_weights* w256, const hipt_vit_weights* w4k,
+                                   int w_256, int h_256, int chunk);
+int hipt_hipt4k_forward(const hipt_vit_weights* w256, const hipt_vit_weights* w4k,
+                        const float* region, int W, int H, int chunk, float* cls256_out, float* out,
+                        void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * CLAM_SB / ABMIL gated-attention pooling (models/model_clam.py:41-64, 77-191)
+ * ---------------------------------------------------------------------------------- */
+typedef struct hipt_clam_weights {
+    int32_t dtype;            /* type of w1 / wab (and of the bag)                              */
+    int32_t s0, s1, s2;       /* size_dict entry [S0,S1,S2] (model_clam.py:81)                  */
+    int32_t n_classes;        /* bag classifier outputs                                         */
+    int32_t reserved;
+    const void*  w1;  const float* b1;     /* attention_net.0: Linear(S0,S1) (+ReLU)  [S1,S0]     */
+    const void*  wab; const float* bab;    /* attention_a.0 / attention_b.0 stacked [2*S2,S1]:
+                                              rows [0,S2) = a, rows [S2,2*S2) = b; bias likewise */
+    const float* wc;  const float* bc;     /* attention_c Linear(S2,1): [S2], [1]               */
+    const float* wcls; const float* bcls;  /* classifiers Linear(S1,C): [C,S1], [C]             */
+} hipt_clam_weights;
+
+size_t hipt_clam_workspace_bytes(const hipt_clam_weights* w, int N);
+
+/* CLAM_SB.forward (model_clam.py:147-191, eval path without instance_eval), one bag:
+ *   h1 = ReLU(bag W1^T + b1); A_raw = (tanh(h1 Wa^T+ba) * sigmoid(h1 Wb^T+bb)) wc + bc;
+ *   M = softmax_N(A_raw) h1; logits = M Wcls^T + bcls; Y_prob = softmax(logits);
+ *   Y_hat = argmax(logits) (int64, first maximum, as torch.topk(logits,1)).
+ * bag: [N,S0] in w->dtype.  Outputs fp32: A_raw[N], M[S1], logits[C], Y_prob[C]; Y_hat int64[1].
+ * attention_only != 0 skips pooling (only A_raw is written; model_clam.py:151-152). */
+int hipt_clam_sb_forward(const hipt_clam_weights* w, const void* bag, int N, int attention_only,
+                         float* A_raw, float* M, float* logits, float* Y_prob, int64_t* Y_hat,
+                         void* workspace, size_t ws_bytes, void* stream);
+
+/* Attn_Net_Gated.forward (model_clam.py:59-64) on its own: A[N] from x[N,L]
+ * (w->s1 = L, w->s2 = D; w1/b1/wcls unused). */
+int hipt_attn_net_gated(const hipt_clam_weights* w, const void* x, int N, float* A,
+                        void* workspace, size_t ws_bytes, void* stream);
+
+/* inst_eval support (model_clam.py:116-145): h1 rows for `n_idx` selected instances,
+ * out[n_idx, S1] fp32 = ReLU(bag[idx] W1^T + b1). */
+int hipt_clam_gather_h1(const hipt_clam_weights* w, const void* bag, const int64_t* idx, int n_idx,
+                        float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPT_ABMIL_H */

@@ -1,0 +1,426 @@
+"""GPU parity tests (-m gpu): the HIP path (through the C ABI) against the numpy oracle on the same
+seeded inputs and against the golden vectors captured from the reference modules.
+
+Tolerances (BASELINE.json north_star): fp32 mode 1e-4 absolute on attention weights / logits /
+features, indices bit-exact.  bf16 mode cannot meet 1e-4 (CPU bf16 autocast of the
+reference itself is 2.4e-2 max-abs off); its bar is rel-L2 <= 2e-2 and cosine >= 0.999 vs the fp32
+golden, stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from hipt_abmil_atec23_amd import _native as N
+from hipt_abmil_atec23_amd import functional as Fn
+from hipt_abmil_atec23_amd import synth
+from oracle import hipt_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda:0"
+ROWS = [0, 1, 128, 256]
+
+
+def md(a, b):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    return float(np.max(np.abs(a.astype(np.float64) - np.asarray(b, np.float64))))
+
+
+def rel_l2(a, b):
+    a = a.detach().float().cpu().numpy().astype(np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def cosine(a, b):
+    a = a.detach().float().cpu().numpy().astype(np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def vit256():
+    from hipt_abmil_atec23_amd.vision_transformer import vit_small
+    m = vit_small(patch_size=16, num_classes=0)
+    m.load_state_dict(synth.make_state_dict(synth.vit_param_specs("vit256"), 256))
+    return m.eval().to(DEV)
+
+
+@pytest.fixture(scope="module")
+def vit4k():
+    from hipt_abmil_atec23_amd.vision_transformer4k import vit4k_xs
+    m = vit4k_xs(num_classes=0)
+    m.load_state_dict(synth.make_state_dict(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096))
+    return m.eval().to(DEV)
+
+
+def test_native_library_is_the_path():
+    assert N.lib().hipt_abi_version() == N.ABI_VERSION
+    before = N.calls
+    x = synth.hash_uniform_torch((8, 64), 1, device=DEV)
+    Fn.layernorm(x, torch.ones(64, device=DEV), torch.zeros(64, device=DEV))
+    assert N.calls == before + 1
+
+
+# ---------------------------------------------------------------------------------------------
+# operators
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,D", [(1, 64), (257, 192), (1000, 384), (5, 1024)])
+def test_layernorm(rows, D):
+    x = synth.hash_uniform_np((rows, D), 31, 2.0, 0.3)
+    w = synth.hash_uniform_np((D,), 32, 0.1, 1.0)
+    b = synth.hash_uniform_np((D,), 33, 0.05)
+    ref = O.layer_norm(x, w, b)
+    out = Fn.layernorm(T(x), T(w), T(b), 1e-6)
+    assert md(out, ref) < 1e-5
+    out16 = Fn.layernorm(T(x), T(w), T(b), 1e-6, out_dtype=N.HIPT_BF16)
+    assert out16.dtype == torch.bfloat16 and md(out16, ref) < 3e-2
+
+
+@pytest.mark.parametrize("M,Nn,K", [(1, 64, 64), (257, 576, 192), (300, 384, 1536), (1000, 1152, 384), (130, 8, 192)])
+@pytest.mark.parametrize("mode", ["plain", "gelu", "relu", "resid"])
+def test_linear_fp32(M, Nn, K, mode):
+    a = synth.hash_uniform_np((M, K), 41)
+    w = synth.hash_uniform_np((Nn, K), 42, 0.05)
+    b = synth.hash_uniform_np((Nn,), 43, 0.1)
+    r = synth.hash_uniform_np((M, Nn), 44)
+    ref = O.linear(a.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    kw = {}
+    if mode == "gelu":
+        ref, kw = O.gelu(ref), dict(gelu=True)
+    elif mode == "relu":
+        ref, kw = np.maximum(ref, 0), dict(relu=True)
+    elif mode == "resid":
+        ref, kw = ref + r, dict(resid=T(r))
+    out = Fn.linear(T(a), T(w), T(b), dtype=N.HIPT_F32, **kw)
+    assert md(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("M,Nn,K", [(257, 576, 192), (1000, 1152, 384), (300, 384, 1536)])
+def test_linear_bf16(M, Nn, K):
+    a = synth.hash_uniform_np((M, K), 41)
+    w = synth.hash_uniform_np((Nn, K), 42, 0.05)
+    b = synth.hash_uniform_np((Nn,), 43, 0.1)
+    # reference on the bf16-rounded operands in fp64: isolates MFMA accumulation from input rounding
+    a16 = T(a).bfloat16().float().cpu().numpy().astype(np.float64)
+    w16 = T(w).bfloat16().float().cpu().numpy().astype(np.float64)
+    ref = O.linear(a16, w16, b.astype(np.float64))
+    out = Fn.linear(T(a), T(w), T(b), dtype=N.HIPT_BF16)
+    assert md(out, ref) < 1e-4
+    out16 = Fn.linear(T(a), T(w), T(b), dtype=N.HIPT_BF16, gelu=True, out_f32=False)
+    assert out16.dtype == torch.bfloat16 and rel_l2(out16, O.gelu(ref)) < 5e-3
+
+
+@pytest.mark.parametrize("B,ntok,heads,dh", [(2, 257, 6, 64), (3, 257, 6, 32), (2, 25, 2, 32), (1, 13, 6, 32), (2, 1, 2, 64),
+                                               (1, 288, 3, 64)])
+def test_attention_fp32(B, ntok, heads, dh):
+    C = heads * dh
+    qkv = synth.hash_uniform_np((B, ntok, 3 * C), 51, 1.5)
+    scale = dh ** -0.5
+    q, k, v = np.transpose(qkv.astype(np.float64).reshape(B, ntok, 3, heads, dh), (2, 0, 3, 1, 4))
+    p = O.softmax(q @ k.transpose(0, 1, 3, 2) * scale, axis=-1)
+    ref = (p @ v).transpose(0, 2, 1, 3).reshape(B, ntok, C)
+    out, probs = Fn.attention(T(qkv), heads, scale, dtype=N.HIPT_F32, return_probs=True)
+    assert md(probs, p) < 1e-5
+    assert md(out, ref) < 2e-5
+    out2, none = Fn.attention(T(qkv), heads, scale, dtype=N.HIPT_F32)
+    assert none is None and torch.equal(out, out2)
+
+
+def test_attention_rescue_large_logits():
+    """a spiked key row forces max-subtraction to matter (exp overflow without it)"""
+    B, ntok, heads, dh = 1, 257, 6, 64
+    qkv = synth.hash_uniform_np((B, ntok, 3 * heads * dh), 52, 1.0)
+    qkv[0, 100, heads * dh:2 * heads * dh] *= 60.0  # key 100 of every head
+    scale = dh ** -0.5
+    q, k, v = np.transpose(qkv.astype(np.float64).reshape(B, ntok, 3, heads, dh), (2, 0, 3, 1, 4))
+    p = O.softmax(q @ k.transpose(0, 1, 3, 2) * scale, axis=-1)
+    ref = (p @ v).transpose(0, 2, 1, 3).reshape(B, ntok, heads * dh)
+    out, probs = Fn.attention(T(qkv), heads, scale, dtype=N.HIPT_F32, return_probs=True)
+    assert torch.isfinite(out).all() and md(probs, p) < 1e-5 and md(out, ref) < 5e-5
+
+
+@pytest.mark.parametrize("B,ntok,heads,dh", [(2, 257, 6, 64), (2, 257, 6, 32), (2, 25, 2, 32)])
+def test_attention_bf16(B, ntok, heads, dh):
+    C = heads * dh
+    qkv = synth.hash_uniform_np((B, ntok, 3 * C), 51, 1.5)
+    q16 = T(qkv).bfloat16().float().cpu().numpy().astype(np.float64)
+    scale = dh ** -0.5
+    q, k, v = np.transpose(q16.reshape(B, ntok, 3, heads, dh), (2, 0, 3, 1, 4))
+    p = O.softmax(q @ k.transpose(0, 1, 3, 2) * scale, axis=-1)
+    ref = (p @ v).transpose(0, 2, 1, 3).reshape(B, ntok, C)
+    out, probs = Fn.attention(T(qkv), heads, scale, dtype=N.HIPT_BF16, return_probs=True)
+    assert md(probs, p) < 1e-5  # probabilities are fp32 in both modes
+    assert rel_l2(out, ref) < 1e-2  # P and O are rounded to bf16
+
+
+# ---------------------------------------------------------------------------------------------
+# ViT-256 / ViT-4K / HIPT_4K vs goldens from the reference
+# ---------------------------------------------------------------------------------------------
+def test_vit256_fp32_vs_reference_golden(vit256):
+    g = golden("vit256_full")
+    vit256.set_compute_dtype("fp32")
+    x = synth.hash_uniform_torch((2, 3, 256, 256), 2, device=DEV)
+    tok = vit256.prepare_tokens(x)
+    assert md(tok[:, ROWS], g["tokens_rows"]) < TOL
+    assert md(vit256.interpolate_pos_encoding(tok, 256, 256), g["pos"]) < 1e-5
+    out = vit256(x)
+    assert out.shape == (2, 384) and md(out, g["out"]) < TOL
+    attn = vit256.get_last_selfattention(x)
+    assert attn.shape == (2, 6, 257, 257)
+    assert md(attn[:, :, 0], g["attn_cls"]) < TOL and md(attn[:, :, 200], g["attn_row200"]) < TOL
+    # BASELINE config 2: a single 256x256 patch
+    assert md(vit256(x[:1]), g["out"][:1]) < TOL
+    # block-level API (Block.forward) agrees with the golden taps
+    t = tok
+    for i, blk in enumerate(vit256.blocks):
+        t = blk(t)
+        if i in (0, 5, 11):
+            assert md(t[:, ROWS], g[f"blk{i}_rows"]) < TOL, i
+    inter = vit256.get_intermediate_layers(x, n=1)
+    assert md(inter[0][:, 0], g["out"]) < TOL
+
+
+def test_vit256_bf16_vs_reference_golden(vit256):
+    g = golden("vit256_full")
+    vit256.set_compute_dtype("bf16")
+    try:
+        x = synth.hash_uniform_torch((2, 3, 256, 256), 2, device=DEV)
+        out = vit256(x)
+        assert rel_l2(out, g["out"]) < 2e-2 and cosine(out, g["out"]) > 0.999
+        attn = vit256.get_last_selfattention(x)
+        assert md(attn[:, :, 0], g["attn_cls"]) < 5e-3
+    finally:
+        vit256.set_compute_dtype("fp32")
+
+
+def test_vit_reduced_nonsquare_fp32():
+    from functools import partial
+    from hipt_abmil_atec23_amd.vision_transformer import VisionTransformer
+    g = golden("vit_small_cfg")
+    cfg = dict(embed_dim=64, depth=2, num_heads=2)
+    m = VisionTransformer(patch_size=16, num_classes=0, mlp_ratio=4, qkv_bias=True,
+                          norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), **cfg)
+    m.load_state_dict(synth.make_state_dict(synth.vit_param_specs("vit256", **cfg), 64))
+    m = m.eval().to(DEV)
+    x = synth.hash_uniform_torch((2, 3, 64, 96), 22, device=DEV)
+    assert md(m.prepare_tokens(x), g["tokens"]) < 1e-5
+    assert md(m(x), g["out"]) < 1e-5
+    assert md(m.get_last_selfattention(x), g["attn"]) < 1e-5
+    assert md(torch.stack(m.get_intermediate_layers(x, n=2)), g["inter"]) < 1e-5
+    assert md(m.patch_embed(x), O.patch_embed(x.cpu().numpy(), m.patch_embed.proj.weight.detach().cpu().numpy(),
+                                              m.patch_embed.proj.bias.detach().cpu().numpy())) < 1e-5
+
+
+def test_vit4k_vs_reference_golden(vit4k):
+    g = golden("vit4k")
+    vit4k.set_compute_dtype("fp32")
+    g16 = synth.hash_uniform_torch((1, 384, 16, 16), 4, device=DEV)
+    g34 = synth.hash_uniform_torch((2, 384, 3, 4), 44, device=DEV)
+    assert md(vit4k.prepare_tokens(g16)[:, ROWS], g["tokens16_rows"]) < 1e-5
+    assert md(vit4k(g16), g["out16"]) < TOL
+    assert md(vit4k(g34), g["out34"]) < TOL
+    assert md(vit4k.get_last_selfattention(g16)[:, :, 0], g["attn_cls16"]) < TOL
+    vit4k.set_compute_dtype("bf16")
+    try:
+        o = vit4k(g16)
+        assert rel_l2(o, g["out16"]) < 2e-2 and cosine(o, g["out16"]) > 0.999
+    finally:
+        vit4k.set_compute_dtype("fp32")
+
+
+@pytest.fixture(scope="module")
+def hipt():
+    from hipt_abmil_atec23_amd import HIPT_4K
+    m = HIPT_4K(None, None, DEV, DEV)
+    m.model256.load_state_dict(synth.make_state_dict(synth.vit_param_specs("vit256"), 256))
+    m.model4k.load_state_dict(synth.make_state_dict(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096))
+    return m.eval().to(DEV)
+
+
+def test_hipt4k_small_region_fp32(hipt):
+    g = golden("hipt4k_1024x768")
+    hipt.set_compute_dtype("fp32")
+    x = synth.hash_uniform_torch((1, 3, 1024, 768), 3, device=DEV)
+    out = hipt(x)
+    assert out.shape == (1, 192) and out.device.type == "cuda"
+    assert md(out, g["out"]) < TOL
+    d = hipt.forward_asset_dict(x)
+    assert md(d["features_cls256"], g["cls256"]) < TOL  # patch order k = p1*h_256 + p2 (bit-exact index work)
+    assert md(d["features_cls4k"], g["out"]) < TOL
+    assert d["features_mean256_cls4k"].shape == (1, 576)
+    # chunked ViT-256 passes give the same answer
+    hipt.chunk = 5
+    try:
+        assert md(hipt(x), g["out"]) < TOL
+    finally:
+        hipt.chunk = 0
+    # centre crop to multiples of 256 (hipt_4k.py:308-330): a padded region reduces to the same crop
+    xp = torch.zeros((1, 3, 1024 + 100, 768 + 37), device=DEV)
+    xp[:, :, 50:50 + 1024, 18:18 + 768] = x
+    assert md(hipt(xp), g["out"]) < TOL
+
+
+def test_hipt4k_full_region_fp32_and_bf16(hipt):
+    """BASELINE config 3 shape: one 4096x4096 region = 256 patches -> ViT-4K over the 16x16 grid."""
+    g = golden("hipt4k_4096")
+    x = synth.hash_uniform_torch((1, 3, 4096, 4096), 3, device=DEV)
+    hipt.set_compute_dtype("fp32")
+    d = hipt.forward_asset_dict(x)
+    assert md(d["features_cls256"], g["cls256"]) < TOL
+    assert md(d["features_cls4k"], g["out"]) < TOL
+    hipt.set_compute_dtype("bf16")
+    try:
+        d = hipt.forward_asset_dict(x)
+        c = torch.from_numpy(d["features_cls256"])
+        o = torch.from_numpy(d["features_cls4k"])
+        assert rel_l2(c, g["cls256"]) < 2e-2 and cosine(c, g["cls256"]) > 0.999
+        assert rel_l2(o, g["out"]) < 3e-2 and cosine(o, g["out"]) > 0.999
+        # idempotence: same input, same bits
+        assert np.array_equal(hipt.forward_asset_dict(x)["features_cls4k"], d["features_cls4k"])
+    finally:
+        hipt.set_compute_dtype("fp32")
+
+
+# ---------------------------------------------------------------------------------------------
+# CLAM_SB / Attn_Net_Gated
+# ---------------------------------------------------------------------------------------------
+CLAM_CASES = [
+    ("clam_384_n2000", "hipt_384", (384, 128, 64), 384, (2000, 384), 1, 1, 8, False, 0.0),
+    ("clam_384_n777", "hipt_384", (384, 128, 64), 384, (777, 384), 11, 0, 8, False, 0.0),
+    ("clam_384_n1", [384, 128, 64], (384, 128, 64), 384, (1, 384), 12, None, 8, False, 0.0),
+    ("clam_hipt_big_n500", "hipt_big", (192, 128, 64), 192, (500, 192), 5, 1, 8, False, 0.0),
+    ("clam_hipt_smallest_n100", "hipt_smallest", (192, 8, 4), 8, (100, 192), 6, 0, 4, True, 0.0),
+    ("clam_small_dropout_n300", "small", (1024, 512, 256), 1024, (300, 1024), 7, None, 8, False, 0.25),
+]
+
+
+def make_clam(size_arg, size, base, k, subtyping, dropout):
+    from hipt_abmil_atec23_amd import CLAM_SB
+    m = CLAM_SB(gate=True, size_arg=size_arg, dropout=dropout, k_sample=k, n_classes=2, subtyping=subtyping)
+    m.load_state_dict(synth.make_state_dict(synth.clam_param_specs(size, dropout=dropout > 0), base), strict=True)
+    m.relocate()
+    return m.eval()
+
+
+@pytest.mark.parametrize("name,size_arg,size,base,shape,seed,label,k,subtyping,dropout", CLAM_CASES)
+def test_clam_sb_fp32_vs_reference_golden(name, size_arg, size, base, shape, seed, label, k, subtyping, dropout):
+    g = golden(name)
+    m = make_clam(size_arg, size, base, k, subtyping, dropout)
+    h = synth.hash_uniform_torch(shape, seed, device=DEV)
+    before = N.calls
+    with torch.no_grad():
+        logits, y_prob, y_hat, a_raw, res = m(h, return_features=True)
+        att = m(h, attention_only=True)
+    assert N.calls >= before + 2  # the HIP entry point ran (no PyTorch path)
+    assert a_raw.shape == (1, shape[0]) and md(a_raw, g["A_raw"]) < TOL
+    assert md(att, g["attention_only"]) < TOL
+    assert md(logits, g["logits"]) < TOL and md(y_prob, g["Y_prob"]) < TOL and md(res["features"], g["M"]) < TOL
+    assert y_hat.dtype == torch.int64 and np.array_equal(y_hat.cpu().numpy(), g["Y_hat"])  # bit-exact
+    if label is not None:
+        with torch.no_grad():
+            _, _, _, a2, r = m(h, label=torch.tensor([label], device=DEV), instance_eval=True)
+        A = torch.softmax(a2, dim=1)
+        assert np.array_equal(torch.topk(A, k)[1][-1].cpu().numpy(), g["top_p"])  # indices bit-exact
+        assert np.array_equal(torch.topk(-A, k, dim=1)[1][-1].cpu().numpy(), g["top_n"])
+        assert abs(float(r["instance_loss"]) - float(g["instance_loss"])) < TOL
+        assert np.array_equal(r["inst_preds"], g["inst_preds"]) and np.array_equal(r["inst_labels"], g["inst_labels"])
+
+
+def test_clam_sb_bf16_config1():
+    g = golden("clam_384_n2000")
+    m = make_clam("hipt_384", (384, 128, 64), 384, 8, False, 0.0).set_compute_dtype("bf16")
+    h = synth.hash_uniform_torch((2000, 384), 1, device=DEV)
+    with torch.no_grad():
+        logits, y_prob, y_hat, a_raw, res = m(h, return_features=True)
+    # bf16 operands: A_raw spans [-6.3, 3.3]; bar = 5e-2 abs on A_raw, 2e-2 rel-L2 on M, same argmax
+    assert md(a_raw, g["A_raw"]) < 5e-2
+    assert rel_l2(res["features"], g["M"]) < 2e-2 and md(logits, g["logits"]) < 2e-2
+    assert np.array_equal(y_hat.cpu().numpy(), g["Y_hat"])
+
+
+def test_attn_net_gated_vs_reference_golden():
+    from hipt_abmil_atec23_amd import Attn_Net_Gated
+    g = golden("attn_net_gated_384_256")
+    spec = {"attention_a.0.weight": ((256, 384), 0.09, 0.0), "attention_a.0.bias": ((256,), 0.02, 0.0),
+            "attention_b.0.weight": ((256, 384), 0.09, 0.0), "attention_b.0.bias": ((256,), 0.02, 0.0),
+            "attention_c.weight": ((1, 256), 0.3, 0.0), "attention_c.bias": ((1,), 0.02, 0.0)}
+    m = Attn_Net_Gated(L=384, D=256, dropout=0.0, n_classes=1)
+    m.load_state_dict(synth.make_state_dict(spec, 9))
+    m = m.eval().to(DEV)
+    h = synth.hash_uniform_torch((2000, 384), 1, device=DEV)
+    with torch.no_grad():
+        A, x = m(h)
+    assert x is h and A.shape == (2000, 1) and md(A, g["A"]) < TOL
+
+
+@pytest.mark.parametrize("dtype,tolA,tolM", [("fp32", 1e-4, 1e-4), ("bf16", 6e-2, 2e-2)])
+def test_clam_full_size_100k_properties(dtype, tolA, tolM):
+    """BASELINE config 4 shape (100 000 x 384): oracle on the full bag + size-independent properties."""
+    n = 100_000
+    m = make_clam("hipt_384", (384, 128, 64), 384, 8, False, 0.0).set_compute_dtype(dtype)
+    p = synth.make_params_np(synth.clam_param_specs((384, 128, 64)), 384)
+    h = synth.hash_uniform_torch((n, 384), 4, device=DEV)
+    with torch.no_grad():
+        logits, y_prob, y_hat, a_raw, res = m(h, return_features=True)
+    r = O.clam_sb_forward(h.cpu().numpy().astype(np.float64), {k: v.astype(np.float64) for k, v in p.items()})
+    assert md(a_raw, r["A_raw"]) < tolA
+    assert rel_l2(res["features"], r["M"]) < tolM and md(logits, r["logits"]) < max(tolM, 1e-4)
+    assert np.array_equal(y_hat.cpu().numpy(), r["Y_hat"])
+    assert abs(float(y_prob.sum()) - 1.0) < 1e-6
+    # rows are independent: a 2000-row prefix bag reproduces the same attention logits bit for bit
+    with torch.no_grad():
+        a_sub = m(h[:2000].contiguous(), attention_only=True)
+    assert torch.equal(a_sub[0], a_raw[0, :2000])
+    # pooling is permutation invariant
+    perm = torch.randperm(n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(0))
+    with torch.no_grad():
+        l2, _, _, a_p, res2 = m(h[perm].contiguous(), return_features=True)
+    assert torch.equal(a_p[0], a_raw[0, perm])
+    assert md(l2, logits.cpu().numpy()) < 1e-4 and md(res2["features"], res["features"].cpu().numpy()) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# boundary behaviour
+# ---------------------------------------------------------------------------------------------
+def test_errors_are_loud(vit256):
+    from hipt_abmil_atec23_amd import CLAM_SB
+    with pytest.raises(RuntimeError, match="HIP device"):
+        vit256(torch.zeros(1, 3, 256, 256))
+    with pytest.raises(ValueError):
+        vit256(torch.zeros(1, 4, 256, 256, device=DEV))
+    with pytest.raises(RuntimeError, match="envelope"):
+        vit256(torch.zeros(1, 3, 512, 512, device=DEV))  # 1025 tokens: outside the on-chip attention envelope
+    m = CLAM_SB(size_arg="hipt_384").eval().to(DEV)
+    with torch.no_grad():
+        with pytest.raises(ValueError):
+            m(torch.zeros(0, 384, device=DEV))
+        with pytest.raises(ValueError):
+            m(torch.zeros(10, 192, device=DEV))
+        with pytest.raises(RuntimeError, match="HIP device"):
+            m(torch.zeros(10, 384))
+    with pytest.raises(RuntimeError, match="libhipt_abmil"):
+        N.call("hipt_layernorm", None, 7, None, None, None, 0, 7, 1, 7, 1e-6, None)  # D % 64 != 0
+
+
+def test_dropin_install_reference_import_paths():
+    import hipt_abmil_atec23_amd as amd
+    amd.install()
+    try:
+        from HIPT_4K.hipt_4k import HIPT_4K  # extract_features_fp.py:15
+        from HIPT_4K.hipt_model_utils import eval_transforms  # extract_features_fp.py:16
+        from models.model_clam import CLAM_MB, CLAM_SB  # utils/core_utils.py:7
+        import HIPT_4K.vision_transformer as vits
+        import HIPT_4K.vision_transformer4k as vits4k
+        assert HIPT_4K is amd.HIPT_4K and CLAM_SB is amd.CLAM_SB and CLAM_MB is amd.CLAM_MB
+        assert vits.__dict__['vit_small'] and vits4k.__dict__['vit4k_xs']  # hipt_model_utils.py:54,91 lookups
+        t = eval_transforms()(np.full((4, 5, 3), 255, np.uint8))
+        assert t.shape == (3, 4, 5) and float(t.max()) == 1.0
+    finally:
+        from hipt_abmil_atec23_amd.dropin import uninstall
+        uninstall()
