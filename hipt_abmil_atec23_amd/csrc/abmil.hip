@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256, 2) void abmil_fused_kernel(const T* __restrict
                 for (int e = 0; e < 4; ++e) {
                     pf[e] = pack_bf16x2(p[2 * e], p[2 * e + 1]);
                     // the sum must use the SAME rounded weights as the MFMA so that M is a true convex mix
-                    const bf16x2 r = __builtin_bit_cast(bf16x2, pf[e]);
+                    const uint32_t packed = pf[e];  // scalar copy: never bit_cast a vector element in place
+                    const bf16x2 r = __builtin_bit_cast(bf16x2, packed);
                     lsum += (float)r[0] + (float)r[1];
                 }
                 const int r0 = mb + 4 * g + (li >> 2);

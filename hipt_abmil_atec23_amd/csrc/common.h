@@ -32,10 +32,11 @@ template <> struct Tr<float> {
     static constexpr int KB = 32;    // elements per 128-byte LDS row
     static constexpr int DT = HIPT_F32;
     static __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b) {
+        // NB: bit-cast the whole vector, not a[j]: __builtin_bit_cast on a vector-element lvalue
+        // reads element 0 (observed with ROCm 7.2 clang)
+        const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a[j]),
-                                                       __builtin_bit_cast(float, b[j]), acc, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc, 0, 0, 0);
     }
     static __device__ __forceinline__ float to_f(float v) { return v; }
     static __device__ __forceinline__ float from_f(float v) { return v; }
