@@ -54,6 +54,10 @@ _i, _i64, _p, _sz, _f = C.c_int, C.c_int64, C.c_void_p, C.c_size_t, C.c_float
 SIGNATURES = {
     "hipt_abi_version": (_i, []),
     "hipt_last_error": (C.c_char_p, []),
+    "hipt_profile_enable": (_i, [_i]),
+    "hipt_profile_categories": (_i, []),
+    "hipt_profile_category_name": (C.c_char_p, [_i]),
+    "hipt_profile_read": (_i, [_p, _p]),
     "hipt_layernorm": (_i, [_p, _i64, _p, _p, _p, _i, _i64, _i, _i, _f, _p]),
     "hipt_linear": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "hipt_attention": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
@@ -152,3 +156,15 @@ def require_cuda(t, what: str):
         raise RuntimeError(
             f"{what}: input is on {t.device}; hipt_abmil_atec23_amd runs only on a HIP device "
             f"(there is deliberately no CPU path — move the module and its inputs to 'cuda').")
+
+
+def profile_enable(on: bool = True) -> None:
+    check(lib().hipt_profile_enable(1 if on else 0), "hipt_profile_enable")
+
+
+def profile_read() -> dict:
+    """{category: (total_ms, launches)} since the last read (synchronises on the recorded events)."""
+    n = lib().hipt_profile_categories()
+    ms, cnt = (C.c_float * n)(), (C.c_int * n)()
+    check(lib().hipt_profile_read(C.cast(ms, C.c_void_p), C.cast(cnt, C.c_void_p)), "hipt_profile_read")
+    return {lib().hipt_profile_category_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n) if cnt[i]}

@@ -321,40 +321,60 @@ __global__ __launch_bounds__(256, 2) void abmil_fused_kernel(const T* __restrict
 }
 
 // Merge per-workgroup partials; bag classifier, softmax, argmax (model_clam.py:180-183).
-__global__ __launch_bounds__(256) void abmil_combine_kernel(const float* __restrict__ partials, int G, int S1,
-                                                            const float* __restrict__ wcls, const float* __restrict__ bcls,
-                                                            int C, float* __restrict__ M, float* __restrict__ logits,
-                                                            float* __restrict__ Y_prob, int64_t* __restrict__ Y_hat) {
-    extern __shared__ float sm[];  // [S1] M, [C] logits, scratch
-    float* Ms = sm;
-    float* Ls = sm + S1;
-    __shared__ float red[8];
-    const int tid = threadIdx.x, stride = 2 + S1;
+// One 1024-thread workgroup: the G rescale factors exp(m_g - m*) are computed once into LDS, then
+// thread (c, part) sums column c over every 8th partial (coalesced 4*S1-byte rows), LDS tree over parts.
+constexpr int CMB_MAXG = 1024;
+__global__ __launch_bounds__(1024) void abmil_combine_kernel(const float* __restrict__ partials, int G, int S1,
+                                                             const float* __restrict__ wcls, const float* __restrict__ bcls,
+                                                             int C, float* __restrict__ M, float* __restrict__ logits,
+                                                             float* __restrict__ Y_prob, int64_t* __restrict__ Y_hat) {
+    extern __shared__ float sm[];  // [CMB_MAXG] factors | [8*S1] column partial sums | [S1] M | [C] logits
+    float* Fs = sm;
+    float* Cs = Fs + CMB_MAXG;
+    float* Ms = Cs + 8 * S1;
+    float* Ls = Ms + S1;
+    __shared__ float red[16];
+    const int tid = threadIdx.x, stride = 2 + S1, wv = tid >> 6, ln = tid & 63;
     float mx = -INFINITY;
-    for (int gidx = tid; gidx < G; gidx += 256) mx = fmaxf(mx, partials[(int64_t)gidx * stride]);
+    for (int gi = tid; gi < G; gi += 1024) mx = fmaxf(mx, partials[(int64_t)gi * stride]);
     mx = wave_max(mx);
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    if (ln == 0) red[wv] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
     __syncthreads();
     float ls = 0.f;
-    for (int gidx = tid; gidx < G; gidx += 256)
-        ls += partials[(int64_t)gidx * stride + 1] * expf(partials[(int64_t)gidx * stride] - mx);
+    for (int gi = tid; gi < G; gi += 1024) {
+        const float f = expf(partials[(int64_t)gi * stride] - mx);
+        Fs[gi] = f;
+        ls += partials[(int64_t)gi * stride + 1] * f;
+    }
     ls = wave_sum(ls);
-    if ((tid & 63) == 0) red[tid >> 6] = ls;
+    if (ln == 0) red[wv] = ls;
     __syncthreads();
-    const float L = red[0] + red[1] + red[2] + red[3];
-    for (int c = tid; c < S1; c += 256) {
+    float L = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) L += red[i];
+    // column sums: S1 <= 128 columns x 8 parts = 1024 threads (wider S1: loop)
+    for (int c0 = 0; c0 < S1; c0 += 128) {
+        const int c = c0 + (tid & 127), part = tid >> 7;
         float a = 0.f;
-        for (int gidx = 0; gidx < G; ++gidx)
-            a += partials[(int64_t)gidx * stride + 2 + c] * expf(partials[(int64_t)gidx * stride] - mx);
+        if (c < S1)
+            for (int gi = part; gi < G; gi += 8) a += partials[(int64_t)gi * stride + 2 + c] * Fs[gi];
+        if (c < S1) Cs[part * S1 + c] = a;
+    }
+    __syncthreads();
+    for (int c = tid; c < S1; c += 1024) {
+        float a = 0.f;
+#pragma unroll
+        for (int part = 0; part < 8; ++part) a += Cs[part * S1 + c];
         a /= L;
         Ms[c] = a;
         M[c] = a;
     }
     __syncthreads();
-    const int wv = tid >> 6, ln = tid & 63;
-    for (int k = wv; k < C; k += 4) {
+    for (int k = wv; k < C; k += 16) {
         float a = 0.f;
         for (int c = ln; c < S1; c += 64) a += Ms[c] * wcls[(int64_t)k * S1 + c];
         a = wave_sum(a);
@@ -512,8 +532,10 @@ int hipt_clam_fused_launch(const hipt_clam_weights* w, const void* bag, int N, i
 
 int hipt_clam_combine_launch(const float* partials, int G, const hipt_clam_weights* w, float* M, float* logits,
                              float* Y_prob, int64_t* Y_hat, hipStream_t st) {
-    hipLaunchKernelGGL(abmil_combine_kernel, dim3(1), dim3(256), (w->s1 + w->n_classes) * sizeof(float), st, partials, G,
-                       w->s1, w->wcls, w->bcls, w->n_classes, M, logits, Y_prob, Y_hat);
+    HIPT_CHECK_ARG(G <= CMB_MAXG, "clam combine: %d partials exceed %d", G, CMB_MAXG);
+    const size_t lds = (CMB_MAXG + 9 * (size_t)w->s1 + w->n_classes) * sizeof(float);
+    hipLaunchKernelGGL(abmil_combine_kernel, dim3(1), dim3(1024), lds, st, partials, G, w->s1, w->wcls, w->bcls,
+                       w->n_classes, M, logits, Y_prob, Y_hat);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }
@@ -537,7 +559,8 @@ int hipt_small_ab_launch(const void* x, int xdtype, int N, int S1, int S2x2, con
 int hipt_pool_launch(const float* A, const float* h1, int N, int S1, float* gmax, float* partials, int* n_partials,
                      hipStream_t st) {
     hipLaunchKernelGGL(max_kernel, dim3(1), dim3(256), 0, st, A, N, gmax);
-    const int rows_per = 256;
+    int rows_per = 256;
+    while ((N + rows_per - 1) / rows_per > 1024) rows_per *= 2;
     const int G = (N + rows_per - 1) / rows_per;
     hipLaunchKernelGGL(pool_kernel, dim3(G), dim3(256), 0, st, A, h1, N, S1, gmax, rows_per, partials);
     HIPT_CHECK_LAUNCH();

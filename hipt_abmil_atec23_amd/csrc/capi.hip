@@ -3,6 +3,7 @@
 // caller may capture any call into a hipGraph.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -34,6 +35,38 @@ struct Carver {
     }
     bool ok() const { return used <= cap && (((uintptr_t)base & 255) == 0 || used == 0); }
 };
+
+// ---- optional per-kernel timing (bench.py's roofline leg): HIP events around every launch -----
+enum { PC_EMBED, PC_LN, PC_QKV, PC_ATTN, PC_PROJ, PC_FC1, PC_FC2, PC_ABMIL, PC_COMBINE, PC_OTHER, PC_N };
+const char* const kProfNames[PC_N] = {"embed_gemm", "layernorm", "qkv_gemm", "attention", "proj_gemm",
+                                      "fc1_gemm",   "fc2_gemm",  "abmil_fused", "abmil_combine", "other"};
+constexpr int kProfMax = 8192;
+struct Prof {
+    bool on = false, created = false;
+    hipEvent_t ev[kProfMax][2];
+    int cat[kProfMax];
+    int n = 0;
+} g_prof;
+
+inline void prof_begin(int cat, hipStream_t st) {
+    if (g_prof.on && g_prof.n < kProfMax) {
+        g_prof.cat[g_prof.n] = cat;
+        (void)hipEventRecord(g_prof.ev[g_prof.n][0], st);
+    }
+}
+inline void prof_end(hipStream_t st) {
+    if (g_prof.on && g_prof.n < kProfMax) {
+        (void)hipEventRecord(g_prof.ev[g_prof.n][1], st);
+        ++g_prof.n;
+    }
+}
+#define PROF(cat, expr)        \
+    do {                       \
+        prof_begin(cat, st);   \
+        rc = (expr);           \
+        prof_end(st);          \
+        if (rc) return rc;     \
+    } while (0)
 
 int check_vit(const hipt_vit_weights* w) {
     HIPT_CHECK_ARG(w != nullptr && w->blocks != nullptr, "vit: null weights");
@@ -71,7 +104,7 @@ BlockScratch carve_blocks(Carver& c, const hipt_vit_weights* w, int nseq) {
 }
 
 int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, void* out,
-           int64_t ldc, int M, int N, int K, int dtype, int flags, hipStream_t st) {
+           int64_t ldc, int M, int N, int K, int dtype, int flags, hipStream_t st, int rpt = 0) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A;
@@ -85,6 +118,7 @@ int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* 
     p.resid = resid;
     p.out = out;
     p.ldc = ldc;
+    p.rpt = rpt;
     return hipt_gemm_launch(p, dtype, ALOAD_PLAIN, flags, st);
 }
 
@@ -93,22 +127,41 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     const int D = w->dim, M = nseq * w->ntok, dt = w->dtype, dh = D / w->heads;
     const float scale = 1.0f / sqrtf((float)dh);  // head_dim ** -0.5 (vision_transformer.py:112)
     int rc;
+    const bool seq = hipt_seqgemm_supported(dt, D) && hipt_mlp_supported(dt, D, w->hidden) && getenv("HIPT_NO_SEQGEMM") == nullptr;
     for (int i = b0; i < b1; ++i) {
         const hipt_block_weights& b = w->blocks[i];
         const bool last_probs = probs != nullptr && i == b1 - 1;
-        if ((rc = hipt_layernorm_launch(x, D, b.ln1_w, b.ln1_b, s.xn, dt, D, M, D, w->ln_eps, st))) return rc;
-        if ((rc = linear(s.xn, D, b.qkv_w, D, b.qkv_b, nullptr, s.qkv, 3 * D, M, 3 * D, D, dt, 0, st))) return rc;
-        if ((rc = hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st)))
-            return rc;
-        if (last_probs) break;  // Block.forward(return_attention=True) returns before the residual (:148-149)
-        if ((rc = linear(s.att, D, b.proj_w, D, b.proj_b, x, x, D, M, D, D, dt, HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st)))
-            return rc;
-        if ((rc = hipt_layernorm_launch(x, D, b.ln2_w, b.ln2_b, s.xn, dt, D, M, D, w->ln_eps, st))) return rc;
-        if ((rc = linear(s.xn, D, b.fc1_w, D, b.fc1_b, nullptr, s.hid, w->hidden, M, w->hidden, D, dt, HIPT_EPI_GELU, st)))
-            return rc;
-        if ((rc = linear(s.hid, w->hidden, b.fc2_w, w->hidden, b.fc2_b, x, x, D, M, D, w->hidden, dt,
-                         HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st)))
-            return rc;
+        if (seq) {
+            // bf16, D in {192,384}: A-stationary kernels.  QKV with LayerNorm-1 fused into the activation
+            // load; proj leaves the attention-branch output y1 in bf16 (s.xn); the fused MLP kernel folds
+            // y1 in, does LN2 + fc1 + GELU + fc2 with the hidden tensor on chip and updates x in place.
+            SeqGemmParams q;
+            memset(&q, 0, sizeof(q));
+            q.M = M; q.K = D; q.ln_eps = w->ln_eps;
+            q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.N = 3 * D; q.bias = b.qkv_b;
+            q.out = s.qkv; q.ldc = 3 * D;
+            PROF(PC_QKV, hipt_seqgemm_launch(q, true, 0, st));
+            PROF(PC_ATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st));
+            if (last_probs) break;
+            q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
+            PROF(PC_PROJ, hipt_seqgemm_launch(q, false, 0, st));
+            MlpParams m;
+            memset(&m, 0, sizeof(m));
+            m.x = x; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
+            m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.M = M; m.D = D; m.hidden = w->hidden;
+            PROF(PC_FC1, hipt_mlp_launch(m, st));
+            continue;
+        } else {
+            PROF(PC_LN, hipt_layernorm_launch(x, D, b.ln1_w, b.ln1_b, s.xn, dt, D, M, D, w->ln_eps, st));
+            PROF(PC_QKV, linear(s.xn, D, b.qkv_w, D, b.qkv_b, nullptr, s.qkv, 3 * D, M, 3 * D, D, dt, 0, st, w->ntok));
+            PROF(PC_ATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st));
+            if (last_probs) break;  // Block.forward(return_attention=True) returns before the residual (:148-149)
+            PROF(PC_PROJ, linear(s.att, D, b.proj_w, D, b.proj_b, x, x, D, M, D, D, dt, HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st, w->ntok));
+            PROF(PC_LN, hipt_layernorm_launch(x, D, b.ln2_w, b.ln2_b, s.xn, dt, D, M, D, w->ln_eps, st));
+            PROF(PC_FC1, linear(s.xn, D, b.fc1_w, D, b.fc1_b, nullptr, s.hid, w->hidden, M, w->hidden, D, dt, HIPT_EPI_GELU, st, w->ntok));
+        }
+        PROF(PC_FC2, linear(s.hid, w->hidden, b.fc2_w, w->hidden, b.fc2_b, x, x, D, M, D, w->hidden, dt,
+                            HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st, w->ntok));
     }
     return HIPT_OK;
 }
@@ -139,13 +192,15 @@ int embed256(const hipt_vit_weights* w, const void* img, const hipt_image_layout
     p.ldc = w->dim;
     p.pos = w->pos;
     p.rows_per_seq = nty * ntx;
+    p.rpt = nty * ntx;
     p.im = *lay;
     p.im_nty = nty;
     p.im_ntx = ntx;
     p.im_seq0 = seq0;
-    int rc = hipt_gemm_launch(p, w->dtype, ALOAD_IM2COL, HIPT_EPI_OUT_F32 | EPI_ROWMAP, st);
-    if (rc) return rc;
-    return hipt_cls_init_launch(x, w->cls, w->pos, nseq, w->ntok, w->dim, st);
+    int rc;
+    PROF(PC_EMBED, hipt_gemm_launch(p, w->dtype, ALOAD_IM2COL, HIPT_EPI_OUT_F32 | EPI_ROWMAP, st));
+    PROF(PC_OTHER, hipt_cls_init_launch(x, w->cls, w->pos, nseq, w->ntok, w->dim, st));
+    return HIPT_OK;
 }
 
 int embed4k(const hipt_vit_weights* w, const void* tokens, int nseq, float* x, hipStream_t st) {
@@ -163,10 +218,11 @@ int embed4k(const hipt_vit_weights* w, const void* tokens, int nseq, float* x, h
     p.ldc = w->dim;
     p.pos = w->pos;
     p.rows_per_seq = w->ntok - 1;
+    p.rpt = w->ntok - 1;
     int rc = HIPT_OK;
-    if (p.M > 0) rc = hipt_gemm_launch(p, w->dtype, ALOAD_PLAIN, HIPT_EPI_GELU | HIPT_EPI_OUT_F32 | EPI_ROWMAP, st);
-    if (rc) return rc;
-    return hipt_cls_init_launch(x, w->cls, w->pos, nseq, w->ntok, w->dim, st);
+    if (p.M > 0) PROF(PC_EMBED, hipt_gemm_launch(p, w->dtype, ALOAD_PLAIN, HIPT_EPI_GELU | HIPT_EPI_OUT_F32 | EPI_ROWMAP, st));
+    PROF(PC_OTHER, hipt_cls_init_launch(x, w->cls, w->pos, nseq, w->ntok, w->dim, st));
+    return HIPT_OK;
 }
 
 int default_chunk(int nseq) { return nseq < 256 ? nseq : 256; }
@@ -176,6 +232,42 @@ int default_chunk(int nseq) { return nseq < 256 ? nseq : 256; }
 extern "C" {
 
 int hipt_abi_version(void) { return HIPT_ABI_VERSION; }
+
+int hipt_profile_enable(int on) {
+    if (on && !g_prof.created) {
+        for (int i = 0; i < kProfMax; ++i)
+            for (int j = 0; j < 2; ++j)
+                if (hipEventCreate(&g_prof.ev[i][j]) != hipSuccess) {
+                    hipt_set_error("profile: hipEventCreate failed");
+                    return HIPT_E_LAUNCH;
+                }
+        g_prof.created = true;
+    }
+    g_prof.on = on != 0;
+    g_prof.n = 0;
+    return HIPT_OK;
+}
+int hipt_profile_categories(void) { return PC_N; }
+const char* hipt_profile_category_name(int i) { return (i >= 0 && i < PC_N) ? kProfNames[i] : ""; }
+int hipt_profile_read(float* ms, int* counts) {
+    for (int i = 0; i < PC_N; ++i) {
+        ms[i] = 0.f;
+        counts[i] = 0;
+    }
+    for (int i = 0; i < g_prof.n; ++i) {
+        if (hipEventSynchronize(g_prof.ev[i][1]) != hipSuccess) {
+            hipt_set_error("profile: hipEventSynchronize failed");
+            return HIPT_E_LAUNCH;
+        }
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, g_prof.ev[i][0], g_prof.ev[i][1]);
+        ms[g_prof.cat[i]] += t;
+        counts[g_prof.cat[i]] += 1;
+    }
+    const int dropped = g_prof.n >= kProfMax;
+    g_prof.n = 0;
+    return dropped ? HIPT_E_WORKSPACE : HIPT_OK;
+}
 const char* hipt_last_error(void) { return g_err; }
 
 int hipt_layernorm(const float* x, int64_t x_stride, const float* w, const float* b, void* out, int out_dtype,
@@ -293,16 +385,15 @@ int hipt_vit256_forward(const hipt_vit_weights* w, const float* images, const hi
         return HIPT_E_WORKSPACE;
     }
     if (imgT) {
-        if ((rc = hipt_f32_to_bf16_launch(images, imgT, n_img, st))) return rc;
+        PROF(PC_OTHER, hipt_f32_to_bf16_launch(images, imgT, n_img, st));
         img = imgT;
     }
     for (int s0 = 0; s0 < nseq; s0 += chunk) {
         const int n = nseq - s0 < chunk ? nseq - s0 : chunk;
         if ((rc = embed256(w, img, lay, s0, n, x, st))) return rc;
         if ((rc = run_blocks(w, x, n, 0, w->depth, nullptr, s, st))) return rc;
-        if ((rc = hipt_layernorm_launch(x, (int64_t)w->ntok * w->dim, w->norm_w, w->norm_b, out + (size_t)s0 * w->dim, HIPT_F32,
-                                        w->dim, n, w->dim, w->ln_eps, st)))
-            return rc;
+        PROF(PC_LN, hipt_layernorm_launch(x, (int64_t)w->ntok * w->dim, w->norm_w, w->norm_b, out + (size_t)s0 * w->dim, HIPT_F32,
+                                          w->dim, n, w->dim, w->ln_eps, st));
     }
     return HIPT_OK;
 }
@@ -386,7 +477,7 @@ static int check_clam(const hipt_clam_weights* w) {
 }
 
 static size_t clam_partials_bytes(const hipt_clam_weights* w, int N) {
-    const size_t g = (size_t)(N / 256 + 2) > 512 ? (size_t)(N / 256 + 2) : 512;
+    const size_t g = 1024;  // fused: <= 512 workgroups; generic pool: <= 1024 row blocks
     return al256(g * (2 + w->s1) * 4);
 }
 
@@ -437,7 +528,7 @@ int hipt_clam_sb_forward(const hipt_clam_weights* w, const void* bag, int N, int
     float* gmax = (float*)c.take(256);
     int G = 0;
     if (hipt_clam_fused_supported(w)) {
-        if ((rc = hipt_clam_fused_launch(w, bag, N, attention_only, A_raw, partials, &G, st))) return rc;
+        PROF(PC_ABMIL, hipt_clam_fused_launch(w, bag, N, attention_only, A_raw, partials, &G, st));
     } else {
         float* h1 = (float*)c.take((size_t)N * w->s1 * 4);
         float* ab = (float*)c.take((size_t)N * 2 * w->s2 * 4);
@@ -449,7 +540,8 @@ int hipt_clam_sb_forward(const hipt_clam_weights* w, const void* bag, int N, int
         if (!attention_only && (rc = hipt_pool_launch(A_raw, h1, N, w->s1, gmax, partials, &G, st))) return rc;
     }
     if (attention_only) return HIPT_OK;
-    return hipt_clam_combine_launch(partials, G, w, M, logits, Y_prob, Y_hat, st);
+    PROF(PC_COMBINE, hipt_clam_combine_launch(partials, G, w, M, logits, Y_prob, Y_hat, st));
+    return HIPT_OK;
 }
 
 int hipt_attn_net_gated(const hipt_clam_weights* w, const void* x, int N, float* A, void* workspace, size_t ws_bytes,

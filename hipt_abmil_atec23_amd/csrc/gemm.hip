@@ -1,33 +1,42 @@
 // out = epilogue(A[M,K] @ W[N,K]^T + bias): the nn.Linear / Conv2d-as-GEMM workhorse of the ViT path
 // (reference call sites: HIPT_4K/vision_transformer.py:93-95,114,116,165; vision_transformer4k.py:169).
 //
-// gfx950 design: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
-// 4x4 MFMA 16x16 tiles), K streamed in 128-byte slabs (64 bf16 / 32 fp32) through a 2-stage LDS
-// ring filled by LDS-DMA (global_load_lds_dwordx4).  The LDS image is lane-linear per DMA
-// instruction, so the bank-conflict swizzle (16-byte chunk index ^= (row>>1)&7) is applied to the
-// per-lane SOURCE address and again on the ds_read_b128 side.  Operands are fed "swapped"
-// (weights as the MFMA A operand) so that each lane ends up with 4 consecutive output columns of
-// one row and the epilogue stores 8/16 bytes per lane without an LDS round trip.
+// gfx950 design.  The token matrix of a region is 256 patches x 257 tokens; 257 is prime, so any
+// power-of-two M tile leaves a ragged last round on 256 CUs (128-row tiles: 1542 tiles of the proj
+// GEMM on 512 slots = 4 rounds for 3.01 rounds of work).  The M tile is therefore ONE SEQUENCE:
+// `rpt` rows (257, or 256 for the patch-embedding GEMM) padded to 17 MFMA row fragments (272 rows,
+// 5.5 % padding), times 128 output columns -> grid = sequences x N/128, an exact multiple of the CU
+// count for a 256-patch region, one 512-thread workgroup (8 waves as 2(M) x 4(N)) per CU.
+// K streams in 128-byte slabs (64 bf16 / 32 fp32) through a 3-stage LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4) that stays in flight across the single raw s_barrier per slab (counted
+// s_waitcnt vmcnt, never 0 inside the loop).  The LDS image is lane-linear per DMA instruction, so the
+// bank-conflict swizzle (16-byte chunk index ^= (row>>1)&7) is applied to the per-lane SOURCE address
+// and again on the ds_read_b128 side.  Operands are fed "swapped" (weights as the MFMA A operand) so
+// each lane ends with 4 consecutive output columns of one row: 8/16-byte epilogue stores, no LDS hop.
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
-constexpr int STAGE_BYTES = (BM + BN) * 128;  // 32 KiB
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;     // 64 KiB -> 2 workgroups per CU
+constexpr int MF = 17;                  // MFMA row fragments per tile (272 rows)
+constexpr int TROWS = MF * 16;          // 272
+constexpr int BN = 128;
+constexpr int A_BYTES = TROWS * 128;    // 34816
+constexpr int STAGE_BYTES = A_BYTES + BN * 128;  // 51200
+constexpr int NSTAGE = 3;
+constexpr int GEMM_LDS = NSTAGE * STAGE_BYTES;   // 153600 B -> one workgroup per CU
+constexpr int A_INSTR = TROWS / 8;      // 34 DMA instructions of 1 KiB per A slab
 
 template <typename T, int ALOAD>
 struct ALoader {
-    // per-lane state for the 4 LDS-DMA instructions this wave issues per K slab for the A tile
-    const T* base[4];
+    const T* base[5];  // this wave issues A instructions q*8 + wave, q = 0..4 (the 5th only for wave < 2)
     int64_t cs, rs;
-    __device__ __forceinline__ void init(const GemmParams& p, int m0, int wave, int lane) {
+    __device__ __forceinline__ void init(const GemmParams& p, int row0, int nrows, int wave, int lane) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = (wave * 4 + q) * 8 + (lane >> 3);
-            int m = m0 + r;
-            m = m < p.M ? m : p.M - 1;
+        for (int q = 0; q < 5; ++q) {
+            int r = (q * 8 + wave) * 8 + (lane >> 3);
+            r = r < nrows ? r : nrows - 1;  // padding rows re-read the last valid row (never stored)
+            const int m = row0 + r;
             if constexpr (ALOAD == ALOAD_PLAIN) {
                 base[q] = (const T*)p.A + (int64_t)m * p.lda;
             } else {
@@ -44,7 +53,7 @@ struct ALoader {
         cs = p.im.chan_stride;
         rs = p.im.row_stride;
     }
-    // source of logical chunk `kc` (16 bytes, global chunk index along K) of instruction q's row
+    // source of logical chunk `kc` (16 bytes, global chunk index along K) of instruction slot q
     __device__ __forceinline__ const T* src(int q, int kc) const {
         if constexpr (ALOAD == ALOAD_PLAIN) {
             return base[q] + kc * Tr<T>::EPC;
@@ -79,99 +88,115 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, int m, int n, f32x
         store4<T>((T*)p.out + orow * p.ldc + n, v);
 }
 
+template <int N> __device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <typename T, int ALOAD, int FLAGS>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 2, wn = wave & 3;  // 2 (M) x 4 (N)
+    const int li = lane & 15, g = lane >> 4;
 
+    // consecutive blocks on one XCD walk the N tiles of the same sequence: A slab re-reads hit that L2
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int row0 = (tile / tiles_n) * p.rpt, n0 = (tile % tiles_n) * BN;
+    int nrows = p.M - row0;
+    nrows = nrows < p.rpt ? nrows : p.rpt;
 
     // ---- LDS-DMA source addressing ----
     ALoader<T, ALOAD> al;
-    al.init(p, m0, wave, lane);
-    const T* wbase[4];
+    al.init(p, row0, nrows, wave, lane);
+    const T* wbase[2];
+    int wchunk[2], achunk[5];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int n = n0 + (wave * 4 + q) * 8 + (lane >> 3);
+    for (int q = 0; q < 2; ++q) {
+        const int r = (q * 8 + wave) * 8 + (lane >> 3);
+        int n = n0 + r;
         n = n < p.N ? n : p.N - 1;
         wbase[q] = (const T*)p.W + (int64_t)n * p.ldw;
+        wchunk[q] = (lane & 7) ^ ((r >> 1) & 7);
     }
-    // instruction q of this wave fills rows (wave*4+q)*8 .. +7; lane -> (row = lane>>3, physical
-    // chunk = lane&7); the logical chunk it must fetch is phys ^ ((row>>1)&7), row&15 pattern only
-    int lchunk[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = (wave * 4 + q) * 8 + (lane >> 3);
-        lchunk[q] = (lane & 7) ^ ((r >> 1) & 7);
+    for (int q = 0; q < 5; ++q) {
+        const int r = (q * 8 + wave) * 8 + (lane >> 3);
+        achunk[q] = (lane & 7) ^ ((r >> 1) & 7);
     }
+    const bool five = wave < (A_INSTR - 32);  // waves 0,1 issue a 5th A instruction (34 = 4*8 + 2)
     auto stage = [&](int s, int kt) {
         char* sa = smem + s * STAGE_BYTES;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(al.src(q, kt * 8 + lchunk[q]), sa + (wave * 4 + q) * 1024);
+        for (int q = 0; q < 4; ++q) glds16(al.src(q, kt * 8 + achunk[q]), sa + (q * 8 + wave) * 1024);
+        if (five) glds16(al.src(4, kt * 8 + achunk[4]), sa + (32 + wave) * 1024);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            glds16(wbase[q] + (kt * 8 + lchunk[q]) * Tr<T>::EPC, sa + BM * 128 + (wave * 4 + q) * 1024);
+        for (int q = 0; q < 2; ++q)
+            glds16(wbase[q] + (kt * 8 + wchunk[q]) * Tr<T>::EPC, sa + A_BYTES + (q * 8 + wave) * 1024);
     };
 
-    // ---- fragment read offsets (bytes within a tile): row (lane&15), chunk ((lane>>4)+4ks) swizzled
+    // ---- fragment read offsets (bytes within a tile): row li, chunk (g + 4ks) swizzled ----
     int foff[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-        foff[ks] = (lane & 15) * 128 + ((((lane >> 4) + 4 * ks) ^ ((lane >> 1) & 7)) << 4);
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = li * 128 + (((g + 4 * ks) ^ ((lane >> 1) & 7)) << 4);
 
-    f32x4 acc[4][4];
+    // wave row wm owns row fragments [wm*9, wm*9 + nf), nf = 9 / 8
+    constexpr int NF = 9;
+    const int f0 = wm * NF;
+    f32x4 acc[NF][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NF; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / Tr<T>::KB;
     stage(0, 0);
-    wait_vm0();
-    __syncthreads();
-    int cur = 0;
+    if (nk > 1) stage(1, 1);
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char* sa = smem + cur * STAGE_BYTES + wm * 64 * 128;
-        const char* sw = smem + cur * STAGE_BYTES + BM * 128 + wn * 64 * 128;
+        // slab kt has landed once at most the loads of slab kt+1 are outstanding (6 or 7 per wave)
+        if (kt + 1 < nk) {
+            if (five) wait_vm<7>(); else wait_vm<6>();
+        } else {
+            wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();  // everyone's slab kt is visible; everyone is done reading slab kt-1
+        if (kt + 2 < nk) stage((kt + 2) % NSTAGE, kt + 2);  // overwrites the buffer of slab kt-1
+        const char* sa = smem + (kt % NSTAGE) * STAGE_BYTES + f0 * 16 * 128;
+        const char* sw = smem + (kt % NSTAGE) * STAGE_BYTES + A_BYTES + wn * 32 * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            u32x4 af[4], wf[4];
+            u32x4 wf[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const u32x4*)(sa + i * 16 * 128 + foff[ks]);
+            for (int j = 0; j < 2; ++j) wf[j] = *(const u32x4*)(sw + j * 16 * 128 + foff[ks]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wf[j] = *(const u32x4*)(sw + j * 16 * 128 + foff[ks]);
+            for (int i = 0; i < NF; ++i) {
+                if (i == NF - 1 && wm == 1) break;  // second wave row has 8 fragments (17 = 9 + 8)
+                const u32x4 af = *(const u32x4*)(sa + i * 16 * 128 + foff[ks]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Tr<T>::mma16(acc[i][j], wf[j], af[i]);
+                for (int j = 0; j < 2; ++j) Tr<T>::mma16(acc[i][j], wf[j], af);
+            }
         }
-        wait_vm0();
-        __syncthreads();
-        cur ^= 1;
     }
 
-    // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3] ----
+    // ---- epilogue: lane holds C[row = frag*16 + li][n = n0 + wn*32 + j*16 + 4g + 0..3] ----
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
+    for (int i = 0; i < NF; ++i) {
+        if (i == NF - 1 && wm == 1) break;
+        const int r = (f0 + i) * 16 + li;
+        if (r >= nrows) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-            if (n < p.N) epilogue<T, FLAGS>(p, m, n, acc[i][j]);
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 32 + j * 16 + 4 * g;
+            if (n < p.N) epilogue<T, FLAGS>(p, row0 + r, n, acc[i][j]);
         }
     }
 }
 
 template <typename T, int ALOAD, int FLAGS>
 int launch(const GemmParams& p, hipStream_t st) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    static bool attr_set = false;  // 64 KiB dynamic LDS needs the opt-in once per kernel
+    const int tiles = ((p.M + p.rpt - 1) / p.rpt) * ((p.N + BN - 1) / BN);
+    static bool attr_set = false;  // > 64 KiB dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)gemm_kernel<T, ALOAD, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GEMM_LDS) != hipSuccess) {
@@ -180,7 +205,7 @@ int launch(const GemmParams& p, hipStream_t st) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, ALOAD, FLAGS>), dim3(tiles), dim3(256), GEMM_LDS, st, p);
+    hipLaunchKernelGGL((gemm_kernel<T, ALOAD, FLAGS>), dim3(tiles), dim3(512), GEMM_LDS, st, p);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }
@@ -205,12 +230,14 @@ int dispatch(const GemmParams& p, int aload, int flags, hipStream_t st) {
 
 }  // namespace
 
-int hipt_gemm_launch(const GemmParams& p, int dtype, int aload, int flags, hipStream_t st) {
+int hipt_gemm_launch(const GemmParams& p_in, int dtype, int aload, int flags, hipStream_t st) {
+    GemmParams p = p_in;
     const int kb = dtype == HIPT_F32 ? 32 : 64;
     HIPT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     HIPT_CHECK_ARG(p.K % kb == 0, "gemm: K=%d must be a multiple of %d", p.K, kb);
     HIPT_CHECK_ARG(p.N % 4 == 0, "gemm: N=%d must be a multiple of 4", p.N);
     HIPT_CHECK_ARG(p.ldc % 4 == 0, "gemm: ldc=%lld must be a multiple of 4", (long long)p.ldc);
+    if (p.rpt <= 0 || p.rpt > TROWS) p.rpt = TROWS;  // no sequence structure: plain 272-row tiles
     const int esz = dtype == HIPT_F32 ? 4 : 2;
     HIPT_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0 && ((uintptr_t)p.out % 16) == 0,
                    "gemm: A/W/out must be 16-byte aligned");

@@ -14,6 +14,7 @@ struct GemmParams {
     const void* W;
     int64_t ldw;
     int M, N, K;
+    int rpt;  // rows per M tile = rows per sequence (<= 272); 0 -> plain 272-row tiles
     const float* bias;
     const float* resid;
     void* out;
@@ -28,6 +29,44 @@ struct GemmParams {
 
 int hipt_gemm_launch(const GemmParams& p, int dtype, int aload, int flags, hipStream_t st);
 
+// A-stationary GEMM (seqgemm.hip): one workgroup per sequence, activations in registers, optional fused LayerNorm
+struct SeqGemmParams {
+    const void* A;       // LN: fp32 x rows; else bf16 rows
+    int64_t lda;         // elements
+    const float* ln_w;
+    const float* ln_b;
+    float ln_eps;
+    const void* W;       // bf16 [N, K]
+    int M, N, K;
+    unsigned long long* stamps;  // debug: per-workgroup phase timestamps (100 MHz), or null
+    int debug;           // HIPT_SEQGEMM_DEBUG bits: 1 = skip epilogue stores, 2 = skip A load (zeros)
+    int full_tiles;      // (set by the launcher) row tiles run whole; the rest are split nsplit ways over N
+    int nsplit;
+    const float* bias;
+    void* out;           // bf16 [M, ldc]
+    int64_t ldc;
+};
+bool hipt_seqgemm_supported(int dtype, int K);
+int hipt_seqgemm_launch(const SeqGemmParams& p, bool ln, int flags, hipStream_t st);
+
+// Fused MLP sub-block (mlp.hip): x <- x + y1 + fc2(GELU(fc1(LN2(x + y1))))
+struct MlpParams {
+    float* x;            // fp32 [M, D] residual stream, updated in place
+    const void* y1;      // bf16 [M, D] attention-branch output still to be added (or null)
+    const float* ln_w;
+    const float* ln_b;
+    float ln_eps;
+    const void* w1;      // bf16 [hidden, D]
+    const float* b1;
+    const void* w2;      // bf16 [D, hidden]
+    const float* b2;
+    int M, D, hidden;
+    int full_tiles;      // (set by the launcher)
+    unsigned long long* stamps;
+};
+bool hipt_mlp_supported(int dtype, int D, int hidden);
+int hipt_mlp_launch(const MlpParams& p, hipStream_t st);
+
 int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, const float* b, void* out, int out_dtype,
                           int64_t out_stride, int rows, int D, float eps, hipStream_t st);
 
@@ -36,6 +75,8 @@ int hipt_attention_launch(const void* qkv, void* out, float* probs, int B, int n
 
 // x[s, 0, :] = cls + pos[0]  for s in [0, nseq)
 int hipt_cls_init_launch(float* x, const float* cls, const float* pos, int nseq, int ntok, int D, hipStream_t st);
+// out[i] = src[i] (+ (float)y[i] if y)  (fp32, bf16 branch, n % 8 == 0): lands the residual stream in the caller's buffer
+int hipt_add_bf16_launch(float* out, const float* src, const void* y, int64_t n, hipStream_t st);
 // fp32 -> bf16 elementwise (n % 8 == 0)
 int hipt_f32_to_bf16_launch(const float* in, void* out, int64_t n, hipStream_t st);
 

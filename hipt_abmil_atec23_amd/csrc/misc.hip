@@ -9,7 +9,17 @@ namespace {
 
 constexpr int LN_MAX_E = 32;  // D <= 2048
 
-template <typename TO>
+template <typename TO, int V> __device__ __forceinline__ void ln_store(TO* p, const float* v);
+template <> __device__ __forceinline__ void ln_store<float, 1>(float* p, const float* v) { p[0] = v[0]; }
+template <> __device__ __forceinline__ void ln_store<float, 2>(float* p, const float* v) { *(f32x2*)p = f32x2{v[0], v[1]}; }
+template <> __device__ __forceinline__ void ln_store<bf16_t, 1>(bf16_t* p, const float* v) { p[0] = (bf16_t)v[0]; }
+template <> __device__ __forceinline__ void ln_store<bf16_t, 2>(bf16_t* p, const float* v) {
+    *(uint32_t*)p = pack_bf16x2(v[0], v[1]);
+}
+
+// one wave per row; lane l owns elements V*l + 64*V*i (+0..V-1): every load/store instruction of the
+// wave is one contiguous 256*V-byte run
+template <typename TO, int V>
 __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, int64_t x_stride,
                                                  const float* __restrict__ w, const float* __restrict__ b,
                                                  TO* __restrict__ out, int64_t out_stride, int rows, int D, float eps) {
@@ -17,30 +27,43 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, in
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (int64_t)row * x_stride;
-    const int E = D >> 6;
-    float v[LN_MAX_E];
+    const int E = D / (64 * V);
+    float v[LN_MAX_E / V][V];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_E; ++i)
+    for (int i = 0; i < LN_MAX_E / V; ++i)
         if (i < E) {
-            v[i] = xr[lane + 64 * i];
-            s += v[i];
+            if constexpr (V == 2) {
+                const f32x2 t = *(const f32x2*)(xr + 2 * lane + 128 * i);
+                v[i][0] = t[0];
+                v[i][1] = t[1];
+            } else {
+                v[i][0] = xr[lane + 64 * i];
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) s += v[i][e];
         }
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_E; ++i)
+    for (int i = 0; i < LN_MAX_E / V; ++i)
         if (i < E) {
-            const float c = v[i] - mean;
-            q += c * c;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float c = v[i][e] - mean;
+                q += c * c;
+            }
         }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
     TO* orow = out + (int64_t)row * out_stride;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_E; ++i)
+    for (int i = 0; i < LN_MAX_E / V; ++i)
         if (i < E) {
-            const int d = lane + 64 * i;
-            orow[d] = (TO)((v[i] - mean) * rstd * w[d] + b[d]);
+            const int d = V * lane + 64 * V * i;
+            float o[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = (v[i][e] - mean) * rstd * w[d + e] + b[d + e];
+            ln_store<TO, V>(orow + d, o);
         }
 }
 
@@ -63,19 +86,54 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restr
     }
 }
 
+__global__ void add_bf16_kernel(float* __restrict__ out, const float* __restrict__ src, const bf16_t* __restrict__ y, int64_t n8) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 a = *(const f32x4*)(src + i * 8), c = *(const f32x4*)(src + i * 8 + 4);
+        if (y) {
+            const bf16x8 v = __builtin_bit_cast(bf16x8, *(const u32x4*)(y + i * 8));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] += (float)v[e];
+                c[e] += (float)v[4 + e];
+            }
+        }
+        *(f32x4*)(out + i * 8) = a;
+        *(f32x4*)(out + i * 8 + 4) = c;
+    }
+}
+
 }  // namespace
+
+int hipt_add_bf16_launch(float* out, const float* src, const void* y, int64_t n, hipStream_t st) {
+    HIPT_CHECK_ARG(n % 8 == 0, "add_bf16: n %% 8 required");
+    const int64_t n8 = n / 8;
+    int64_t blocks = (n8 + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, src, (const bf16_t*)y, n8);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}
 
 int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, const float* b, void* out, int out_dtype,
                           int64_t out_stride, int rows, int D, float eps, hipStream_t st) {
     HIPT_CHECK_ARG(rows > 0 && D > 0 && D % 64 == 0 && D <= 64 * LN_MAX_E, "layernorm: D=%d must be a multiple of 64, <= %d",
                    D, 64 * LN_MAX_E);
     const dim3 grid((rows + 3) / 4), block(256);
-    if (out_dtype == HIPT_F32)
-        hipLaunchKernelGGL(ln_kernel<float>, grid, block, 0, st, x, x_stride, w, b, (float*)out, out_stride, rows, D, eps);
-    else if (out_dtype == HIPT_BF16)
-        hipLaunchKernelGGL(ln_kernel<bf16_t>, grid, block, 0, st, x, x_stride, w, b, (bf16_t*)out, out_stride, rows, D, eps);
-    else
+    const bool v2 = D % 128 == 0 && x_stride % 2 == 0 && out_stride % 2 == 0 && ((uintptr_t)x % 8) == 0 &&
+                    ((uintptr_t)out % 8) == 0;
+    if (out_dtype == HIPT_F32) {
+        if (v2)
+            hipLaunchKernelGGL((ln_kernel<float, 2>), grid, block, 0, st, x, x_stride, w, b, (float*)out, out_stride, rows, D, eps);
+        else
+            hipLaunchKernelGGL((ln_kernel<float, 1>), grid, block, 0, st, x, x_stride, w, b, (float*)out, out_stride, rows, D, eps);
+    } else if (out_dtype == HIPT_BF16) {
+        if (v2)
+            hipLaunchKernelGGL((ln_kernel<bf16_t, 2>), grid, block, 0, st, x, x_stride, w, b, (bf16_t*)out, out_stride, rows, D, eps);
+        else
+            hipLaunchKernelGGL((ln_kernel<bf16_t, 1>), grid, block, 0, st, x, x_stride, w, b, (bf16_t*)out, out_stride, rows, D, eps);
+    } else {
         HIPT_CHECK_ARG(false, "layernorm: bad out dtype %d", out_dtype);
+    }
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }

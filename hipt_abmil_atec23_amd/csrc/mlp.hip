@@ -1,0 +1,464 @@
+// FUSED MLP SUB-BLOCK (bf16 mode):   x <- x + y1 + fc2( GELU( fc1( LN2(x + y1) ) ) )
+//   (Block.forward second half, HIPT_4K/vision_transformer.py:151 with Mlp.forward :98-104; y1 is the
+//    attention-branch output the proj kernel left in bf16, i.e. the first residual add :150 is folded in.)
+//
+// The reference materialises the [M, 4D] hidden tensor (202 MB in bf16 for one region) and re-reads it;
+// here it never leaves the chip.  One 4-wave workgroup owns 128 rows (8 MFMA row fragments, 2 per wave)
+// and keeps, at one wave per SIMD:
+//     af   LN2(x+y1) as operand fragments for fc1           2 x D/8 chunks      (96 VGPRs at D=384)
+//     acc1 one 128-wide hidden chunk of fc1                  2 x 8 x 4           (64)
+//     hf   GELU(acc1) re-packed IN REGISTERS as the operand of fc2 (accumulator-as-operand: the lane
+//          that owns 4 consecutive hidden units of a row after fc1 owns exactly those K slots in fc2;
+//          the W2 fragments are read with the matching K permutation)           (32)
+//     acc2 the [128, D] output of fc2                        2 x D/16 x 4        (192)
+// Only weights stream: per hidden chunk 6 slabs of W1 and 6 of W2 (16 KiB each) through the 8-slot
+// LDS-DMA ring shared by the 4 waves.  HBM traffic per call: x and y1 read twice (prologue, epilogue),
+// x written once = 403 MB per region instead of 807 MB (LN2 + fc1 + fc2 as separate kernels).
+// Row tiling: 65792 rows = 514 tiles of 128; the 2 tiles beyond two full rounds of 256 CUs are cut into
+// 16-row workgroups (one active fragment) so the tail costs half a round instead of a whole one.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int TMR = 128;               // rows per full workgroup
+constexpr int SLAB_BYTES = 128 * 128;  // 128 weight rows x 64 bf16
+constexpr int NSLOT = 8;
+
+template <int N> __device__ __forceinline__ void wait_vm_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int U> __device__ __forceinline__ void wait_units(int units) {  // 4*U DMA instructions per unit per wave
+    if constexpr (U == 2) {
+        switch (units) {
+            case 0: wait_vm_n<0>(); break;
+            case 1: wait_vm_n<8>(); break;
+            default: wait_vm_n<16>(); break;
+        }
+    } else {
+        switch (units) {
+            case 0: wait_vm_n<0>(); break;
+            case 1: wait_vm_n<4>(); break;
+            case 2: wait_vm_n<8>(); break;
+            case 3: wait_vm_n<12>(); break;
+            case 4: wait_vm_n<16>(); break;
+            case 5: wait_vm_n<20>(); break;
+            default: wait_vm_n<24>(); break;
+        }
+    }
+}
+
+// GELU for the bf16 path.  nn.GELU() is the exact erf form (vision_transformer.py:89); ocml erff costs
+// ~36 VALU instructions, which at one wave per SIMD is as expensive as the MFMAs it sits between.  This
+// is Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below the bf16 rounding of the result):
+//   erfc(|z|) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1 / (1 + p |z|),  z = x / sqrt(2)
+//   Phi(x) = x >= 0 ? 1 - erfc/2 : erfc/2 ;  gelu = x Phi(x)
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float az = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(az * az * -1.4426950408889634f);
+    const float q = 0.5f * poly * t * e;  // erfc(|z|) / 2
+    return x * (x >= 0.f ? 1.0f - q : q);
+}
+
+template <int NCH>
+__device__ __forceinline__ void ln_rows(f32x4 (&v)[NCH][2], const float* gam, const float* bet, int K, float eps, int g,
+                                        u32x4 (&out)[NCH]) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += v[c][0][e] + v[c][1][e];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s / (float)K;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = v[c][0][e] - mean, b = v[c][1][e] - mean;
+            q += a * a + b * b;
+        }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)K + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k0 = (g + 4 * c) * 8;
+        const f32x4 g0 = *(const f32x4*)(gam + k0), g1 = *(const f32x4*)(gam + k0 + 4);
+        const f32x4 b0 = *(const f32x4*)(bet + k0), b1 = *(const f32x4*)(bet + k0 + 4);
+        const f32x4 y0 = (v[c][0] - mean) * rstd * g0 + b0, y1 = (v[c][1] - mean) * rstd * g1 + b1;
+        u32x4 o;
+        o[0] = pack_bf16x2(y0[0], y0[1]);
+        o[1] = pack_bf16x2(y0[2], y0[3]);
+        o[2] = pack_bf16x2(y1[0], y1[1]);
+        o[3] = pack_bf16x2(y1[2], y1[3]);
+        out[c] = o;
+    }
+}
+
+#define MSTAMP(k)                                                                                   \
+    do {                                                                                            \
+        if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+
+// KS = D / 64 (6: ViT-256, 3: ViT-4K)
+template <int KS>
+__global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
+    constexpr int D = KS * 64;
+    constexpr int NCH = KS * 2;          // A chunks per lane per row fragment
+    constexpr int NF2 = D / 16;          // fc2 output column fragments (24 / 12)
+    constexpr int NG = (D + 127) / 128;  // fc2 weight slabs (128 output rows each) per hidden half
+    constexpr int SPC = KS + 2 * NG;     // slabs per hidden chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* gam = (float*)(smem + NSLOT * SLAB_BYTES);
+    float* bet = gam + D;
+    float* b2s = bet + D;
+    float* b1s = b2s + D;  // [hidden]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    // blocks [0, full_tiles): 128 rows each; then 16-row tail workgroups (only wave 0 / fragment 0 has rows)
+    int row0, nrows;
+    if ((int)blockIdx.x < p.full_tiles) {
+        row0 = blockIdx.x * TMR;
+        nrows = TMR;
+    } else {
+        row0 = p.full_tiles * TMR + (blockIdx.x - p.full_tiles) * 16;
+        nrows = 16;
+    }
+    nrows = (p.M - row0) < nrows ? (p.M - row0) : nrows;
+    const int nchunk = p.hidden / 128;
+    const int nslab = nchunk * SPC;
+    // fragments this wave really owns (a tail workgroup has one): lets idle waves skip the matrix work
+    const int my_frags = nrows > wave * 32 + 16 ? 2 : (nrows > wave * 32 ? 1 : 0);
+
+    // ---- weight slab DMA: per-lane base pointers are fixed; a slab only adds wave-uniform offsets ----
+    // U consecutive slabs form one ring unit (one barrier + one counted wait per unit): U = 2 when the
+    // per-chunk slab count is even (D = 384: 12), else 1.
+    constexpr int U = (SPC % 2 == 0) ? 2 : 1;
+    constexpr int NUS = NSLOT / U;  // ring slots in units
+    const bf16_t* W1 = (const bf16_t*)p.w1;
+    const bf16_t* W2 = (const bf16_t*)p.w2;
+    // instruction q of a wave fills rows (q*4 + wave)*8 + (lane>>3): +32 rows per q, and the swizzled
+    // chunk does not depend on q, so ONE per-lane base per matrix is enough (q adds a uniform stride)
+    const int r0 = wave * 8 + (lane >> 3);
+    const int ch0 = (lane & 7) ^ ((r0 >> 1) & 7);
+    const bf16_t* w1b = W1 + (int64_t)r0 * D + ch0 * 8;
+    const bf16_t* w2b = W2 + (int64_t)r0 * p.hidden + ch0 * 8;
+    const int nunit = nslab / U;
+    auto issue_unit = [&](int u) {
+#pragma unroll
+        for (int h = 0; h < U; ++h) {
+            const int i = u * U + h;
+            const int c = i / SPC, j = i % SPC;
+            char* dst = smem + ((u % NUS) * U + h) * SLAB_BYTES;
+            if (j < KS) {  // fc1: hidden rows [128c, +128) x k [64j, +64)
+                const int64_t off = (int64_t)c * 128 * D + j * 64;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) glds16(w1b + off + q * 32 * D, dst + (q * 4 + wave) * 1024);
+            } else {       // fc2: output rows [128ng, +128) x hidden [128c + 64kh, +64)
+                const int kh = (j - KS) / NG, ng = (j - KS) % NG;
+                const int64_t off = (int64_t)ng * 128 * p.hidden + c * 128 + kh * 64;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16_t* src = w2b + off + (int64_t)q * 32 * p.hidden;
+                    if constexpr (D % 128 != 0) {  // last row group of a D = 192 model: clamp rows >= D
+                        const int r = (q * 4 + wave) * 8 + (lane >> 3);
+                        if (ng * 128 + r >= D) src = W2 + (int64_t)(D - 1) * p.hidden + c * 128 + kh * 64;
+                    }
+                    glds16(src, dst + (q * 4 + wave) * 1024);
+                }
+            }
+        }
+    };
+    MSTAMP(0);
+    const int pre = nunit < NUS - 1 ? nunit : NUS - 1;
+    for (int u = 0; u < pre; ++u) issue_unit(u);
+
+    for (int i = tid; i < D; i += 256) {
+        gam[i] = p.ln_w[i];
+        bet[i] = p.ln_b[i];
+        b2s[i] = p.b2[i];
+    }
+    for (int i = tid; i < p.hidden; i += 256) b1s[i] = p.b1[i];
+    __syncthreads();  // (drains the weight prefetch once)
+    MSTAMP(1);
+
+    // ---- activations: v = x + y1 -> LN2 -> operand fragments ----
+    u32x4 af[2][NCH];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        int r = (wave * 2 + mf) * 16 + li;
+        r = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
+        const float* xr = p.x + (int64_t)(row0 + r) * D;
+        f32x4 v[NCH][2];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            v[c][0] = *(const f32x4*)(xr + (g + 4 * c) * 8);
+            v[c][1] = *(const f32x4*)(xr + (g + 4 * c) * 8 + 4);
+        }
+        if (p.y1) {
+            const bf16_t* yr = (const bf16_t*)p.y1 + (int64_t)(row0 + r) * D;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const bf16x8 y = __builtin_bit_cast(bf16x8, *(const u32x4*)(yr + (g + 4 * c) * 8));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[c][0][e] += (float)y[e];
+                    v[c][1][e] += (float)y[4 + e];
+                }
+            }
+        }
+        ln_rows<NCH>(v, gam, bet, D, p.ln_eps, g, af[mf]);
+    }
+    MSTAMP(2);
+
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = li * 128 + (((g + 4 * ks) ^ ((lane >> 1) & 7)) << 4);
+    // fc2 weight fragment: two 8-byte pieces per lane, hidden offsets 32fl + 4g + (0..3) and + 16, so that
+    // the K slots match how GELU(acc1) is packed below.  Byte offset inside the 128-byte row: 64fl + 8g (+32).
+    int f2off[2][2];
+#pragma unroll
+    for (int fl = 0; fl < 2; ++fl)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int byte = 64 * fl + 32 * h + 8 * g;
+            f2off[fl][h] = li * 128 + ((((byte >> 4)) ^ ((lane >> 1) & 7)) << 4) + (byte & 8);
+        }
+    const uint32_t lbase = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
+
+    f32x4 acc2[2][NF2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF2; ++nf) acc2[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define LGKM(n)                                             \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0)
+// before slab j of chunk c: if it opens a ring unit, wait until that unit has landed (at most the NUS-2
+// later units in flight; 4*U DMA instructions per unit per wave), barrier, refill the slot freed by the
+// previous unit
+#define SLAB_SYNC(c, j)                                                                          \
+    if ((j) % U == 0) {                                                                          \
+        const int u = ((c) * SPC + (j)) / U;                                                     \
+        const int later = (u + NUS - 2 < nunit ? u + NUS - 2 : nunit - 1) - u;                   \
+        wait_units<U>(later);                                                                    \
+        __builtin_amdgcn_s_barrier();                                                            \
+        if (u + NUS - 1 < nunit) issue_unit(u + NUS - 1);                                        \
+    }
+#define SLAB_ADDR(c, j) ((((((c) * SPC + (j)) / U) % NUS) * U + (j) % U) * SLAB_BYTES)
+
+    for (int c = 0; c < nchunk; ++c) {
+        // ================= fc1 chunk: acc1[128 rows, 128 hidden] =================
+        if (c == 1) MSTAMP(5);
+        f32x4 acc1[2][8];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf) acc1[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KS; ++kt) {
+            SLAB_SYNC(c, kt);
+            if (my_frags > 0) {
+                const uint32_t a0 = lbase + SLAB_ADDR(c, kt) + foff[0];
+                const uint32_t a1 = lbase + SLAB_ADDR(c, kt) + foff[1];
+                // 4 groups per slab: 4 W fragments (ks, 4 column fragments) -> 8 MFMAs; two register sets
+                u32x4 wa[4], wb[4];
+#define RD4(w, addr, base)                 \
+    DSR128(w[0], addr, base + 0);          \
+    DSR128(w[1], addr, base + 2048);       \
+    DSR128(w[2], addr, base + 4096);       \
+    DSR128(w[3], addr, base + 6144)
+#define MM1(w, ks, q0)                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
+        Tr<bf16_t>::mma16(acc1[0][(q0) + j], w[j], af[0][kt * 2 + (ks)]);                  \
+        Tr<bf16_t>::mma16(acc1[1][(q0) + j], w[j], af[1][kt * 2 + (ks)]);                  \
+    }                                                                                      \
+    __builtin_amdgcn_sched_barrier(0)
+                RD4(wa, a0, 0);
+                RD4(wb, a0, 8192);
+                LGKM(4); MM1(wa, 0, 0);
+                RD4(wa, a1, 0);
+                LGKM(4); MM1(wb, 0, 4);
+                RD4(wb, a1, 8192);
+                LGKM(4); MM1(wa, 1, 0);
+                LGKM(0); MM1(wb, 1, 4);
+#undef RD4
+#undef MM1
+            }
+        }
+        if (c == 1) MSTAMP(6);
+        // ================= bias + GELU, re-pack as fc2 operand fragments =================
+        // acc1[mf][nf][e] = h[row li][hidden 128c + 16nf + 4g + e]; fragment f takes nf = 2f (slots 0-3) and 2f+1 (4-7)
+        u32x4 hf[2][4];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                float t[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 b = *(const f32x4*)(b1s + c * 128 + (2 * f + h) * 16 + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[4 * h + e] = gelu_fast(acc1[mf][2 * f + h][e] + b[e]);
+                }
+                u32x4 o;
+                o[0] = pack_bf16x2(t[0], t[1]);
+                o[1] = pack_bf16x2(t[2], t[3]);
+                o[2] = pack_bf16x2(t[4], t[5]);
+                o[3] = pack_bf16x2(t[6], t[7]);
+                hf[mf][f] = o;
+            }
+        if (c == 1) MSTAMP(7);
+        // ================= fc2 chunk: acc2 += h_c @ W2[:, chunk]^T =================
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int ng = 0; ng < NG; ++ng) {
+                SLAB_SYNC(c, KS + kh * NG + ng);
+                if (my_frags > 0) {
+                    // 4 groups per slab: (fl, 4 output-column fragments) -> 8 x ds_read_b64, 8 MFMAs; two register sets
+                    const uint32_t sb = lbase + SLAB_ADDR(c, KS + kh * NG + ng);
+                    const uint32_t b00 = sb + f2off[0][0], b01 = sb + f2off[0][1], b10 = sb + f2off[1][0], b11 = sb + f2off[1][1];
+                    u32x2 la[4], ha[4], lb[4], hb[4];
+#define DSR64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define RD8(l, h, alo, ahi, base)                                       \
+    DSR64(l[0], alo, base + 0);    DSR64(h[0], ahi, base + 0);          \
+    DSR64(l[1], alo, base + 2048); DSR64(h[1], ahi, base + 2048);       \
+    DSR64(l[2], alo, base + 4096); DSR64(h[2], ahi, base + 4096);       \
+    DSR64(l[3], alo, base + 6144); DSR64(h[3], ahi, base + 6144)
+#define MM2(l, h, fl, q0)                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+        if (ng * 8 + (q0) + j < NF2) {                                                        \
+            u32x4 wf;                                                                         \
+            wf[0] = l[j][0]; wf[1] = l[j][1]; wf[2] = h[j][0]; wf[3] = h[j][1];               \
+            Tr<bf16_t>::mma16(acc2[0][ng * 8 + (q0) + j], wf, hf[0][2 * kh + (fl)]);          \
+            Tr<bf16_t>::mma16(acc2[1][ng * 8 + (q0) + j], wf, hf[1][2 * kh + (fl)]);          \
+        }                                                                                     \
+    }                                                                                         \
+    __builtin_amdgcn_sched_barrier(0)
+                    RD8(la, ha, b00, b01, 0);
+                    RD8(lb, hb, b00, b01, 8192);
+                    LGKM(8); MM2(la, ha, 0, 0);
+                    RD8(la, ha, b10, b11, 0);
+                    LGKM(8); MM2(lb, hb, 0, 4);
+                    RD8(lb, hb, b10, b11, 8192);
+                    LGKM(8); MM2(la, ha, 1, 0);
+                    LGKM(0); MM2(lb, hb, 1, 4);
+#undef DSR64
+#undef RD8
+#undef MM2
+                }
+            }
+    }
+    MSTAMP(3);
+#undef DSR128
+#undef LGKM
+#undef SLAB_SYNC
+#undef SLAB_ADDR
+
+    // ---- epilogue: x <- x + y1 + acc2 + b2 (this workgroup owns its rows: in place, no other reader) ----
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        const int r = (wave * 2 + mf) * 16 + li;
+        if (r < nrows) {
+            float* xr = p.x + (int64_t)(row0 + r) * D;
+            const bf16_t* yr = p.y1 ? (const bf16_t*)p.y1 + (int64_t)(row0 + r) * D : nullptr;
+#pragma unroll
+            for (int nf = 0; nf < NF2; ++nf) {
+                const int n = nf * 16 + 4 * g;
+                f32x4 v = acc2[mf][nf] + *(const f32x4*)(b2s + n) + *(const f32x4*)(xr + n);
+                if (yr) {
+                    const bf16x4 y = __builtin_bit_cast(bf16x4, *(const u32x2*)(yr + n));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)y[e];
+                }
+                *(f32x4*)(xr + n) = v;
+            }
+        }
+    }
+    MSTAMP(4);
+}
+
+template <int KS>
+int launch(const MlpParams& p_in, hipStream_t st) {
+    MlpParams p = p_in;
+    constexpr int D = KS * 64;
+    const int lds = NSLOT * SLAB_BYTES + (3 * D + p.hidden) * 4;
+    auto k = mlp_kernel<KS>;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            hipt_set_error("hipFuncSetAttribute(mlp) failed");
+            return HIPT_E_LAUNCH;
+        }
+        attr = true;
+    }
+    // whole rounds of 256 workgroups take 128 rows each; a last partial round that would be less than a
+    // quarter full is cut into 16-row workgroups instead
+    const int tiles = (p.M + TMR - 1) / TMR;
+    const int rem = tiles % 256;
+    int tail_tiles = (tiles > 256 && rem > 0 && rem <= 32) ? rem : 0;
+    p.full_tiles = tiles - tail_tiles;
+    const int tail_rows = p.M - p.full_tiles * TMR;
+    const int grid = p.full_tiles + (tail_rows > 0 ? (tail_rows + 15) / 16 : 0);
+
+    static const bool want_stamps = getenv("HIPT_SEQGEMM_STAMPS") != nullptr;
+    static unsigned long long* dbuf = nullptr;
+    if (want_stamps) {
+        if (!dbuf) (void)hipMalloc(&dbuf, 4096 * 8 * sizeof(unsigned long long));
+        p.stamps = dbuf;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
+    HIPT_CHECK_LAUNCH();
+    if (want_stamps && grid <= 4096) {
+        static unsigned long long h[4096 * 8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, dbuf, (size_t)grid * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t4 = 0;
+        for (int b = 0; b < grid; ++b) {
+            if (h[b * 8] < t0) t0 = h[b * 8];
+            if (h[b * 8 + 4] > t4) t4 = h[b * 8 + 4];
+        }
+        double ph[4] = {0, 0, 0, 0};
+        const int nb = grid < 256 ? grid : 256;
+        for (int b = 0; b < nb; ++b)
+            for (int k2 = 0; k2 < 4; ++k2) ph[k2] += (double)(h[b * 8 + k2 + 1] - h[b * 8 + k2]) * 0.01 / nb;
+        double c1 = 0, c2 = 0;
+        for (int b = 0; b < nb; ++b) {
+            c1 += (double)(h[b * 8 + 6] - h[b * 8 + 5]) * 0.01 / nb;
+            c2 += (double)(h[b * 8 + 7] - h[b * 8 + 6]) * 0.01 / nb;
+        }
+        fprintf(stderr, "[mlp KS=%d hidden=%d grid=%d full=%d] total %.1f us | first-256 WGs: stage %.1f, Aload+LN %.1f, chunks %.1f (chunk1: fc1 %.2f, gelu %.2f), epilogue %.1f\n", KS,
+                p.hidden, grid, p.full_tiles, (double)(t4 - t0) * 0.01, ph[0], ph[1], ph[2], c1, c2, ph[3]);
+    }
+    return HIPT_OK;
+}
+
+}  // namespace
+
+bool hipt_mlp_supported(int dtype, int D, int hidden) {
+    return dtype == HIPT_BF16 && (D == 384 || D == 192) && hidden % 128 == 0 && hidden <= 4096;
+}
+
+int hipt_mlp_launch(const MlpParams& p, hipStream_t st) {
+    HIPT_CHECK_ARG(p.M > 0 && p.x && p.w1 && p.w2 && p.b1 && p.b2 && p.ln_w && p.ln_b, "mlp: null/empty argument");
+    HIPT_CHECK_ARG(((uintptr_t)p.x % 16) == 0 && ((uintptr_t)p.w1 % 16) == 0 && ((uintptr_t)p.w2 % 16) == 0 &&
+                       ((uintptr_t)p.y1 % 16) == 0,
+                   "mlp: 16-byte alignment required");
+    if (p.D == 384) return launch<6>(p, st);
+    if (p.D == 192) return launch<3>(p, st);
+    hipt_set_error("mlp: D=%d not in {192, 384}", p.D);
+    return HIPT_E_UNSUPPORTED;
+}

@@ -46,6 +46,16 @@ enum {
 int hipt_abi_version(void);
 const char* hipt_last_error(void);
 
+/* Optional per-kernel timing for benchmarking (not part of the reference surface): when enabled,
+ * every kernel launch of the calls below is bracketed by HIP events on the caller's stream.
+ * hipt_profile_read() synchronises on them, returns total milliseconds and launch counts per
+ * category (hipt_profile_categories() entries, named by hipt_profile_category_name) and resets.
+ * Returns HIPT_E_WORKSPACE if more launches were issued than the event pool (8192) holds. */
+int hipt_profile_enable(int on);
+int hipt_profile_categories(void);
+const char* hipt_profile_category_name(int i);
+int hipt_profile_read(float* ms, int* counts);
+
 /* ------------------------------------------------------------------------------------
  * Transformer block weights: Block / Attention / Mlp
  * (HIPT_4K/vision_transformer.py:88-152, duplicated HIPT_4K/vision_transformer4k.py:94-158).
