@@ -1,0 +1,392 @@
+// CLAM_SB / ABMIL gated-attention pooling, bf16 hot configuration [S0, 128, 64], streaming form
+// (models/model_clam.py:41-64, 83-92, 147-183; same math as abmil.hip, which remains the general kernel).
+//
+// HBM-bound design: the 100 000 x 384 bf16 bag (76.8 MB) is read exactly once; nothing else moves.
+//   * weights are staged ONCE per workgroup into LDS as swizzled MFMA operand images (W1: 6 slabs of
+//     [128 hidden x 64 k] = 96 KiB; [Wa;Wb] with rows interleaved a,a,b,b: 32 KiB);
+//   * every WAVE owns a contiguous range of rows end to end — no barrier, no LDS exchange in steady
+//     state.  Per step of 32 rows (2 MFMA row fragments):
+//       - the rows go HBM -> VGPRs directly in operand-fragment layout (lane (li,g) loads the 16-byte
+//         chunks g, g+4, ... of row li), double buffered one step ahead;
+//       - h1 = ReLU(x W1^T + b1) accumulates in registers (W1 fragments read from LDS, each feeding 2 MFMAs);
+//       - the accumulators are re-packed in place as the operand of the gate GEMM (accumulator-as-operand:
+//         the lane that owns 4 consecutive hidden units of a row owns exactly those K slots; the [Wa;Wb]
+//         fragments are read with the matching K permutation), so h1 never leaves the register file;
+//       - tanh * sigmoid as two sigmoids, dotted with wc: lane-local sum over the gate units + 2 shuffles;
+//       - softmax pooling in fp32 on the un-rounded h1 accumulators: per-wave running max, each lane
+//         accumulates its own rows' p * h1, one 16-lane reduction at the very end.
+//   * partial (max, sum, acc[128]) per wave; the shared combine kernel merges them.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int SLAB = 128 * 128;  // 16 KiB: 128 rows x 64 bf16
+constexpr int S1 = 128, S2 = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+
+// tanh(x) * sigmoid(y) * w with ONE reciprocal: (E - 1) w / ((E + 1)(1 + F)), E = e^{2x}, F = e^{-y}.
+// x is clamped to +-15 (tanh is 1 - 2e-13 there) so E stays finite; F = inf gives 0 as it should.
+__device__ __forceinline__ float gate1(float x, float y, float w) {
+    x = fminf(fmaxf(x, -15.0f), 15.0f);
+    const float E = __builtin_amdgcn_exp2f(x * (2.0f * LOG2E));
+    const float F = __builtin_amdgcn_exp2f(y * -LOG2E);
+    return (E - 1.0f) * w * __builtin_amdgcn_rcpf((E + 1.0f) * (1.0f + F));
+}
+
+__device__ __forceinline__ float sigm(float x) {  // 1 / (1 + 2^(-x log2 e)); saturates cleanly at +-inf
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -LOG2E));
+}
+
+#define DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define DSR64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define LGKM(n)                                             \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0)
+
+template <int KS>  // S0 = 64 * KS
+__global__ __launch_bounds__(256, 1) void abmil_stream_kernel(const bf16_t* __restrict__ bag, int N, int rows_per_wave,
+                                                              const bf16_t* __restrict__ w1, const float* __restrict__ b1,
+                                                              const bf16_t* __restrict__ wab, const float* __restrict__ bab,
+                                                              const float* __restrict__ wc, const float* __restrict__ bc,
+                                                              float* __restrict__ A_raw, float* __restrict__ partials,
+                                                              int attention_only, unsigned long long* stamps) {
+#define ASTAMP(k)                                                                                          \
+    do {                                                                                                   \
+        if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+    ASTAMP(0);
+    constexpr int S0 = KS * 64;
+    constexpr int NC = KS * 2;  // 16-byte chunks per lane per row
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // W1 image (KS slabs) | [Wa;Wb] image (2 slabs)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+
+    // ---- stage the weights (LDS-DMA, swizzle on the source address) ----
+    {
+        const int r0 = wave * 8 + (lane >> 3);
+        const int ch0 = (lane & 7) ^ ((r0 >> 1) & 7);
+#pragma unroll
+        for (int kt = 0; kt < KS; ++kt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                glds16(w1 + (int64_t)(q * 32 + r0) * S0 + (kt * 8 + ch0) * 8, smem + kt * SLAB + (q * 4 + wave) * 1024);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = q * 32 + r0;  // packed gate row -> source row ((r&3)>>1)*S2 + (r>>2)*2 + (r&1)
+                const int srow = ((r & 3) >> 1) * S2 + (r >> 2) * 2 + (r & 1);
+                glds16(wab + (int64_t)srow * S1 + (sl * 8 + ch0) * 8, smem + (KS + sl) * SLAB + (q * 4 + wave) * 1024);
+            }
+    }
+    // small constants -> LDS (kept out of the register file: the streaming loop needs all of it):
+    // b1[128] | ba[64] | bb[64] | wc[64]
+    float* cst = (float*)(smem + (KS + 2) * SLAB);
+    for (int i = tid; i < S1; i += 256) cst[i] = b1[i];
+    for (int i = tid; i < 2 * S2; i += 256) cst[S1 + i] = bab[i];
+    for (int i = tid; i < S2; i += 256) cst[S1 + 2 * S2 + i] = wc[i];
+    const float bcv = bc[0];
+    wait_vm0();
+    __syncthreads();  // weights are in LDS; from here on the waves never synchronise again
+    ASTAMP(1);
+
+    // ---- my rows ----
+    const int gw = blockIdx.x * 4 + wave;
+    const int rbeg = gw * rows_per_wave;
+    int rend = rbeg + rows_per_wave;
+    rend = rend < N ? rend : N;
+    const int nstep = rend > rbeg ? (rend - rbeg + 31) / 32 : 0;
+
+    const uint32_t lbase = lds_addr(smem);
+    uint32_t foff[2], fhi[2], f2off[2][2];  // ds_read immediates are 16-bit: slabs 3.. use a second base
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        foff[ks] = lbase + li * 128 + (((g + 4 * ks) ^ ((lane >> 1) & 7)) << 4);
+        fhi[ks] = foff[ks] + 3 * SLAB;
+    }
+#pragma unroll
+    for (int fl = 0; fl < 2; ++fl)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int byte = 64 * fl + 32 * h + 8 * g;  // K slots 32fl + 4g + (0..3) and + 16 of a 64-wide slab
+            f2off[fl][h] = lbase + KS * SLAB + li * 128 + (((byte >> 4) ^ ((lane >> 1) & 7)) << 4) + (byte & 8);
+        }
+
+    float m_run = -INFINITY, l_lane = 0.f;
+    f32x4 pool[8];
+#pragma unroll
+    for (int nf = 0; nf < 8; ++nf) pool[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load_rows = [&](u32x4 (&xf)[2][NC], int s) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            int r = rbeg + s * 32 + m * 16 + li;
+            r = r < rend ? r : rend - 1;
+            const bf16_t* xr = bag + (int64_t)r * S0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) xf[m][c] = *(const u32x4*)(xr + (g + 4 * c) * 8);
+        }
+    };
+
+    auto compute = [&](u32x4 (&xf)[2][NC], int s) {
+        // ================= phase 1: acc1[m][nf] = x W1^T  (lane: row li of fragment m, hidden 16nf + 4g + e) =================
+        f32x4 acc1[2][8];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf) acc1[m][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define RD4(w, addr, base)            \
+    DSR128(w[0], addr, base + 0);     \
+    DSR128(w[1], addr, base + 2048);  \
+    DSR128(w[2], addr, base + 4096);  \
+    DSR128(w[3], addr, base + 6144)
+#define MM1(w, c, q0)                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                     \
+        Tr<bf16_t>::mma16(acc1[0][(q0) + j], w[j], xf[0][c]);           \
+        Tr<bf16_t>::mma16(acc1[1][(q0) + j], w[j], xf[1][c]);           \
+    }                                                                   \
+    __builtin_amdgcn_sched_barrier(0)
+// one W1 slab (kt): wa holds (kt, ks0, nf 0-3) on entry; B = base pair for this slab, O = its byte offset (< 64 KiB)
+#define PH1(B, O, c0)                                   \
+    RD4(wb, B[0], O + 8192);                             \
+    LGKM(4); MM1(wa, c0, 0);                             \
+    RD4(wa, B[1], O);                                    \
+    LGKM(4); MM1(wb, c0, 4);                             \
+    RD4(wb, B[1], O + 8192);                             \
+    LGKM(4); MM1(wa, (c0) + 1, 0)
+        {
+            u32x4 wa[4], wb[4];
+            RD4(wa, foff[0], 0);
+            PH1(foff, 0, 0);     RD4(wa, foff[0], 16384); LGKM(4); MM1(wb, 1, 4);
+            PH1(foff, 16384, 2); RD4(wa, foff[0], 32768); LGKM(4); MM1(wb, 3, 4);
+            if constexpr (KS == 3) {
+                PH1(foff, 32768, 4); LGKM(0); MM1(wb, 5, 4);
+            } else {
+                PH1(foff, 32768, 4);  RD4(wa, fhi[0], 0);     LGKM(4); MM1(wb, 5, 4);
+                PH1(fhi, 0, 6);       RD4(wa, fhi[0], 16384); LGKM(4); MM1(wb, 7, 4);
+                PH1(fhi, 16384, 8);   RD4(wa, fhi[0], 32768); LGKM(4); MM1(wb, 9, 4);
+                PH1(fhi, 32768, 10);  LGKM(0); MM1(wb, 11, 4);
+            }
+        }
+#undef PH1
+#undef RD4
+#undef MM1
+        // ================= h1 = ReLU(. + b1); re-pack as operand fragments of the gate GEMM =================
+        u32x4 hf[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf) {
+                acc1[m][nf] += *(const f32x4*)(cst + 16 * nf + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1[m][nf][e] = fmaxf(acc1[m][nf][e], 0.f);
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                u32x4 o;
+                o[0] = pack_bf16x2(acc1[m][2 * f][0], acc1[m][2 * f][1]);
+                o[1] = pack_bf16x2(acc1[m][2 * f][2], acc1[m][2 * f][3]);
+                o[2] = pack_bf16x2(acc1[m][2 * f + 1][0], acc1[m][2 * f + 1][1]);
+                o[3] = pack_bf16x2(acc1[m][2 * f + 1][2], acc1[m][2 * f + 1][3]);
+                hf[m][f] = o;
+            }
+        }
+        // ================= phase 2: ab[m][n2] = h1 [Wa;Wb]^T, gate, A =================
+        f32x4 acc2[2][8];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) acc2[m][n2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define RD8(l, h, alo, ahi, base)                                   \
+    DSR64(l[0], alo, base + 0);    DSR64(h[0], ahi, base + 0);      \
+    DSR64(l[1], alo, base + 2048); DSR64(h[1], ahi, base + 2048);   \
+    DSR64(l[2], alo, base + 4096); DSR64(h[2], ahi, base + 4096);   \
+    DSR64(l[3], alo, base + 6144); DSR64(h[3], ahi, base + 6144)
+#define MM2(l, h, f, q0)                                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                             \
+        u32x4 wf;                                                               \
+        wf[0] = l[j][0]; wf[1] = l[j][1]; wf[2] = h[j][0]; wf[3] = h[j][1];     \
+        Tr<bf16_t>::mma16(acc2[0][(q0) + j], wf, hf[0][f]);                     \
+        Tr<bf16_t>::mma16(acc2[1][(q0) + j], wf, hf[1][f]);                     \
+    }                                                                           \
+    __builtin_amdgcn_sched_barrier(0)
+        {
+            u32x2 la[4], ha[4], lb[4], hb[4];
+            // operand fragment f = 2 * slab + fl covers hidden units [32f, 32f + 32)
+            RD8(la, ha, f2off[0][0], f2off[0][1], 0);
+            RD8(lb, hb, f2off[0][0], f2off[0][1], 8192);
+            LGKM(8); MM2(la, ha, 0, 0);
+            RD8(la, ha, f2off[1][0], f2off[1][1], 0);
+            LGKM(8); MM2(lb, hb, 0, 4);
+            RD8(lb, hb, f2off[1][0], f2off[1][1], 8192);
+            LGKM(8); MM2(la, ha, 1, 0);
+            RD8(la, ha, f2off[0][0], f2off[0][1], 16384);
+            LGKM(8); MM2(lb, hb, 1, 4);
+            RD8(lb, hb, f2off[0][0], f2off[0][1], 24576);
+            LGKM(8); MM2(la, ha, 2, 0);
+            RD8(la, ha, f2off[1][0], f2off[1][1], 16384);
+            LGKM(8); MM2(lb, hb, 2, 4);
+            RD8(lb, hb, f2off[1][0], f2off[1][1], 24576);
+            LGKM(8); MM2(la, ha, 3, 0);
+            LGKM(0); MM2(lb, hb, 3, 4);
+        }
+#undef RD8
+#undef MM2
+        float a_row[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float gs = 0.f;
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) {
+                const f32x4 v = acc2[m][n2];  // (a_j0, a_j0+1, b_j0, b_j0+1), j0 = 8 n2 + 2 g
+                const int j0 = 8 * n2 + 2 * g;
+                const f32x2 ba = *(const f32x2*)(cst + S1 + j0), bb = *(const f32x2*)(cst + S1 + S2 + j0),
+                            cw = *(const f32x2*)(cst + S1 + 2 * S2 + j0);
+                gs += gate1(v[0] + ba[0], v[2] + bb[0], cw[0]);
+                gs += gate1(v[1] + ba[1], v[3] + bb[1], cw[1]);
+            }
+            gs += __shfl_xor(gs, 16, 64);
+            gs += __shfl_xor(gs, 32, 64);
+            const int r = rbeg + s * 32 + m * 16 + li;
+            const bool valid = r < rend;
+            a_row[m] = valid ? gs + bcv : -INFINITY;
+            if (valid && g == 0) A_raw[r] = a_row[m];
+        }
+        if (attention_only) return;
+        // ================= softmax pooling (fp32, on the un-rounded h1) =================
+        const float mt = wave_max(fmaxf(a_row[0], a_row[1]));  // finite: every step has at least one valid row
+        const float m_new = fmaxf(m_run, mt);
+        const float resc = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);  // 0 on the first step
+        m_run = m_new;
+        const float p0 = __builtin_amdgcn_exp2f((a_row[0] - m_new) * LOG2E), p1 = __builtin_amdgcn_exp2f((a_row[1] - m_new) * LOG2E);
+        l_lane = l_lane * resc + p0 + p1;
+#pragma unroll
+        for (int nf = 0; nf < 8; ++nf) pool[nf] = pool[nf] * resc + acc1[0][nf] * p0 + acc1[1][nf] * p1;
+    };
+
+    // ---- double-buffered stream over my rows ----
+    u32x4 xa[2][NC], xb[2][NC];
+    if (nstep > 0) load_rows(xa, 0);
+    for (int s = 0; s < nstep; s += 2) {
+        if (s + 1 < nstep) load_rows(xb, s + 1);
+        if (s == 0) ASTAMP(2);
+        compute(xa, s);
+        if (s == 0) ASTAMP(3);
+        if (s + 1 < nstep) {
+            if (s + 2 < nstep) load_rows(xa, s + 2);
+            compute(xb, s + 1);
+            if (s == 0) ASTAMP(4);
+        }
+    }
+    ASTAMP(5);
+
+    if (!attention_only) {
+        // every lane (li, g) holds the contribution of its rows to columns 16nf + 4g + e: sum over li (16 lanes);
+        // l: the 4 g-lanes of a row hold the same p, count each row once (g == 0) and sum over li
+        float l = g == 0 ? l_lane : 0.f;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            l += __shfl_xor(l, o, 64);
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pool[nf][e] += __shfl_xor(pool[nf][e], o, 64);
+        }
+        // merge the 4 waves of this workgroup through LDS (the weight images are dead now): slot w = (m, l, acc[128])
+        __syncthreads();
+        float* red = (float*)smem;
+        if (lane == 0) {
+            red[wave * 132] = nstep > 0 ? m_run : -INFINITY;
+            red[wave * 132 + 1] = l;
+        }
+        if (li == 0) {
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave * 132 + 2 + 16 * nf + 4 * g + e] = pool[nf][e];
+        }
+        __syncthreads();
+        if (tid < S1 + 2) {
+            const float m0 = red[0], m1 = red[132], m2 = red[264], m3 = red[396];
+            const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+            float* pw = partials + (int64_t)blockIdx.x * (2 + S1);
+            if (tid == 0) {
+                pw[0] = mm;
+            } else {
+                const float f0 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m0 - mm) * LOG2E);
+                const float f1 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m1 - mm) * LOG2E);
+                const float f2 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m2 - mm) * LOG2E);
+                const float f3 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m3 - mm) * LOG2E);
+                pw[tid] = red[tid] * f0 + red[132 + tid] * f1 + red[264 + tid] * f2 + red[396 + tid] * f3;
+            }
+        }
+    }
+    ASTAMP(6);
+}
+
+template <int KS>
+int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, float* partials,
+           int* n_partials, hipStream_t st) {
+    constexpr int lds = (KS + 2) * SLAB + (S1 + 3 * S2) * 4;
+    auto k = abmil_stream_kernel<KS>;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            hipt_set_error("hipFuncSetAttribute(abmil stream) failed");
+            return HIPT_E_LAUNCH;
+        }
+        attr = true;
+    }
+    // contiguous row ranges per wave, multiples of 16 rows; at most 256 workgroups x 4 waves
+    int rows = (N + 1023) / 1024;
+    rows = (rows + 15) / 16 * 16;
+    const int waves = (N + rows - 1) / rows;
+    const int grid = (waves + 3) / 4;
+    static const bool want_stamps = getenv("HIPT_ABMIL_STAMPS") != nullptr;
+    static unsigned long long* dbuf = nullptr;
+    if (want_stamps && !dbuf) (void)hipMalloc(&dbuf, 512 * 8 * sizeof(unsigned long long));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (const bf16_t*)bag, N, rows, (const bf16_t*)w->w1, w->b1,
+                       (const bf16_t*)w->wab, w->bab, w->wc, w->bc, A_raw, partials, attention_only, want_stamps ? dbuf : nullptr);
+    HIPT_CHECK_LAUNCH();
+    if (want_stamps && grid <= 512) {
+        static unsigned long long h[512 * 8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, dbuf, (size_t)grid * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t6 = 0;
+        for (int b = 0; b < grid; ++b) {
+            if (h[b * 8] < t0) t0 = h[b * 8];
+            if (h[b * 8 + 6] > t6) t6 = h[b * 8 + 6];
+        }
+        double ph[6] = {0, 0, 0, 0, 0, 0}, smax = 0;
+        for (int b = 0; b < grid; ++b) {
+            for (int k2 = 0; k2 < 6; ++k2) ph[k2] += (double)(h[b * 8 + k2 + 1] - h[b * 8 + k2]) * 0.01 / grid;
+            const double s0 = (double)(h[b * 8] - t0) * 0.01;
+            if (s0 > smax) smax = s0;
+        }
+        fprintf(stderr, "[abmil stream N=%d grid=%d rows/wave=%d] total %.1f us | start<=%.1f; weights->LDS %.1f; issue loads %.1f; step0 %.1f; step1 %.1f; steps2+ %.1f; final %.1f\n",
+                N, grid, rows, (double)(t6 - t0) * 0.01, smax, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
+    }
+    *n_partials = grid;
+    return HIPT_OK;
+}
+
+}  // namespace
+
+bool hipt_clam_stream_supported(const hipt_clam_weights* w) {
+    return w->dtype == HIPT_BF16 && w->s1 == S1 && w->s2 == S2 && (w->s0 == 384 || w->s0 == 192) &&
+           getenv("HIPT_NO_ABMIL2") == nullptr;
+}
+
+int hipt_clam_stream_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw,
+                            float* partials, int* n_partials, hipStream_t st) {
+    if (w->s0 == 384) return launch<6>(w, bag, N, attention_only, A_raw, partials, n_partials, st);
+    if (w->s0 == 192) return launch<3>(w, bag, N, attention_only, A_raw, partials, n_partials, st);
+    hipt_set_error("clam stream: unsupported S0=%d", w->s0);
+    return HIPT_E_UNSUPPORTED;
+}

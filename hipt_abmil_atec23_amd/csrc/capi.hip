@@ -527,7 +527,9 @@ int hipt_clam_sb_forward(const hipt_clam_weights* w, const void* bag, int N, int
     float* partials = (float*)c.take(clam_partials_bytes(w, N));
     float* gmax = (float*)c.take(256);
     int G = 0;
-    if (hipt_clam_fused_supported(w)) {
+    if (hipt_clam_stream_supported(w)) {  // bf16 [S0,128,64]: weight-stationary streaming kernel
+        PROF(PC_ABMIL, hipt_clam_stream_launch(w, bag, N, attention_only, A_raw, partials, &G, st));
+    } else if (hipt_clam_fused_supported(w)) {
         PROF(PC_ABMIL, hipt_clam_fused_launch(w, bag, N, attention_only, A_raw, partials, &G, st));
     } else {
         float* h1 = (float*)c.take((size_t)N * w->s1 * 4);

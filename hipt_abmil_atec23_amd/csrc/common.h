@@ -91,6 +91,30 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
+// ---- "invisible" LDS accesses -----------------------------------------------------------------------
+// While LDS-DMA (global_load_lds) is in flight, hipcc cannot prove that a C++-level LDS access does not
+// alias the DMA destination and inserts s_waitcnt vmcnt(0) in front of it — draining the whole DMA ring.
+// Inside ring loops every LDS access therefore goes through these helpers (the compiler sees no LDS op);
+// each carries its own lgkmcnt(0), so they are for the non-hot accesses (biases, tiny exchange buffers).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(LDS_AS const char*)p; }
+__device__ __forceinline__ f32x4 lds_ld128(uint32_t a) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ float lds_ld32(uint32_t a) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ u32x2 lds_ld_tr64(uint32_t a) {  // ds_read_b64_tr_b16: EXEC must be all ones
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_st32(uint32_t a, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st64(uint32_t a, u32x2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // XCD-aware bijective remap of a linear block id: blocks b and b+8 share an XCD (and its L2),

@@ -51,8 +51,8 @@ __device__ __forceinline__ void wait_slabs(int slabs) {
 // outstanding store and the whole W ring once per fragment (measured: 2-3x kernel time).  The bias comes
 // from LDS; the residual add is deferred to the consumer kernel's activation load.
 template <int FLAGS>
-__device__ __forceinline__ void seq_epilogue(const SeqGemmParams& p, const float* bias_lds, int64_t row, int n, f32x4 v) {
-    v += *(const f32x4*)(bias_lds + n);
+__device__ __forceinline__ void seq_epilogue(const SeqGemmParams& p, uint32_t bias_lds, int64_t row, int n, f32x4 v) {
+    v += lds_ld128(bias_lds + n * 4);  // asm LDS read: a visible one would cost a vmcnt(0) ring drain (common.h)
     if constexpr (FLAGS & HIPT_EPI_GELU) {
         if (!(p.debug & 4)) {
 #pragma unroll
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void seqgemm_kernel(const SeqGemmParams p) 
 #pragma unroll
                 for (int nf = 0; nf < 8; ++nf) {
                     const int n = n0 + nf * 16 + 4 * g;
-                    if (n < p.N) seq_epilogue<FLAGS>(p, bia, row0 + r, n, acc[mf][nf]);
+                    if (n < p.N) seq_epilogue<FLAGS>(p, lds_addr(bia), row0 + r, n, acc[mf][nf]);
                 }
             }
         }
