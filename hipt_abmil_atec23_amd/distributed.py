@@ -77,9 +77,8 @@ def gather_slide_outputs(slide_ids: Sequence[int], logits: Sequence[torch.Tensor
         block[j, 2:2 + C] = logits[j].reshape(-1).float()
         block[j, 2 + C:2 + C + n] = a_raw[j].reshape(-1).float()
     if ws > 1:
-        out = torch.empty((ws,) + tuple(block.shape), dtype=torch.float32, device=device)
+        out = torch.empty((ws * S, block.shape[1]), dtype=torch.float32, device=device)  # concatenated along dim 0
         dist.all_gather_into_tensor(out, block)
-        out = out.reshape(ws * S, -1)
     else:
         out = block
     all_logits = torch.zeros((n_slides, C), dtype=torch.float32, device=device)

@@ -12,6 +12,7 @@ The reference imports the hot-path classes by module path:
 from __future__ import annotations
 
 import importlib
+import importlib.util
 import sys
 import types
 
@@ -31,11 +32,23 @@ def install(verbose: bool = False):
     for ref_name, ours in _MAP.items():
         mod = importlib.import_module(f"{pkg}.{ours}")
         parent_name = ref_name.split(".")[0]
-        if parent_name == "HIPT_4K" and parent_name not in sys.modules:
-            # the reference's HIPT_4K/ directory is a namespace of four files we replace entirely
-            parent = types.ModuleType(parent_name)
-            parent.__path__ = []
-            sys.modules[parent_name] = parent
+        if parent_name not in sys.modules:
+            # HIPT_4K/: a directory of four files we replace entirely -> always a stub namespace.
+            # models/: the reference's real package (model_mil.py, resnet_custom.py ...) must keep working,
+            # so it is imported if it is on sys.path and only stubbed when there is no reference checkout.
+            spec = None
+            if parent_name != "HIPT_4K":
+                try:
+                    spec = importlib.util.find_spec(parent_name)
+                except (ImportError, ValueError):
+                    spec = None
+            if spec is not None:
+                importlib.import_module(parent_name)
+            else:
+                parent = types.ModuleType(parent_name)
+                parent.__path__ = []
+                parent.__hipt_amd_stub__ = True
+                sys.modules[parent_name] = parent
         sys.modules[ref_name] = mod
         parent = sys.modules.get(parent_name)
         if parent is not None:
@@ -49,5 +62,6 @@ def install(verbose: bool = False):
 def uninstall():
     for ref_name in _MAP:
         sys.modules.pop(ref_name, None)
-    if "HIPT_4K" in sys.modules and not getattr(sys.modules["HIPT_4K"], "__file__", None):
-        sys.modules.pop("HIPT_4K", None)
+    for parent in ("HIPT_4K", "models"):
+        if getattr(sys.modules.get(parent), "__hipt_amd_stub__", False):
+            sys.modules.pop(parent, None)
