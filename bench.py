@@ -53,11 +53,30 @@ def build_models(dev, dtype):
     return m, c
 
 
-def gemm_flops(cat, chunk_rows):
-    D, H = 384, 1536
-    return {"qkv_gemm": 2 * chunk_rows * 3 * D * D, "proj_gemm": 2 * chunk_rows * D * D,
-            "fc1_gemm": 2 * chunk_rows * D * H, "fc2_gemm": 2 * chunk_rows * D * H,
-            "attention": 4 * (chunk_rows // 257) * 6 * 257 * 257 * 64}.get(cat)
+def kernel_flops(cat, rows, D=384, H=1536, heads=6, ntok=257):
+    """Algorithmic FLOPs of one launch of a kernel category over `rows` token rows."""
+    dh = D // heads
+    return {"qkv_gemm": 2 * rows * 3 * D * D, "proj_gemm": 2 * rows * D * D,
+            "fc1_gemm": 2 * rows * D * H, "fc2_gemm": 2 * rows * D * H, "mlp_fused": 4 * rows * D * H,
+            "attention": 4 * (rows // ntok) * heads * ntok * ntok * dh}.get(cat)
+
+
+# rocprofv3 kernel names of the categories (profiles/<tag>_traffic.json keys)
+TRAFFIC_KEYS = {"mlp_fused": "void mlp_kernel<6>", "qkv_gemm": "void seqgemm_kernel<6, true, 0>",
+                "proj_gemm": "void seqgemm_kernel<6, false, 0>", "attention": "attn_kernel<DF16bLi64ELi18ELb0E>",
+                "abmil_fused": "void abmil_stream_kernel<6>"}
+
+
+def pmc_traffic(cat):
+    """Per-launch HBM bytes from the committed PMC summary (separate rocprofv3 --pmc passes, corrected
+    as MI355X_MICROARCH.md prescribes; tools/summarize_profile.py), or None."""
+    for f in sorted([p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_traffic.json")], reverse=True) \
+            if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        t = json.load(open(os.path.join(ROOT, "profiles", f)))
+        k = TRAFFIC_KEYS.get(cat)
+        if k in t:
+            return t[k]["hbm_bytes"]
+    return None
 
 
 def host_cores():
@@ -207,31 +226,32 @@ def main():
         prof = N.profile_read()
         N.profile_enable(False)
     chunk_rows = (args.chunk or 256) * 257
+    n256 = 12 * (256 // (args.chunk or 256))  # ViT-256 launches per step and category
     kernels = {}
     for cat, (ms, cnt) in prof.items():
-        k = {"launches_per_step": cnt / args.profile_steps, "total_ms": ms, "avg_us": ms / cnt * 1e3, "ms_per_step": ms / args.profile_steps}
-        fl = gemm_flops(cat, chunk_rows)
-        if fl and cat != "embed_gemm":
-            # ViT-4K launches of the same category are ~1e-3 of the work; price the ViT-256 launches
-            k["tflops_if_vit256_shape"] = fl / (ms / cnt * 1e-3) / 1e12
-        kernels[cat] = k
+        kernels[cat] = {"launches_per_step": cnt / args.profile_steps, "total_ms": ms, "avg_us": ms / cnt * 1e3,
+                        "ms_per_step": ms / args.profile_steps}
     out["kernels"] = kernels
-    mf = {c: v for c, v in kernels.items() if c in ("qkv_gemm", "proj_gemm", "fc1_gemm", "fc2_gemm", "attention")}
+    mf = {c: v for c, v in kernels.items() if kernel_flops(c, chunk_rows)}
     if mf:
+        # dominant kernel = largest share of the step.  Each category has 12 ViT-256 launches (65 792 rows)
+        # and 6 ViT-4K launches (257 rows, D=192) per region: achieved = all their algorithmic FLOPs / their time.
         dom = max(mf, key=lambda c: mf[c]["ms_per_step"])
-        # 18 launches per step per category: 12 ViT-256 (big) + 6 ViT-4K (257 rows).  Total algorithmic
-        # flops of the category per step / total time of the category per step:
-        n256 = 12 * (256 // (args.chunk or 256))
-        fl_step = n256 * gemm_flops(dom, chunk_rows) + 6 * (gemm_flops(dom, 257) if dom != "attention" else 4 * 6 * 257 * 257 * 32)
+        fl_step = n256 * kernel_flops(dom, chunk_rows) + 6 * kernel_flops(dom, 257, D=192, H=768)
         ach = fl_step / (mf[dom]["ms_per_step"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                           "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": None}
+                           "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": pmc_traffic(dom),
+                           "flops_per_step": fl_step, "launches_per_step": mf[dom]["launches_per_step"],
+                           "avg_launch_us": mf[dom]["avg_us"]}
+        out["roofline_all"] = {c: round((n256 * kernel_flops(c, chunk_rows) + 6 * kernel_flops(c, 257, D=192, H=768)) /
+                                        (v["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4) for c, v in mf.items()}
     if "abmil_fused" in kernels:
         esz = 2 if args.dtype == "bf16" else 4
         alg = BAG_N * BAG_S0 * esz + 4 * BAG_N
         gbs = alg / (kernels["abmil_fused"]["avg_us"] * 1e-6) / 1e9
         out["roofline_abmil"] = {"kernel": "abmil_fused", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": gbs / PEAK_HBM_GBS, "traffic": None, "algorithmic_bytes": alg}
+                                 "frac": gbs / PEAK_HBM_GBS, "traffic": pmc_traffic("abmil_fused"), "algorithmic_bytes": alg,
+                                 "avg_launch_us": kernels["abmil_fused"]["avg_us"]}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

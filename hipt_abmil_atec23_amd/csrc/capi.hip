@@ -37,9 +37,9 @@ struct Carver {
 };
 
 // ---- optional per-kernel timing (bench.py's roofline leg): HIP events around every launch -----
-enum { PC_EMBED, PC_LN, PC_QKV, PC_ATTN, PC_PROJ, PC_FC1, PC_FC2, PC_ABMIL, PC_COMBINE, PC_OTHER, PC_N };
+enum { PC_EMBED, PC_LN, PC_QKV, PC_ATTN, PC_PROJ, PC_FC1, PC_FC2, PC_MLP, PC_ABMIL, PC_COMBINE, PC_OTHER, PC_N };
 const char* const kProfNames[PC_N] = {"embed_gemm", "layernorm", "qkv_gemm", "attention", "proj_gemm",
-                                      "fc1_gemm",   "fc2_gemm",  "abmil_fused", "abmil_combine", "other"};
+                                      "fc1_gemm",   "fc2_gemm",  "mlp_fused",   "abmil_fused", "abmil_combine", "other"};
 constexpr int kProfMax = 8192;
 struct Prof {
     bool on = false, created = false;
@@ -149,7 +149,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             memset(&m, 0, sizeof(m));
             m.x = x; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
             m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.M = M; m.D = D; m.hidden = w->hidden;
-            PROF(PC_FC1, hipt_mlp_launch(m, st));
+            PROF(PC_MLP, hipt_mlp_launch(m, st));
             continue;
         } else {
             PROF(PC_LN, hipt_layernorm_launch(x, D, b.ln1_w, b.ln1_b, s.xn, dt, D, M, D, w->ln_eps, st));
