@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--chunk", type=int, default=0, help="patches per ViT-256 pass (0 = library default)")
+    ap.add_argument("--regions", type=int, default=8, help="4096x4096 regions per HIPT_4K call (1 = the reference's batch_size)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -159,7 +160,8 @@ def main():
 
     model, clam = build_models(dev, args.dtype)
     model.chunk = args.chunk
-    region = synth.hash_uniform_torch((1, 3, REGION, REGION), 3 + rank, device=dev)
+    R = args.regions
+    region = synth.hash_uniform_torch((R, 3, REGION, REGION), 3 + rank, device=dev)
     n_bags = 5  # 5 x 76.8 MB > 256 MiB Infinity Cache
     bag_dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     bags = [synth.hash_uniform_torch((BAG_N, BAG_S0), 40 + 10 * rank + i, device=dev).to(bag_dt) for i in range(n_bags)]
@@ -204,16 +206,16 @@ def main():
     if rank != 0:
         return
     out = {
-        "metric": METRIC, "value": world * args.steps / dt, "unit": "regions/s", "n_gpus": world,
+        "metric": METRIC, "value": world * args.steps * R / dt, "unit": "regions/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "per step: HIPT_4K.forward on one [1,3,4096,4096] fp32 region (256 patches ViT-256 -> "
-                               "ViT-4K, BASELINE configs[2]) + CLAM_SB gated-attention pooling over one "
+        "config": {"workload": "per step: HIPT_4K.forward on R resident [3,4096,4096] fp32 regions (R x 256 patches ViT-256 -> "
+                               "ViT-4K over each 16x16 [CLS] grid, BASELINE configs[2]) + CLAM_SB gated-attention pooling over one "
                                "100000x384 bag (configs[3]); random-init weights of the reference architectures",
-                   "regions_per_step": 1, "bag": [BAG_N, BAG_S0], "chunk_patches": args.chunk or 256,
+                   "regions_per_step": R, "bag": [BAG_N, BAG_S0], "chunk_patches": args.chunk or 256 * R,
                    "parallelism": f"slide-sharded x{world}, one all-gather"},
         "abmil_fwd_ms": abmil_ms,
-        "model_tflops": world * args.steps * FLOP_PER_REGION / dt / 1e12,
+        "model_tflops": world * args.steps * R * FLOP_PER_REGION / dt / 1e12,
     }
 
     # ---- per-kernel roofline leg: same workload, HIP events around every launch ----
@@ -225,8 +227,8 @@ def main():
         torch.cuda.synchronize()
         prof = N.profile_read()
         N.profile_enable(False)
-    chunk_rows = (args.chunk or 256) * 257
-    n256 = 12 * (256 // (args.chunk or 256))  # ViT-256 launches per step and category
+    chunk_rows = (args.chunk or 256 * R) * 257
+    n256 = 12 * ((256 * R) // (args.chunk or 256 * R))  # ViT-256 launches per step and category
     kernels = {}
     for cat, (ms, cnt) in prof.items():
         kernels[cat] = {"launches_per_step": cnt / args.profile_steps, "total_ms": ms, "avg_us": ms / cnt * 1e3,
@@ -237,13 +239,13 @@ def main():
         # dominant kernel = largest share of the step.  Each category has 12 ViT-256 launches (65 792 rows)
         # and 6 ViT-4K launches (257 rows, D=192) per region: achieved = all their algorithmic FLOPs / their time.
         dom = max(mf, key=lambda c: mf[c]["ms_per_step"])
-        fl_step = n256 * kernel_flops(dom, chunk_rows) + 6 * kernel_flops(dom, 257, D=192, H=768)
+        fl_step = n256 * kernel_flops(dom, chunk_rows) + 6 * kernel_flops(dom, 257 * R, D=192, H=768)
         ach = fl_step / (mf[dom]["ms_per_step"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                            "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": pmc_traffic(dom),
                            "flops_per_step": fl_step, "launches_per_step": mf[dom]["launches_per_step"],
                            "avg_launch_us": mf[dom]["avg_us"]}
-        out["roofline_all"] = {c: round((n256 * kernel_flops(c, chunk_rows) + 6 * kernel_flops(c, 257, D=192, H=768)) /
+        out["roofline_all"] = {c: round((n256 * kernel_flops(c, chunk_rows) + 6 * kernel_flops(c, 257 * R, D=192, H=768)) /
                                         (v["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4) for c, v in mf.items()}
     if "abmil_fused" in kernels:
         esz = 2 if args.dtype == "bf16" else 4

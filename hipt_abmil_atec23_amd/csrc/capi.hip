@@ -225,7 +225,7 @@ int embed4k(const hipt_vit_weights* w, const void* tokens, int nseq, float* x, h
     return HIPT_OK;
 }
 
-int default_chunk(int nseq) { return nseq < 256 ? nseq : 256; }
+int default_chunk(int nseq) { return nseq < 2048 ? nseq : 2048; }
 
 }  // namespace
 
@@ -423,47 +423,47 @@ int hipt_vit4k_forward(const hipt_vit_weights* w, const float* tokens_in, int ns
     return hipt_layernorm_launch(x, (int64_t)w->ntok * w->dim, w->norm_w, w->norm_b, out, HIPT_F32, w->dim, nseq, w->dim, w->ln_eps, st);
 }
 
-size_t hipt_hipt4k_workspace_bytes(const hipt_vit_weights* w256, const hipt_vit_weights* w4k, int w_256, int h_256,
-                                   int chunk) {
+static hipt_image_layout region_layout(int W, int H) {
     hipt_image_layout lay;
-    lay.grid_w = w_256;
-    lay.grid_h = h_256;
-    lay.patch_h = lay.patch_w = 256;
-    lay.row_stride = (int64_t)h_256 * 256;
-    lay.chan_stride = (int64_t)w_256 * 256 * lay.row_stride;
-    lay.batch_stride = 3 * lay.chan_stride;
-    const int nseq = w_256 * h_256;
-    return hipt_vit256_forward_workspace_bytes(w256, &lay, nseq, chunk) + hipt_vit4k_forward_workspace_bytes(w4k, 1) +
-           al256((size_t)nseq * w256->dim * 4);
-}
-
-int hipt_hipt4k_forward(const hipt_vit_weights* w256, const hipt_vit_weights* w4k, const float* region, int W, int H, int chunk,
-                        float* cls256_out, float* out, void* workspace, size_t ws_bytes, void* stream) {
-    HIPT_CHECK_ARG(w256 && w4k && region && out, "hipt4k_forward: null argument");
-    HIPT_CHECK_ARG(W > 0 && H > 0 && W % 256 == 0 && H % 256 == 0, "hipt4k_forward: region %dx%d must be cropped to multiples of 256",
-                   W, H);
-    const int w_256 = W / 256, h_256 = H / 256, nseq = w_256 * h_256;
-    HIPT_CHECK_ARG(w4k->ntok == nseq + 1, "hipt4k_forward: ViT-4K weights prepared for %d tokens, region has %d", w4k->ntok, nseq + 1);
-    HIPT_CHECK_ARG(w4k->embed_k == w256->dim, "hipt4k_forward: ViT-4K input width %d != ViT-256 width %d", w4k->embed_k, w256->dim);
-    hipt_image_layout lay;
-    lay.grid_w = w_256;
-    lay.grid_h = h_256;
+    lay.grid_w = W / 256;
+    lay.grid_h = H / 256;
     lay.patch_h = lay.patch_w = 256;
     lay.row_stride = H;
     lay.chan_stride = (int64_t)W * H;
     lay.batch_stride = 3 * lay.chan_stride;
+    return lay;
+}
+
+size_t hipt_hipt4k_workspace_bytes(const hipt_vit_weights* w256, const hipt_vit_weights* w4k, int nreg, int w_256, int h_256,
+                                   int chunk) {
+    const hipt_image_layout lay = region_layout(w_256 * 256, h_256 * 256);
+    const int nseq = nreg * w_256 * h_256;
+    return hipt_vit256_forward_workspace_bytes(w256, &lay, nseq, chunk) + hipt_vit4k_forward_workspace_bytes(w4k, nreg) +
+           al256((size_t)nseq * w256->dim * 4);
+}
+
+int hipt_hipt4k_forward(const hipt_vit_weights* w256, const hipt_vit_weights* w4k, const float* regions, int nreg, int W, int H,
+                        int chunk, float* cls256_out, float* out, void* workspace, size_t ws_bytes, void* stream) {
+    HIPT_CHECK_ARG(w256 && w4k && regions && out && nreg > 0, "hipt4k_forward: null/empty argument");
+    HIPT_CHECK_ARG(W > 0 && H > 0 && W % 256 == 0 && H % 256 == 0, "hipt4k_forward: region %dx%d must be cropped to multiples of 256",
+                   W, H);
+    const int per = (W / 256) * (H / 256), nseq = nreg * per;
+    HIPT_CHECK_ARG(w4k->ntok == per + 1, "hipt4k_forward: ViT-4K weights prepared for %d tokens, region has %d", w4k->ntok, per + 1);
+    HIPT_CHECK_ARG(w4k->embed_k == w256->dim, "hipt4k_forward: ViT-4K input width %d != ViT-256 width %d", w4k->embed_k, w256->dim);
+    const hipt_image_layout lay = region_layout(W, H);
     const size_t n256 = hipt_vit256_forward_workspace_bytes(w256, &lay, nseq, chunk);
-    const size_t n4k = hipt_vit4k_forward_workspace_bytes(w4k, 1);
+    const size_t n4k = hipt_vit4k_forward_workspace_bytes(w4k, nreg);
     const size_t ncls = al256((size_t)nseq * w256->dim * 4);
     if (ws_bytes < n256 + n4k + ncls || ((uintptr_t)workspace & 255)) {
         hipt_set_error("hipt4k_forward: workspace %zu B too small / unaligned (need %zu)", ws_bytes, n256 + n4k + ncls);
         return HIPT_E_WORKSPACE;
     }
     char* ws = (char*)workspace;
-    float* cls = cls256_out ? cls256_out : (float*)ws;  // [nseq, 384] token-major: exactly phi's input (hipt_4k.py:72-74)
-    int rc = hipt_vit256_forward(w256, region, &lay, nseq, chunk, cls, ws + ncls, n256, stream);
+    // cls256 [nreg * per, 384] token-major = nreg sequences of `per` tokens: exactly phi's input (hipt_4k.py:72-74)
+    float* cls = cls256_out ? cls256_out : (float*)ws;
+    int rc = hipt_vit256_forward(w256, regions, &lay, nseq, chunk, cls, ws + ncls, n256, stream);
     if (rc) return rc;
-    return hipt_vit4k_forward(w4k, cls, 1, out, ws + ncls + n256, n4k, stream);
+    return hipt_vit4k_forward(w4k, cls, nreg, out, ws + ncls + n256, n4k, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

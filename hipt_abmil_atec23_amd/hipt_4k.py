@@ -8,8 +8,6 @@ hipt_4k.py:70,74, is gone), ViT-4K.
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import torch
 
 from . import _native as N
@@ -58,40 +56,41 @@ class HIPT_4K(torch.nn.Module):
 
     def _run(self, x: torch.Tensor, want_cls256: bool):
         batch, w_256, h_256 = self.prepare_img_tensor(x)
-        if batch.shape[0] != 1:
-            raise ValueError("HIPT_4K.forward takes one region at a time ([1,3,W,H]), as the reference does "
-                             "(hipt_4k.py:73 reshapes the patch features to one grid)")
         if w_256 == 0 or h_256 == 0:
             raise ValueError(f"region {tuple(x.shape)} is smaller than one 256x256 patch")
+        nreg = batch.shape[0]  # the reference takes 1 (hipt_4k.py:73); R > 1 regions are independent -> stacked
         d256 = next(self.model256.parameters()).device
         d4k = next(self.model4k.parameters()).device
         region = batch.to(d256, non_blocking=True).detach().float().contiguous()
         N.require_cuda(region, "HIPT_4K")
-        nseq = w_256 * h_256
+        per = w_256 * h_256
+        nseq = nreg * per
         W, H = region.shape[2], region.shape[3]
         if d256 == d4k:
             m256, m4k = self.model256, self.model4k
             pk256 = m256._packed_for(m256._pos_for(256, 256, 256))
-            pk4k = m4k._packed_for(m4k._pos_for(nseq, w_256, h_256))
-            out = torch.empty((1, pk4k.w.dim), dtype=torch.float32, device=d4k)
+            pk4k = m4k._packed_for(m4k._pos_for(per, w_256, h_256))
+            out = torch.empty((nreg, pk4k.w.dim), dtype=torch.float32, device=d4k)
             cls256 = torch.empty((nseq, pk256.w.dim), dtype=torch.float32, device=d256) if want_cls256 else None
-            need = N.lib().hipt_hipt4k_workspace_bytes(pk256.ref, pk4k.ref, w_256, h_256, self.chunk)
+            need = N.lib().hipt_hipt4k_workspace_bytes(pk256.ref, pk4k.ref, nreg, w_256, h_256, self.chunk)
             ws = Fn.workspace(d256, need)
-            N.call("hipt_hipt4k_forward", pk256.ref, pk4k.ref, N.ptr(region), W, H, self.chunk, N.ptr(cls256), N.ptr(out),
+            N.call("hipt_hipt4k_forward", pk256.ref, pk4k.ref, N.ptr(region), nreg, W, H, self.chunk, N.ptr(cls256), N.ptr(out),
                    N.ptr(ws), ws.numel(), N.stream_ptr(d256))
             return out, cls256
         # two-device placement (hipt_4k.py:39-46): ViT-256 on device256, grid copied to device4k
         lay = N.ImageLayout(w_256, h_256, 256, 256, H, W * H, 3 * W * H)
         cls256 = self.model256.forward_features(region, layout=lay, nseq=nseq, chunk=self.chunk)
-        tokens = cls256.to(d4k, non_blocking=True).view(1, nseq, -1)
+        tokens = cls256.to(d4k, non_blocking=True).view(nreg, per, -1)
         return self.model4k.forward_tokens(tokens, w_256, h_256), cls256
 
     def forward(self, x):
-        """[1,3,W',H'] -> [1,192] ViT-4K [CLS] feature (hipt_4k.py:48-76)."""
+        """[R,3,W',H'] -> [R,192] ViT-4K [CLS] features (hipt_4k.py:48-76; the reference takes R = 1)."""
         return self._run(x, want_cls256=False)[0]
 
     def forward_asset_dict(self, x: torch.Tensor):
         """hipt_4k.py:79-118: intermediate features as numpy arrays."""
+        if x.shape[0] != 1:
+            raise ValueError("forward_asset_dict describes ONE region ([1,3,W,H]), as in the reference (hipt_4k.py:96-97)")
         out, cls256 = self._run(x, want_cls256=True)
         f256 = cls256.detach().cpu()
         mean256 = f256.mean(dim=0).unsqueeze(dim=0)

@@ -174,13 +174,15 @@ int hipt_vit256_forward(const hipt_vit_weights* w, const float* images, const hi
 int hipt_vit4k_forward(const hipt_vit_weights* w, const float* tokens_in, int nseq, float* out,
                        void* workspace, size_t ws_bytes, void* stream);
 
-/* HIPT_4K.forward (HIPT_4K/hipt_4k.py:48-76) for ONE region already cropped to multiples of 256:
- * region fp32 [1,3,W,H] -> cls256[w_256*h_256, 384] (kept on device, no CPU hop) -> out[1,192].
+/* HIPT_4K.forward (HIPT_4K/hipt_4k.py:48-76) for `nreg` regions already cropped to multiples of 256:
+ * regions fp32 [nreg,3,W,H] -> cls256[nreg*w_256*h_256, 384] (kept on device, no CPU hop) -> out[nreg,192].
+ * The reference processes one region per call (batch_size 1, hipt_4k.py:73); nreg > 1 is the throughput
+ * form: regions are independent, so their patches are simply stacked along the sequence axis.
  * cls256_out may be NULL.  workspace >= hipt_hipt4k_workspace_bytes(). */
 size_t hipt_hipt4k_workspace_bytes(const hipt_vit_weights* w256, const hipt_vit_weights* w4k,
-                                   int w_256, int h_256, int chunk);
+                                   int nreg, int w_256, int h_256, int chunk);
 int hipt_hipt4k_forward(const hipt_vit_weights* w256, const hipt_vit_weights* w4k,
-                        const float* region, int W, int H, int chunk, float* cls256_out, float* out,
+                        const float* regions, int nreg, int W, int H, int chunk, float* cls256_out, float* out,
                         void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------

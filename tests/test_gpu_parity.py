@@ -266,6 +266,21 @@ def test_hipt4k_small_region_fp32(hipt):
     assert md(hipt(xp), g["out"]) < TOL
 
 
+def test_hipt4k_region_batch_equals_single_regions(hipt):
+    """R regions per call (throughput form) give the same features as R single-region calls."""
+    x = synth.hash_uniform_torch((3, 3, 512, 768), 33, device=DEV)
+    for dt, tol in (("fp32", 1e-5), ("bf16", 1e-5)):
+        hipt.set_compute_dtype(dt)
+        try:
+            batched = hipt(x)
+            singles = torch.cat([hipt(x[i:i + 1]) for i in range(3)], dim=0)
+        finally:
+            hipt.set_compute_dtype("fp32")
+        assert batched.shape == (3, 192) and md(batched, singles.cpu().numpy()) < tol, dt
+    with pytest.raises(ValueError):
+        hipt.forward_asset_dict(x)
+
+
 def test_hipt4k_full_region_fp32_and_bf16(hipt):
     """BASELINE config 3 shape: one 4096x4096 region = 256 patches -> ViT-4K over the 16x16 grid."""
     g = golden("hipt4k_4096")
