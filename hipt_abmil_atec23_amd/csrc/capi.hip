@@ -149,6 +149,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             memset(&m, 0, sizeof(m));
             m.x = x; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
             m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.M = M; m.D = D; m.hidden = w->hidden;
+            m.counter = (int*)s.hid;  // (the hidden tensor is never materialised on this path: its slot holds the tile queue)
             PROF(PC_MLP, hipt_mlp_launch(m, st));
             continue;
         } else {

@@ -61,11 +61,16 @@ struct MlpParams {
     const void* w2;      // bf16 [D, hidden]
     const float* b2;
     int M, D, hidden;
-    int full_tiles;      // (set by the launcher)
+    int* counter;        // device int the launcher zeroes on the stream: the kernel's tile queue
+    int full_tiles;      // (set by the launcher) 128-row tiles; tiles beyond are 16-row tail tiles
+    int ntiles;          // (set by the launcher)
+    int stagger;         // (set by the launcher) start offset between workgroup groups, 10 ns ticks (0 = none)
     unsigned long long* stamps;
 };
 bool hipt_mlp_supported(int dtype, int D, int hidden);
-int hipt_mlp_launch(const MlpParams& p, hipStream_t st);
+int hipt_mlp_launch(const MlpParams& p, hipStream_t st);  // dispatches to the pipelined D = 384 kernel when it applies
+bool hipt_mlp_pipe_supported(int dtype, int D, int hidden);
+int hipt_mlp_pipe_launch(const MlpParams& p, hipStream_t st);
 
 int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, const float* b, void* out, int out_dtype,
                           int64_t out_stride, int rows, int D, float eps, hipStream_t st);

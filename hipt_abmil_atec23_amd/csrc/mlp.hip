@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "mlp_common.h"
 
 namespace {
 
@@ -49,67 +50,21 @@ template <int U> __device__ __forceinline__ void wait_units(int units) {  // 4*U
     }
 }
 
-// GELU for the bf16 path.  nn.GELU() is the exact erf form (vision_transformer.py:89); ocml erff costs
-// ~36 VALU instructions, which at one wave per SIMD is as expensive as the MFMAs it sits between.  This
-// is Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below the bf16 rounding of the result):
-//   erfc(|z|) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1 / (1 + p |z|),  z = x / sqrt(2)
-//   Phi(x) = x >= 0 ? 1 - erfc/2 : erfc/2 ;  gelu = x Phi(x)
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float az = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(az * az * -1.4426950408889634f);
-    const float q = 0.5f * poly * t * e;  // erfc(|z|) / 2
-    return x * (x >= 0.f ? 1.0f - q : q);
-}
-
-template <int NCH>
-__device__ __forceinline__ void ln_rows(f32x4 (&v)[NCH][2], const float* gam, const float* bet, int K, float eps, int g,
-                                        u32x4 (&out)[NCH]) {
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s += v[c][0][e] + v[c][1][e];
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s / (float)K;
-    float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float a = v[c][0][e] - mean, b = v[c][1][e] - mean;
-            q += a * a + b * b;
-        }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q / (float)K + eps);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int k0 = (g + 4 * c) * 8;
-        const f32x4 g0 = *(const f32x4*)(gam + k0), g1 = *(const f32x4*)(gam + k0 + 4);
-        const f32x4 b0 = *(const f32x4*)(bet + k0), b1 = *(const f32x4*)(bet + k0 + 4);
-        const f32x4 y0 = (v[c][0] - mean) * rstd * g0 + b0, y1 = (v[c][1] - mean) * rstd * g1 + b1;
-        u32x4 o;
-        o[0] = pack_bf16x2(y0[0], y0[1]);
-        o[1] = pack_bf16x2(y0[2], y0[3]);
-        o[2] = pack_bf16x2(y1[0], y1[1]);
-        o[3] = pack_bf16x2(y1[2], y1[3]);
-        out[c] = o;
-    }
-}
-
 #define MSTAMP(k)                                                                                   \
     do {                                                                                            \
-        if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
-// KS = D / 64 (6: ViT-256, 3: ViT-4K)
-template <int KS>
+// KS = D / 64 (6: ViT-256, 3: ViT-4K).  DBG (tools/mlp_probe.hip only; the library instantiates 0) removes
+// one ingredient at a time to price it: 1 = no weight DMA / waits inside the loop, 2 = GELU replaced by a
+// plain pack, 4 = no LDS fragment reads / MFMAs.
+//
+// Persistent: gridDim.x <= #CUs workgroups pull row tiles from an atomic counter (p.counter, zeroed by the
+// launcher).  The weight stream does not depend on the tile, so the ring runs CONTINUOUSLY across tiles
+// (the first slabs of the next pass are in flight during a tile's epilogue and the next tile's loads).
+// The row loads / stores of a tile are pure HBM time (786 KB per tile, ~5.6 TB/s when all CUs do it at
+// once): workgroup groups start p.stagger ticks apart so that some CUs compute while others move rows.
+template <int KS, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     constexpr int D = KS * 64;
     constexpr int NCH = KS * 2;          // A chunks per lane per row fragment
@@ -121,24 +76,13 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     float* bet = gam + D;
     float* b2s = bet + D;
     float* b1s = b2s + D;  // [hidden]
+    int* tile_s = (int*)(b1s + p.hidden);  // [2] tile handed to this workgroup, double-buffered by parity
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
-    // blocks [0, full_tiles): 128 rows each; then 16-row tail workgroups (only wave 0 / fragment 0 has rows)
-    int row0, nrows;
-    if ((int)blockIdx.x < p.full_tiles) {
-        row0 = blockIdx.x * TMR;
-        nrows = TMR;
-    } else {
-        row0 = p.full_tiles * TMR + (blockIdx.x - p.full_tiles) * 16;
-        nrows = 16;
-    }
-    nrows = (p.M - row0) < nrows ? (p.M - row0) : nrows;
     const int nchunk = p.hidden / 128;
     const int nslab = nchunk * SPC;
-    // fragments this wave really owns (a tail workgroup has one): lets idle waves skip the matrix work
-    const int my_frags = nrows > wave * 32 + 16 ? 2 : (nrows > wave * 32 ? 1 : 0);
 
     // ---- weight slab DMA: per-lane base pointers are fixed; a slab only adds wave-uniform offsets ----
     // U consecutive slabs form one ring unit (one barrier + one counted wait per unit): U = 2 when the
@@ -154,6 +98,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     const bf16_t* w1b = W1 + (int64_t)r0 * D + ch0 * 8;
     const bf16_t* w2b = W2 + (int64_t)r0 * p.hidden + ch0 * 8;
     const int nunit = nslab / U;
+    // continuous stream: unit u of the NEXT pass goes to the ring slot after unit nunit-1 of this one,
+    // which is slot u again only if a pass is a whole number of ring turns
+    const bool cont = (nunit % NUS) == 0;
     auto issue_unit = [&](int u) {
 #pragma unroll
         for (int h = 0; h < U; ++h) {
@@ -179,9 +126,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             }
         }
     };
-    MSTAMP(0);
     const int pre = nunit < NUS - 1 ? nunit : NUS - 1;
-    for (int u = 0; u < pre; ++u) issue_unit(u);
 
     for (int i = tid; i < D; i += 256) {
         gam[i] = p.ln_w[i];
@@ -189,37 +134,15 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         b2s[i] = p.b2[i];
     }
     for (int i = tid; i < p.hidden; i += 256) b1s[i] = p.b1[i];
-    __syncthreads();  // (drains the weight prefetch once)
-    MSTAMP(1);
-
-    // ---- activations: v = x + y1 -> LN2 -> operand fragments ----
-    u32x4 af[2][NCH];
-#pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
-        int r = (wave * 2 + mf) * 16 + li;
-        r = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
-        const float* xr = p.x + (int64_t)(row0 + r) * D;
-        f32x4 v[NCH][2];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            v[c][0] = *(const f32x4*)(xr + (g + 4 * c) * 8);
-            v[c][1] = *(const f32x4*)(xr + (g + 4 * c) * 8 + 4);
-        }
-        if (p.y1) {
-            const bf16_t* yr = (const bf16_t*)p.y1 + (int64_t)(row0 + r) * D;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const bf16x8 y = __builtin_bit_cast(bf16x8, *(const u32x4*)(yr + (g + 4 * c) * 8));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[c][0][e] += (float)y[e];
-                    v[c][1][e] += (float)y[4 + e];
-                }
-            }
-        }
-        ln_rows<NCH>(v, gam, bet, D, p.ln_eps, g, af[mf]);
+    if (tid == 0) tile_s[0] = atomicAdd(p.counter, 1);
+    __syncthreads();
+    int tile = __builtin_amdgcn_readfirstlane(tile_s[0]);
+    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+    if (p.stagger > 0) {  // start groups apart: (block / 8) & 3 mixes the groups inside every XCD
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)(((blockIdx.x >> 3) & 3) * p.stagger);
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
     }
-    MSTAMP(2);
 
     int foff[2];
 #pragma unroll
@@ -236,11 +159,60 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         }
     const uint32_t lbase = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
 
-    f32x4 acc2[2][NF2];
+    for (int seq = 0; tile < p.ntiles; ++seq) {
+        // tiles [0, full_tiles): 128 rows each; then 16-row tail tiles (only wave 0 / fragment 0 has rows)
+        int row0, nrows;
+        if (tile < p.full_tiles) {
+            row0 = tile * TMR;
+            nrows = TMR;
+        } else {
+            row0 = p.full_tiles * TMR + (tile - p.full_tiles) * 16;
+            nrows = 16;
+        }
+        nrows = (p.M - row0) < nrows ? (p.M - row0) : nrows;
+        // fragments this wave really owns (a tail tile has one): lets idle waves skip the matrix work
+        const int my_frags = nrows > wave * 32 + 16 ? 2 : (nrows > wave * 32 ? 1 : 0);
+        MSTAMP(0);
+        if (seq == 0 || !cont)
+            for (int u = 0; u < pre; ++u) issue_unit(u);
+        if (tid == 0) tile_s[(seq + 1) & 1] = atomicAdd(p.counter, 1);  // read after this tile's barriers
+        MSTAMP(1);
+
+        // ---- activations: v = x + y1 -> LN2 -> operand fragments ----
+        u32x4 af[2][NCH];
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
+        for (int mf = 0; mf < 2; ++mf) {
+            int r = (wave * 2 + mf) * 16 + li;
+            r = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
+            const float* xr = p.x + (int64_t)(row0 + r) * D;
+            f32x4 v[NCH][2];
 #pragma unroll
-        for (int nf = 0; nf < NF2; ++nf) acc2[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < NCH; ++c) {
+                v[c][0] = *(const f32x4*)(xr + (g + 4 * c) * 8);
+                v[c][1] = *(const f32x4*)(xr + (g + 4 * c) * 8 + 4);
+            }
+            if (p.y1) {
+                const bf16_t* yr = (const bf16_t*)p.y1 + (int64_t)(row0 + r) * D;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const bf16x8 y = __builtin_bit_cast(bf16x8, *(const u32x4*)(yr + (g + 4 * c) * 8));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[c][0][e] += (float)y[e];
+                        v[c][1][e] += (float)y[4 + e];
+                    }
+                }
+            }
+            ln_rows<NCH>(v, gam, bet, D, p.ln_eps, g, af[mf]);
+        }
+        MSTAMP(2);
+        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
+
+        f32x4 acc2[2][NF2];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF2; ++nf) acc2[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #define DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 #define LGKM(n)                                             \
@@ -248,33 +220,34 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     __builtin_amdgcn_sched_barrier(0)
 // before slab j of chunk c: if it opens a ring unit, wait until that unit has landed (at most the NUS-2
 // later units in flight; 4*U DMA instructions per unit per wave), barrier, refill the slot freed by the
-// previous unit
+// previous unit (with the matching unit of the next pass once this pass is fully issued)
 #define SLAB_SYNC(c, j)                                                                          \
-    if ((j) % U == 0) {                                                                          \
+    if ((DBG & 1) == 0 && (j) % U == 0) {                                                        \
         const int u = ((c) * SPC + (j)) / U;                                                     \
-        const int later = (u + NUS - 2 < nunit ? u + NUS - 2 : nunit - 1) - u;                   \
+        const int later = cont ? NUS - 2 : (u + NUS - 2 < nunit ? u + NUS - 2 : nunit - 1) - u;  \
         wait_units<U>(later);                                                                    \
         __builtin_amdgcn_s_barrier();                                                            \
         if (u + NUS - 1 < nunit) issue_unit(u + NUS - 1);                                        \
+        else if (cont) issue_unit(u + NUS - 1 - nunit);                                          \
     }
 #define SLAB_ADDR(c, j) ((((((c) * SPC + (j)) / U) % NUS) * U + (j) % U) * SLAB_BYTES)
 
-    for (int c = 0; c < nchunk; ++c) {
-        // ================= fc1 chunk: acc1[128 rows, 128 hidden] =================
-        if (c == 1) MSTAMP(5);
-        f32x4 acc1[2][8];
+        for (int c = 0; c < nchunk; ++c) {
+            // ================= fc1 chunk: acc1[128 rows, 128 hidden] =================
+            if (c == 1) MSTAMP(5);
+            f32x4 acc1[2][8];
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
+            for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-            for (int nf = 0; nf < 8; ++nf) acc1[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int nf = 0; nf < 8; ++nf) acc1[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < KS; ++kt) {
-            SLAB_SYNC(c, kt);
-            if (my_frags > 0) {
-                const uint32_t a0 = lbase + SLAB_ADDR(c, kt) + foff[0];
-                const uint32_t a1 = lbase + SLAB_ADDR(c, kt) + foff[1];
-                // 4 groups per slab: 4 W fragments (ks, 4 column fragments) -> 8 MFMAs; two register sets
-                u32x4 wa[4], wb[4];
+            for (int kt = 0; kt < KS; ++kt) {
+                SLAB_SYNC(c, kt);
+                if ((DBG & 4) == 0 && my_frags > 0) {
+                    const uint32_t a0 = lbase + SLAB_ADDR(c, kt) + foff[0];
+                    const uint32_t a1 = lbase + SLAB_ADDR(c, kt) + foff[1];
+                    // 4 groups per slab: 4 W fragments (ks, 4 column fragments) -> 8 MFMAs; two register sets
+                    u32x4 wa[4], wb[4];
 #define RD4(w, addr, base)                 \
     DSR128(w[0], addr, base + 0);          \
     DSR128(w[1], addr, base + 2048);       \
@@ -286,52 +259,52 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         Tr<bf16_t>::mma16(acc1[1][(q0) + j], w[j], af[1][kt * 2 + (ks)]);                  \
     }                                                                                      \
     __builtin_amdgcn_sched_barrier(0)
-                RD4(wa, a0, 0);
-                RD4(wb, a0, 8192);
-                LGKM(4); MM1(wa, 0, 0);
-                RD4(wa, a1, 0);
-                LGKM(4); MM1(wb, 0, 4);
-                RD4(wb, a1, 8192);
-                LGKM(4); MM1(wa, 1, 0);
-                LGKM(0); MM1(wb, 1, 4);
+                    RD4(wa, a0, 0);
+                    RD4(wb, a0, 8192);
+                    LGKM(4); MM1(wa, 0, 0);
+                    RD4(wa, a1, 0);
+                    LGKM(4); MM1(wb, 0, 4);
+                    RD4(wb, a1, 8192);
+                    LGKM(4); MM1(wa, 1, 0);
+                    LGKM(0); MM1(wb, 1, 4);
 #undef RD4
 #undef MM1
-            }
-        }
-        if (c == 1) MSTAMP(6);
-        // ================= bias + GELU, re-pack as fc2 operand fragments =================
-        // acc1[mf][nf][e] = h[row li][hidden 128c + 16nf + 4g + e]; fragment f takes nf = 2f (slots 0-3) and 2f+1 (4-7)
-        u32x4 hf[2][4];
-#pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                float t[8];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x4 b = *(const f32x4*)(b1s + c * 128 + (2 * f + h) * 16 + 4 * g);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[4 * h + e] = gelu_fast(acc1[mf][2 * f + h][e] + b[e]);
                 }
-                u32x4 o;
-                o[0] = pack_bf16x2(t[0], t[1]);
-                o[1] = pack_bf16x2(t[2], t[3]);
-                o[2] = pack_bf16x2(t[4], t[5]);
-                o[3] = pack_bf16x2(t[6], t[7]);
-                hf[mf][f] = o;
             }
-        if (c == 1) MSTAMP(7);
-        // ================= fc2 chunk: acc2 += h_c @ W2[:, chunk]^T =================
+            if (c == 1) MSTAMP(6);
+            // ================= bias + GELU, re-pack as fc2 operand fragments =================
+            // acc1[mf][nf][e] = h[row li][hidden 128c + 16nf + 4g + e]; fragment f takes nf = 2f (slots 0-3) and 2f+1 (4-7)
+            u32x4 hf[2][4];
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
+            for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-            for (int ng = 0; ng < NG; ++ng) {
-                SLAB_SYNC(c, KS + kh * NG + ng);
-                if (my_frags > 0) {
-                    // 4 groups per slab: (fl, 4 output-column fragments) -> 8 x ds_read_b64, 8 MFMAs; two register sets
-                    const uint32_t sb = lbase + SLAB_ADDR(c, KS + kh * NG + ng);
-                    const uint32_t b00 = sb + f2off[0][0], b01 = sb + f2off[0][1], b10 = sb + f2off[1][0], b11 = sb + f2off[1][1];
-                    u32x2 la[4], ha[4], lb[4], hb[4];
+                for (int f = 0; f < 4; ++f) {
+                    u32x4 o;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 u4 = acc1[mf][2 * f + h] + *(const f32x4*)(b1s + c * 128 + (2 * f + h) * 16 + 4 * g);
+                        f32x2 lo = {u4[0], u4[1]}, hi = {u4[2], u4[3]};
+                        if ((DBG & 2) == 0) {
+                            lo = gelu2(lo);
+                            hi = gelu2(hi);
+                        }
+                        o[2 * h] = pack_bf16x2(lo[0], lo[1]);
+                        o[2 * h + 1] = pack_bf16x2(hi[0], hi[1]);
+                    }
+                    hf[mf][f] = o;
+                }
+            if (c == 1) MSTAMP(7);
+            // ================= fc2 chunk: acc2 += h_c @ W2[:, chunk]^T =================
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int ng = 0; ng < NG; ++ng) {
+                    SLAB_SYNC(c, KS + kh * NG + ng);
+                    if ((DBG & 4) == 0 && my_frags > 0) {
+                        // 4 groups per slab: (fl, 4 output-column fragments) -> 8 x ds_read_b64, 8 MFMAs; two register sets
+                        const uint32_t sb = lbase + SLAB_ADDR(c, KS + kh * NG + ng);
+                        const uint32_t b00 = sb + f2off[0][0], b01 = sb + f2off[0][1], b10 = sb + f2off[1][0], b11 = sb + f2off[1][1];
+                        u32x2 la[4], ha[4], lb[4], hb[4];
 #define DSR64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 #define RD8(l, h, alo, ahi, base)                                       \
     DSR64(l[0], alo, base + 0);    DSR64(h[0], ahi, base + 0);          \
@@ -348,100 +321,144 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         }                                                                                     \
     }                                                                                         \
     __builtin_amdgcn_sched_barrier(0)
-                    RD8(la, ha, b00, b01, 0);
-                    RD8(lb, hb, b00, b01, 8192);
-                    LGKM(8); MM2(la, ha, 0, 0);
-                    RD8(la, ha, b10, b11, 0);
-                    LGKM(8); MM2(lb, hb, 0, 4);
-                    RD8(lb, hb, b10, b11, 8192);
-                    LGKM(8); MM2(la, ha, 1, 0);
-                    LGKM(0); MM2(lb, hb, 1, 4);
+                        // (an asm read whose result is never used must not be issued: its destination would be
+                        //  re-used while the data is still landing -- D = 192 has no fragments 12..15)
+                        if (ng * 8 + 4 < NF2) {
+                            RD8(la, ha, b00, b01, 0);
+                            RD8(lb, hb, b00, b01, 8192);
+                            LGKM(8); MM2(la, ha, 0, 0);
+                            RD8(la, ha, b10, b11, 0);
+                            LGKM(8); MM2(lb, hb, 0, 4);
+                            RD8(lb, hb, b10, b11, 8192);
+                            LGKM(8); MM2(la, ha, 1, 0);
+                            LGKM(0); MM2(lb, hb, 1, 4);
+                        } else {
+                            RD8(la, ha, b00, b01, 0);
+                            RD8(lb, hb, b10, b11, 0);
+                            LGKM(8); MM2(la, ha, 0, 0);
+                            LGKM(0); MM2(lb, hb, 1, 0);
+                        }
 #undef DSR64
 #undef RD8
 #undef MM2
+                    }
                 }
-            }
-    }
-    MSTAMP(3);
+        }
+        MSTAMP(3);
+        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
 #undef DSR128
 #undef LGKM
 #undef SLAB_SYNC
 #undef SLAB_ADDR
 
-    // ---- epilogue: x <- x + y1 + acc2 + b2 (this workgroup owns its rows: in place, no other reader) ----
+        // ---- epilogue: x <- x + y1 + acc2 + b2 (this workgroup owns its rows: in place, no other reader).
+        //      All of a fragment's row loads are issued before the first use (the operand registers are free now).
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
-        const int r = (wave * 2 + mf) * 16 + li;
-        if (r < nrows) {
-            float* xr = p.x + (int64_t)(row0 + r) * D;
-            const bf16_t* yr = p.y1 ? (const bf16_t*)p.y1 + (int64_t)(row0 + r) * D : nullptr;
+        for (int mf = 0; mf < 2; ++mf) {
+            const int r = (wave * 2 + mf) * 16 + li;
+            if (r < nrows) {
+                float* xr = p.x + (int64_t)(row0 + r) * D;
+                const bf16_t* yr = p.y1 ? (const bf16_t*)p.y1 + (int64_t)(row0 + r) * D : nullptr;
+                f32x4 xv[NF2];
+                u32x2 yv[NF2];
 #pragma unroll
-            for (int nf = 0; nf < NF2; ++nf) {
-                const int n = nf * 16 + 4 * g;
-                f32x4 v = acc2[mf][nf] + *(const f32x4*)(b2s + n) + *(const f32x4*)(xr + n);
+                for (int nf = 0; nf < NF2; ++nf) xv[nf] = *(const f32x4*)(xr + nf * 16 + 4 * g);
                 if (yr) {
-                    const bf16x4 y = __builtin_bit_cast(bf16x4, *(const u32x2*)(yr + n));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)y[e];
+                    for (int nf = 0; nf < NF2; ++nf) yv[nf] = *(const u32x2*)(yr + nf * 16 + 4 * g);
                 }
-                *(f32x4*)(xr + n) = v;
+#pragma unroll
+                for (int nf = 0; nf < NF2; ++nf) {
+                    const int n = nf * 16 + 4 * g;
+                    f32x4 v = acc2[mf][nf] + *(const f32x4*)(b2s + n) + xv[nf];
+                    if (yr) {
+                        const bf16x4 y = __builtin_bit_cast(bf16x4, yv[nf]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)y[e];
+                    }
+                    *(f32x4*)(xr + n) = v;
+                }
             }
         }
+        MSTAMP(4);
+        if (!cont) __syncthreads();  // the ring is re-primed from unit 0: every wave must be done reading it
+        if (DBG & 1) __syncthreads();  // (no ring barriers in this debug build)
+        tile = __builtin_amdgcn_readfirstlane(tile_s[(seq + 1) & 1]);
     }
-    MSTAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (continuous stream: units of a pass that never runs)
+    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int KS>
+template <int KS, int DBG = 0>
 int launch(const MlpParams& p_in, hipStream_t st) {
     MlpParams p = p_in;
     constexpr int D = KS * 64;
-    const int lds = NSLOT * SLAB_BYTES + (3 * D + p.hidden) * 4;
-    auto k = mlp_kernel<KS>;
+    const int lds = NSLOT * SLAB_BYTES + (3 * D + p.hidden) * 4 + 16;
+    auto k = mlp_kernel<KS, DBG>;
     static bool attr = false;
+    static int ncu = 0;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(mlp) failed");
             return HIPT_E_LAUNCH;
         }
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            hipt_set_error("mlp: cannot query the device");
+            return HIPT_E_LAUNCH;
+        }
+        ncu = prop.multiProcessorCount;
         attr = true;
     }
-    // whole rounds of 256 workgroups take 128 rows each; a last partial round that would be less than a
-    // quarter full is cut into 16-row workgroups instead
+    // whole rounds of #CU workgroups take 128 rows each; a last partial round that would be less than an
+    // eighth full is cut into 16-row tiles (one active wave each: such a tile costs about half a full one)
     const int tiles = (p.M + TMR - 1) / TMR;
-    const int rem = tiles % 256;
-    int tail_tiles = (tiles > 256 && rem > 0 && rem <= 32) ? rem : 0;
+    const int rem = tiles % ncu;
+    const int tail_tiles = (tiles > ncu && rem > 0 && rem <= ncu / 8) ? rem : 0;
     p.full_tiles = tiles - tail_tiles;
     const int tail_rows = p.M - p.full_tiles * TMR;
-    const int grid = p.full_tiles + (tail_rows > 0 ? (tail_rows + 15) / 16 : 0);
+    p.ntiles = p.full_tiles + (tail_rows > 0 ? (tail_rows + 15) / 16 : 0);
+    const int grid = p.ntiles < ncu ? p.ntiles : ncu;
+    // long launches (>= 6 tiles per workgroup) start their 4 workgroup groups a quarter of a tile time apart
+    static const char* stag_env = getenv("HIPT_MLP_STAGGER_US");
+    const int stag_us = stag_env ? atoi(stag_env) : 20;
+    p.stagger = (p.full_tiles >= 6 * ncu) ? stag_us * 100 : 0;
+    if (hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
+        hipt_set_error("mlp: hipMemsetAsync(counter) failed");
+        return HIPT_E_LAUNCH;
+    }
 
     static const bool want_stamps = getenv("HIPT_SEQGEMM_STAMPS") != nullptr;
     static unsigned long long* dbuf = nullptr;
     if (want_stamps) {
-        if (!dbuf) (void)hipMalloc(&dbuf, 4096 * 8 * sizeof(unsigned long long));
+        if (!dbuf) (void)hipMalloc(&dbuf, 4096 * 16 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbuf, 0, 4096 * 16 * sizeof(unsigned long long), st);
         p.stamps = dbuf;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
     HIPT_CHECK_LAUNCH();
     if (want_stamps && grid <= 4096) {
-        static unsigned long long h[4096 * 8];
+        static unsigned long long h[4096 * 16];
         (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(h, dbuf, (size_t)grid * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h, dbuf, (size_t)grid * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         unsigned long long t0 = ~0ull, t4 = 0;
         for (int b = 0; b < grid; ++b) {
-            if (h[b * 8] < t0) t0 = h[b * 8];
-            if (h[b * 8 + 4] > t4) t4 = h[b * 8 + 4];
+            if (h[b * 16 + 11] < t0) t0 = h[b * 16 + 11];
+            if (h[b * 16 + 10] > t4) t4 = h[b * 16 + 10];
         }
         double ph[4] = {0, 0, 0, 0};
         const int nb = grid < 256 ? grid : 256;
         for (int b = 0; b < nb; ++b)
-            for (int k2 = 0; k2 < 4; ++k2) ph[k2] += (double)(h[b * 8 + k2 + 1] - h[b * 8 + k2]) * 0.01 / nb;
-        double c1 = 0, c2 = 0;
+            for (int k2 = 0; k2 < 4; ++k2) ph[k2] += (double)(h[b * 16 + k2 + 1] - h[b * 16 + k2]) * 0.01 / nb;
+        double c1 = 0, c2 = 0, ghz = 0;
         for (int b = 0; b < nb; ++b) {
-            c1 += (double)(h[b * 8 + 6] - h[b * 8 + 5]) * 0.01 / nb;
-            c2 += (double)(h[b * 8 + 7] - h[b * 8 + 6]) * 0.01 / nb;
+            c1 += (double)(h[b * 16 + 6] - h[b * 16 + 5]) * 0.01 / nb;
+            c2 += (double)(h[b * 16 + 7] - h[b * 16 + 6]) * 0.01 / nb;
+            ghz += (double)(h[b * 16 + 9] - h[b * 16 + 8]) / (double)(h[b * 16 + 3] - h[b * 16 + 2]) * 0.1 / nb;
         }
-        fprintf(stderr, "[mlp KS=%d hidden=%d grid=%d full=%d] total %.1f us | first-256 WGs: stage %.1f, Aload+LN %.1f, chunks %.1f (chunk1: fc1 %.2f, gelu %.2f), epilogue %.1f\n", KS,
-                p.hidden, grid, p.full_tiles, (double)(t4 - t0) * 0.01, ph[0], ph[1], ph[2], c1, c2, ph[3]);
+        fprintf(stderr, "[mlp KS=%d dbg=%d hidden=%d grid=%d full=%d stagger=%d] total %.1f us | first tiles: stage %.1f, Aload+LN %.1f, chunks %.1f (chunk1: fc1 %.2f, gelu %.2f; %.2f GHz), epilogue %.1f\n", KS,
+                DBG, p.hidden, grid, p.full_tiles, p.stagger, (double)(t4 - t0) * 0.01, ph[0], ph[1], ph[2], c1, c2, ghz, ph[3]);
     }
     return HIPT_OK;
 }
@@ -453,10 +470,12 @@ bool hipt_mlp_supported(int dtype, int D, int hidden) {
 }
 
 int hipt_mlp_launch(const MlpParams& p, hipStream_t st) {
-    HIPT_CHECK_ARG(p.M > 0 && p.x && p.w1 && p.w2 && p.b1 && p.b2 && p.ln_w && p.ln_b, "mlp: null/empty argument");
+    HIPT_CHECK_ARG(p.M > 0 && p.x && p.w1 && p.w2 && p.b1 && p.b2 && p.ln_w && p.ln_b && p.counter, "mlp: null/empty argument");
     HIPT_CHECK_ARG(((uintptr_t)p.x % 16) == 0 && ((uintptr_t)p.w1 % 16) == 0 && ((uintptr_t)p.w2 % 16) == 0 &&
                        ((uintptr_t)p.y1 % 16) == 0,
                    "mlp: 16-byte alignment required");
+    static const bool no_pipe = getenv("HIPT_NO_MLP_PIPE") != nullptr;
+    if (!no_pipe && hipt_mlp_pipe_supported(HIPT_BF16, p.D, p.hidden)) return hipt_mlp_pipe_launch(p, st);
     if (p.D == 384) return launch<6>(p, st);
     if (p.D == 192) return launch<3>(p, st);
     hipt_set_error("mlp: D=%d not in {192, 384}", p.D);

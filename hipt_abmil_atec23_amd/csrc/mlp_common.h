@@ -1,0 +1,65 @@
+// Device helpers shared by the fused-MLP kernels (mlp.hip: generic persistent kernel; mlp_pipe.hip: the
+// software-pipelined D = 384 kernel).
+#pragma once
+#include "common.h"
+
+// GELU for the bf16 path.  nn.GELU() is the exact erf form x * Phi(x) (vision_transformer.py:89).  ocml erff
+// costs ~36 VALU instructions per element, which at one wave per SIMD is as expensive as the MFMAs around
+// it.  Here Phi(x) = 1 / (1 + exp2(x * q(x^2))) with q a degree-4 polynomial fitted (minimax on the GELU
+// error, tools/fit_gelu.py) to -log2(e) * logit(Phi(x)) / x: |gelu error| <= 3.5e-6 for every finite fp32 x
+// (the bf16 rounding of the result is 4e-3 relative), tails exact (q's leading term keeps the sign), and
+// the arithmetic is all packed-fp32 (two elements per VALU instruction) plus one v_exp_f32 and one v_rcp_f32.
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+    const f32x2 t = x * x;
+    f32x2 q = t * -3.228983431e-06f + 8.823808482e-05f;
+    q = q * t + 3.602743489e-04f;
+    q = q * t + -1.052266864e-01f;
+    q = q * t + -2.302045392e+00f;
+    const f32x2 pw = x * q;
+    f32x2 d;
+    d[0] = __builtin_amdgcn_exp2f(pw[0]);
+    d[1] = __builtin_amdgcn_exp2f(pw[1]);
+    d = d + 1.0f;
+    f32x2 r;
+    r[0] = __builtin_amdgcn_rcpf(d[0]);
+    r[1] = __builtin_amdgcn_rcpf(d[1]);
+    return x * r;
+}
+
+template <int NCH>
+__device__ __forceinline__ void ln_rows(f32x4 (&v)[NCH][2], const float* gam, const float* bet, int K, float eps, int g,
+                                        u32x4 (&out)[NCH]) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += v[c][0][e] + v[c][1][e];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s / (float)K;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = v[c][0][e] - mean, b = v[c][1][e] - mean;
+            q += a * a + b * b;
+        }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)K + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k0 = (g + 4 * c) * 8;
+        const f32x4 g0 = *(const f32x4*)(gam + k0), g1 = *(const f32x4*)(gam + k0 + 4);
+        const f32x4 b0 = *(const f32x4*)(bet + k0), b1 = *(const f32x4*)(bet + k0 + 4);
+        const f32x4 y0 = (v[c][0] - mean) * rstd * g0 + b0, y1 = (v[c][1] - mean) * rstd * g1 + b1;
+        u32x4 o;
+        o[0] = pack_bf16x2(y0[0], y0[1]);
+        o[1] = pack_bf16x2(y0[2], y0[3]);
+        o[2] = pack_bf16x2(y1[0], y1[1]);
+        o[3] = pack_bf16x2(y1[2], y1[3]);
+        out[c] = o;
+    }
+}
+

@@ -1,0 +1,544 @@
+// FUSED MLP SUB-BLOCK for D = 384 (ViT-256), software-pipelined:   x <- x + y1 + fc2( GELU( fc1( LN2(x + y1) ) ) )
+//   (Block.forward second half, HIPT_4K/vision_transformer.py:151 with Mlp.forward :98-104.)
+//
+// Same data flow as mlp.hip (one 4-wave workgroup owns 128 rows; LN2(x+y1) as MFMA operand fragments, the fc1
+// chunk accumulator, GELU re-packed in registers as the fc2 operand, the [128, 384] fc2 accumulator: all in
+// registers at one wave per SIMD; only weights stream through LDS) but the per-chunk work is re-ordered so
+// that the matrix pipe never waits for the vector pipe:
+//   * a hidden chunk of 128 is cut in two halves.  Per chunk c the MFMA phases run in the order
+//         A0(c)   fc1, hidden half 0          (96 MFMAs per wave, 3 weight slabs of 64 hidden x 128 k)
+//         B1(c-1) fc2 of the PREVIOUS chunk's half 1
+//         A1(c)   fc1, hidden half 1
+//         B0(c)   fc2, half 0                 (3 slabs of 128 outputs x 64 hidden)
+//     so GELU of half 0 (needed by B0(c)) has the two phases B1(c-1), A1(c) to hide in, and GELU of half 1
+//     (needed by B1(c)) has B0(c), A0(c+1): one 2-element packed GELU (~70 VALU cycles) per 8-MFMA group,
+//     inside the 8 of every 16 cycles in which an MFMA leaves the vector issue port free.
+//   * one ring unit = one phase = 3 slabs (48 KiB); 3 units in LDS (being read / landed / landing).  One
+//     barrier per phase; the LDS fragment reads run one 8-MFMA group ahead, across phase boundaries.
+//   * the fc1 weight rows are laid into LDS in a permuted hidden order (the DMA picks the global row per LDS
+//     row) chosen so that the 8 fc2 K slots a lane owns after GELU are 8 CONSECUTIVE hidden units: the fc2
+//     weight fragment is then one plain 16-byte LDS read, exactly like the fc1 fragment.
+//   * the fc1 bias enters as the C operand of a half's first MFMA (no add, no accumulator init).
+//   * persistent workgroups pull tiles from an atomic counter; the weight stream is tile-independent and
+//     runs continuously across tiles.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+#include "mlp_common.h"
+
+namespace {
+
+constexpr int D = 384, NCH = 12, NF2 = 24, TMR = 128;
+constexpr int SLAB = 16384, UNIT = 3 * SLAB;
+
+template <int I, int N, class F> __device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+
+#define DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define DSR64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+// four / eight LDS reads AND their wait in ONE statement: the outputs are valid when the statement ends, so the
+// compiler may do what it likes with them (the split form -- reads, then a counted wait -- is only safe where
+// nothing makes hipcc copy or re-use the destinations in between: tools/audit_asm_reads.py checks the .s)
+#define DSR128X4_WAIT(d0, d1, d2, d3, addr, o0, o1, o2, o3)                                                      \
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t" \
+                 "ds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"                                           \
+                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)                                                     \
+                 : "v"(addr), "n"(o0), "n"(o1), "n"(o2), "n"(o3))
+#define LGKM(n)                                                 \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); \
+    __builtin_amdgcn_sched_barrier(0)
+#define PSTAMP(k)                                                                                                    \
+    do {                                                                                                             \
+        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+
+// LayerNorm of the 16-row fragment a lane quartet holds (lanes sharing lane&15 own one row), result packed as MFMA
+// operand chunks.  gamma / beta come from LDS through asm reads with immediate offsets off ONE address register:
+// written as C++ loads, hipcc hoists the 48 per-chunk addresses out of the tile loop and spills every one of them.
+// gaddr = LDS byte address of gamma + 32 g;  beta sits D floats behind gamma.
+__device__ __forceinline__ void ln_rows_lds(f32x4 (&v)[NCH][2], uint32_t gaddr, float eps, u32x4 (&out)[NCH]) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += v[c][0][e] + v[c][1][e];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = v[c][0][e] - mean, b = v[c][1][e] - mean;
+            q += a * a + b * b;
+        }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / D) + eps);
+    sfor<0, NCH>([&](auto C_) __attribute__((always_inline)) {
+        constexpr int c = decltype(C_)::value;
+        f32x4 g0, g1, b0, b1;
+        const uint32_t ga = gaddr;
+        DSR128X4_WAIT(g0, g1, b0, b1, ga, c * 128, c * 128 + 16, c * 128 + D * 4, c * 128 + D * 4 + 16);
+        const f32x4 y0 = (v[c][0] - mean) * rstd * g0 + b0, y1 = (v[c][1] - mean) * rstd * g1 + b1;
+        u32x4 o;
+        o[0] = pack_bf16x2(y0[0], y0[1]);
+        o[1] = pack_bf16x2(y0[2], y0[3]);
+        o[2] = pack_bf16x2(y1[0], y1[1]);
+        o[3] = pack_bf16x2(y1[2], y1[3]);
+        out[c] = o;
+    });
+}
+
+enum { KA = 0, KB = 1 };            // phase kind: fc1 half / fc2 half
+
+// DBG (tools/mlp_probe.hip only): 1 = no weight DMA / ring syncs, 2 = GELU replaced by a plain pack,
+// 4 = no LDS fragment reads / MFMAs.
+template <int DBG = 0>
+__global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* gam = (float*)(smem + 3 * UNIT);
+    float* bet = gam + D;
+    float* b2s = bet + D;
+    float* b1s = b2s + D;                  // [hidden]
+    int* tile_s = (int*)(b1s + p.hidden);  // [2] tile handed to this workgroup, double-buffered by parity
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int nchunk = p.hidden / 128;
+    const int upt = 4 * nchunk;  // ring units (phases) per tile pass
+
+    // ---- weight DMA: LDS row R of a slab is filled by (wave, piece q) with R = wave*8 + (lane>>3) + 32q; the
+    //      16-byte chunk a lane fetches is its LDS chunk position XOR ((R>>1)&7) (same for every q) ----
+    const bf16_t* W1 = (const bf16_t*)p.w1;
+    const bf16_t* W2 = (const bf16_t*)p.w2;
+    const int r0 = wave * 8 + (lane >> 3);
+    const int ch0 = (lane & 7) ^ ((r0 >> 1) & 7);
+    // A slab: 64 hidden x 128 k, LDS row R = 64*khalf + rho.  MFMA row rho = 16nf + 4g' + e of the half holds hidden
+    // unit U(rho) = 32(nf>>1) + 8g' + 4(nf&1) + e: lane g' then owns, over the fragment pair (2f, 2f+1), hidden
+    // 32f + 8g' + (0..7).  U(rho + 32) = U(rho) + 32, so piece q still only adds a uniform offset.
+    const int urow = 32 * (r0 >> 5) + 8 * ((r0 >> 2) & 3) + 4 * ((r0 >> 4) & 1) + (r0 & 3);
+    const uint32_t l1off = (uint32_t)(urow * D + ch0 * 8) * 2;  // per-lane BYTE offsets; everything else is wave-uniform
+    const uint32_t l2off = (uint32_t)(r0 * p.hidden + ch0 * 8) * 2;  // B slab: 128 outputs x 64 hidden -> R = output
+    // issue side of the ring: the unit whose 12 pieces per wave are being issued
+    const char* ibase = (const char*)W1;  // uniform: matrix base + unit offset (bytes)
+    uint32_t ilane = l1off;
+    int64_t ijoff = 0, iq1 = 0, iq2 = 0;   // bytes
+    int islot = 0, ipos = 0;
+    // position i of a tile pass -> which weights: A0(0) A1(0) B0(0) | A0(c) B1(c-1) A1(c) B0(c) ... | B1(n-1)
+    auto set_issue = [&](int pos, int slot) {
+        bool is_a;
+        int c, h;
+        if (pos < 3) {
+            c = 0;
+            is_a = pos < 2;
+            h = pos == 1 ? 1 : 0;
+        } else if (pos == upt - 1) {
+            c = nchunk - 1;
+            is_a = false;
+            h = 1;
+        } else {
+            const int m = pos - 3, r = m & 3;
+            c = 1 + (m >> 2);
+            is_a = (r & 1) == 0;
+            h = r == 2 ? 1 : (r == 1 ? 1 : 0);
+            if (r == 1) c -= 1;
+        }
+        if (is_a) {  // hidden rows [128c + 64h, +64) x all k; slab j covers k [128j, +128)
+            ibase = (const char*)(W1 + (int64_t)(c * 128 + 64 * h) * D);
+            ilane = l1off;
+            ijoff = 128 * 2;
+            iq1 = 32 * D * 2;
+            iq2 = 64 * 2;
+        } else {  // output rows [128j, +128) x hidden [128c + 64h, +64)
+            ibase = (const char*)(W2 + c * 128 + 64 * h);
+            ilane = l2off;
+            ijoff = (int64_t)128 * p.hidden * 2;
+            iq1 = (int64_t)32 * p.hidden * 2;
+            iq2 = (int64_t)64 * p.hidden * 2;
+        }
+        islot = slot;
+    };
+    auto dma_piece = [&](auto T_) __attribute__((always_inline)) {
+        constexpr int t = decltype(T_)::value, j = t >> 2, q = t & 3;
+        if constexpr ((DBG & 1) == 0)
+            glds16(ibase + (j * ijoff + (q & 1) * iq1 + (q >> 1) * iq2) + ilane, smem + islot * UNIT + j * SLAB + (q * 4 + wave) * 1024);
+    };
+
+    for (int i = tid; i < D; i += 256) {
+        gam[i] = p.ln_w[i];
+        bet[i] = p.ln_b[i];
+        b2s[i] = p.b2[i];
+    }
+    for (int i = tid; i < p.hidden; i += 256) {  // same permutation inside every 64-half: b1s[base + rho] = b1[base + U(rho)]
+        const int rho = i & 63;
+        b1s[i] = p.b1[(i & ~63) + 32 * (rho >> 5) + 8 * ((rho >> 2) & 3) + 4 * ((rho >> 4) & 1) + (rho & 3)];
+    }
+    if (tid == 0) tile_s[0] = atomicAdd(p.counter, 1);
+    __syncthreads();
+    int tile = __builtin_amdgcn_readfirstlane(tile_s[0]);
+    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+
+    // fragment read offsets inside a slab (128-byte LDS rows, chunk XOR ((row>>1)&7))
+    uint32_t foff[2];
+#pragma unroll
+    for (int k1 = 0; k1 < 2; ++k1) foff[k1] = li * 128 + (((g + 4 * k1) ^ ((lane >> 1) & 7)) << 4);
+    const uint32_t lbase = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
+    const uint32_t b1base = (uint32_t)(uintptr_t)(LDS_AS char*)b1s + 16 * g;
+    const uint32_t tsbase = (uint32_t)(uintptr_t)(LDS_AS char*)tile_s;
+    const uint32_t gbase = (uint32_t)(uintptr_t)(LDS_AS char*)gam + 32 * g;
+    const uint32_t b2base = (uint32_t)(uintptr_t)(LDS_AS char*)b2s + 16 * g;
+
+    // ---- prime the ring: units 0 and 1 of the pass ----
+    int cons = 0;  // units consumed since kernel start (slot = cons % 3)
+    if (tile < p.ntiles) {
+        set_issue(0, 0);
+        sfor<0, 12>(dma_piece);
+        set_issue(1, 1);  // its other ten pieces go out in groups 0..4 of the first phase, as in steady state
+        dma_piece(std::integral_constant<int, 0>{});
+        dma_piece(std::integral_constant<int, 1>{});
+        ipos = 2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // fragment registers: two sets of 4 (one 8-MFMA group each).  Group 0 of BOTH kinds reads slab 0, rows
+    // 16n + li (n = 0..3), chunk g: the cross-phase prefetch does not need to know what the next phase is.
+    u32x4 wA[2][4];
+    auto rd_frag = [&](auto KIND_, auto SET_, auto G_, uint32_t sa) __attribute__((always_inline)) {
+        constexpr int kind = decltype(KIND_)::value, set = decltype(SET_)::value, gg = decltype(G_)::value, j = gg >> 2;
+        // fc1: k-step ks = gg & 3 of slab j -> LDS rows 64(ks>>1) + 16n + li, chunk 4(ks&1) + g
+        // fc2: k-step fl = (gg>>1)&1, output fragments 4(gg&1) + n -> rows 16(4(gg&1) + n) + li, chunk 4fl + g
+        constexpr int k1 = kind == KA ? (gg & 1) : ((gg >> 1) & 1);
+        constexpr int off = j * SLAB + (kind == KA ? ((gg & 3) >> 1) * 8192 : (gg & 1) * 8192);
+        if constexpr ((DBG & 4) == 0) {
+            const uint32_t a = sa + foff[k1];
+            // (asm operands do not trigger the implicit capture in a generic lambda: bind references first)
+            u32x4 &d0 = wA[set][0], &d1 = wA[set][1], &d2 = wA[set][2], &d3 = wA[set][3];
+            DSR128(d0, a, off);
+            DSR128(d1, a, off + 2048);
+            DSR128(d2, a, off + 4096);
+            DSR128(d3, a, off + 6144);
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+
+    f32x4 bq[4];  // fc1 bias a half starts from: b1s[off + 16 nf + 4g + e], read one phase ahead
+    auto bias_rd = [&](int off) __attribute__((always_inline)) {  // 4 reads, no wait: covered by the next counted wait
+        const uint32_t a = b1base + off * 4;
+        f32x4 &q0 = bq[0], &q1 = bq[1], &q2 = bq[2], &q3 = bq[3];
+        DSR128(q0, a, 0);
+        DSR128(q1, a, 64);
+        DSR128(q2, a, 128);
+        DSR128(q3, a, 192);
+    };
+    // first fragments and bias of the pass (they stay in registers across a tile's row phases)
+
+    for (int seq = 0; tile < p.ntiles; ++seq) {
+        // tiles [0, full_tiles): 128 rows each; then 16-row tail tiles (only wave 0 / fragment 0 has rows)
+        int row0, nrows;
+        if (tile < p.full_tiles) {
+            row0 = tile * TMR;
+            nrows = TMR;
+        } else {
+            row0 = p.full_tiles * TMR + (tile - p.full_tiles) * 16;
+            nrows = 16;
+        }
+        nrows = (p.M - row0) < nrows ? (p.M - row0) : nrows;
+        PSTAMP(0);
+        if (tid == 0) {  // next tile: fetched now, read after this tile's ring barriers
+            const int nt = atomicAdd(p.counter, 1);
+            asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt) : "memory");
+        }
+
+        // ---- activations: v = x + y1 -> LN2 -> operand fragments ----
+        u32x4 af[2][NCH];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+            int r = (wave * 2 + mf) * 16 + li;
+            r = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
+            const float* xr = p.x + (int64_t)(row0 + r) * D;
+            f32x4 v[NCH][2];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                v[c][0] = *(const f32x4*)(xr + (g + 4 * c) * 8);
+                v[c][1] = *(const f32x4*)(xr + (g + 4 * c) * 8 + 4);
+            }
+            if (p.y1) {
+                const bf16_t* yr = (const bf16_t*)p.y1 + (int64_t)(row0 + r) * D;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const bf16x8 y = __builtin_bit_cast(bf16x8, *(const u32x4*)(yr + (g + 4 * c) * 8));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[c][0][e] += (float)y[e];
+                        v[c][1][e] += (float)y[4 + e];
+                    }
+                }
+            }
+            ln_rows_lds(v, gbase, p.ln_eps, af[mf]);
+        }
+        PSTAMP(2);
+        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
+
+        f32x4 acc2[2][NF2];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF2; ++nf) acc2[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 acc1[2][8];
+        u32x4 hf[2][4];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) hf[mf][f] = u32x4{0u, 0u, 0u, 0u};
+        // one 2-element GELU: unit u of half-chunk GH -> one 32-bit word of the fc2 operand fragments
+        // (fragment f of fc2 takes fc1 fragments 2f (K slots 0-3) and 2f+1 (4-7): hidden 32f + 8g + slot)
+        auto gelu_unit = [&](auto GH_, auto U_) __attribute__((always_inline)) {
+            constexpr int gh = decltype(GH_)::value, u = decltype(U_)::value;
+            constexpr int mf = u >> 3, nfl = (u >> 1) & 3, jp = u & 1, nf = 4 * gh + nfl;
+            f32x2 v = {acc1[mf][nf][2 * jp], acc1[mf][nf][2 * jp + 1]};
+            if constexpr ((DBG & 2) == 0) v = gelu2(v);
+            hf[mf][nf >> 1][2 * (nf & 1) + jp] = pack_bf16x2(v[0], v[1]);
+        };
+
+        // ---- one phase: 12 groups of 8 MFMAs on the unit in slot cons % 3 ----
+        // KIND/H: fc1 half H (into acc1[.][4H..4H+3], started from the bias in bq) or fc2 half H (hf[.][2H..2H+1])
+        // GH/GSEC: GELU units of half-chunk GH, first (0) or second (1) eight, one per group 4..11; GH = -1: none
+        // NB/nb: the NEXT phase is an fc1 phase and starts from the bias at b1s offset nb (read with the cross-phase
+        //     prefetch).  An asm read whose result is never used must not be issued: its destination would be
+        //     re-used by the compiler while the data is still landing.
+        //     NB = -1: last phase of the tile, nothing is prefetched (the row phases in between need the registers)
+        auto phase = [&](auto KIND_, auto H_, auto GH_, auto GSEC_, auto NB_, int nb) __attribute__((always_inline)) {
+            constexpr int kind = decltype(KIND_)::value, h = decltype(H_)::value, gh = decltype(GH_)::value;
+            constexpr int gsec = decltype(GSEC_)::value, needb = decltype(NB_)::value;
+            const uint32_t sa = lbase + (cons % 3) * UNIT;
+            const uint32_t sn = lbase + ((cons + 1) % 3) * UNIT;
+            sfor<0, 12>([&](auto G_) __attribute__((always_inline)) {
+                constexpr int gg = decltype(G_)::value, set = gg & 1;
+                typedef std::integral_constant<int, set ^ 1> NS;
+                // (1) fragment reads one group ahead
+                if constexpr (gg == 11) {
+                    if constexpr ((DBG & 1) == 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of the next unit have landed
+                        __builtin_amdgcn_s_barrier();                     // ... everyone's; unit cons-1 is no longer read
+                        set_issue(ipos, (cons + 2) % 3);
+                        ipos = ipos + 1 == upt ? 0 : ipos + 1;
+                    }
+                    if constexpr (needb < 0) {
+                        LGKM(0);
+                    } else {
+                        rd_frag(I0{}, NS{}, I0{}, sn);
+                        if constexpr (needb > 0) {
+                            bias_rd(nb);
+                            LGKM(8);
+                        } else {
+                            LGKM(4);
+                        }
+                    }
+                } else {
+                    rd_frag(KIND_, NS{}, std::integral_constant<int, gg + 1>{}, sa);
+                    LGKM(4);
+                }
+                // (2) 8 MFMAs, with the vector work that hides under them
+                if constexpr ((DBG & 4) == 0) {
+                    if constexpr (kind == KA) {
+                        constexpr int j = gg >> 2, ks = gg & 3, kidx = 4 * j + ks;
+                        if constexpr (gg == 0) {
+                            // the bias read a phase ago has landed only NOW (the wait above): re-define it here, so that
+                            // no copy of it (hipcc moves it to the accumulator file) can be placed before this point
+                            f32x4 &q0 = bq[0], &q1 = bq[1], &q2 = bq[2], &q3 = bq[3];
+                            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+                        }
+#pragma unroll
+                        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                            for (int mf = 0; mf < 2; ++mf) {
+                                if constexpr (gg == 0) {  // C operand = bias: acc1[e] = b1[.. 16nf + 4g + e] + ...
+                                    f32x4 t = bq[nf];
+                                    Tr<bf16_t>::mma16(t, wA[set][nf], af[mf][kidx]);
+                                    acc1[mf][4 * h + nf] = t;
+                                } else {
+                                    Tr<bf16_t>::mma16(acc1[mf][4 * h + nf], wA[set][nf], af[mf][kidx]);
+                                }
+                            }
+                    } else {
+                        constexpr int j = gg >> 2, fl = (gg >> 1) & 1, q0 = (gg & 1) * 4;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int mf = 0; mf < 2; ++mf) Tr<bf16_t>::mma16(acc2[mf][8 * j + q0 + jj], wA[set][jj], hf[mf][2 * h + fl]);
+                    }
+                }
+                if constexpr (gg == 11) {
+                    dma_piece(std::integral_constant<int, 0>{});
+                    dma_piece(std::integral_constant<int, 1>{});
+                } else if constexpr (gg <= 4) {
+                    dma_piece(std::integral_constant<int, 2 + 2 * gg>{});
+                    dma_piece(std::integral_constant<int, 3 + 2 * gg>{});
+                }
+                if constexpr (gh >= 0 && gg >= 4) gelu_unit(std::integral_constant<int, (gh >= 0 ? gh : 0)>{}, std::integral_constant<int, 8 * gsec + gg - 4>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            cons += 1;
+        };
+        typedef std::integral_constant<int, -1> IM1;
+        typedef std::integral_constant<int, KA> TA;
+        typedef std::integral_constant<int, KB> TB;
+
+        // first fragments and bias of the pass (asm reads land asynchronously: nothing but the first phase may sit
+        // between them and their counted wait -- in particular not the row phases, where the compiler moves registers)
+        rd_frag(I0{}, I0{}, I0{}, lbase + (cons % 3) * UNIT);
+        bias_rd(0);
+        // chunk 0 (peeled: no runtime branches around phases inside the steady-state loop).  Its half-0 GELUs have
+        // only A1(0) to hide in: the second eight run bare.
+        phase(TA{}, I0{}, IM1{}, I0{}, I1{}, 64);
+        phase(TA{}, I1{}, I0{}, I0{}, I0{}, 0);
+        sfor<8, 16>([&](auto U_) __attribute__((always_inline)) { gelu_unit(I0{}, U_); });
+        __builtin_amdgcn_sched_barrier(0);
+        phase(TB{}, I0{}, I1{}, I0{}, I1{}, 128);
+        PSTAMP(5);
+        for (int c = 1; c < nchunk; ++c) {
+            phase(TA{}, I0{}, I1{}, I1{}, I0{}, 0);             // A0(c)   + second eight GELUs of half 1 of chunk c-1
+            phase(TB{}, I1{}, I0{}, I0{}, I1{}, c * 128 + 64);  // B1(c-1) + first eight of half 0 of chunk c
+            phase(TA{}, I1{}, I0{}, I1{}, I0{}, 0);             // A1(c)   + second eight of half 0
+            phase(TB{}, I0{}, I1{}, I0{}, I1{}, c + 1 < nchunk ? (c + 1) * 128 : 0);  // B0(c) + first eight of half 1
+        }
+        LGKM(0);  // (the last B0 read a bias nobody uses: let it land before its registers are re-used)
+        // tail: second eight of the last half 1, then B1(last); its prefetch is the next tile's A0(0)
+        sfor<8, 16>([&](auto U_) __attribute__((always_inline)) { gelu_unit(I1{}, U_); });
+        __builtin_amdgcn_sched_barrier(0);
+        phase(TB{}, I1{}, IM1{}, I0{}, IM1{}, 0);
+        PSTAMP(3);
+        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
+
+        // ---- epilogue: x <- x + y1 + acc2 + b2 (this workgroup owns its rows: in place, no other reader).
+        //      All row loads of a fragment are issued before the first asm statement (nothing moves across those).
+        sfor<0, 2>([&](auto MF_) __attribute__((always_inline)) {
+            constexpr int mf = decltype(MF_)::value;
+            const int r = (wave * 2 + mf) * 16 + li;
+            const bool live = r < nrows;
+            float* xr = p.x + (int64_t)(row0 + (live ? r : 0)) * D + 4 * g;
+            const bf16_t* yr = (const bf16_t*)p.y1 + (int64_t)(row0 + (live ? r : 0)) * D + 4 * g;
+            f32x4 xv[NF2];
+            u32x2 yv[NF2];
+#pragma unroll
+            for (int nf = 0; nf < NF2; ++nf) xv[nf] = *(const f32x4*)(xr + nf * 16);
+            if (p.y1) {
+#pragma unroll
+                for (int nf = 0; nf < NF2; ++nf) yv[nf] = *(const u32x2*)(yr + nf * 16);
+            } else {
+#pragma unroll
+                for (int nf = 0; nf < NF2; ++nf) yv[nf] = u32x2{0u, 0u};
+            }
+            sfor<0, NF2 / 4>([&](auto Q_) __attribute__((always_inline)) {  // 4 output fragments at a time
+                constexpr int q4 = decltype(Q_)::value;
+                f32x4 bb[4];
+                const uint32_t ba = b2base;
+                f32x4 &r0_ = bb[0], &r1_ = bb[1], &r2_ = bb[2], &r3_ = bb[3];
+                DSR128X4_WAIT(r0_, r1_, r2_, r3_, ba, (4 * q4) * 64, (4 * q4 + 1) * 64, (4 * q4 + 2) * 64, (4 * q4 + 3) * 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nf = 4 * q4 + j;
+                    f32x4 v = acc2[mf][nf] + bb[j] + xv[nf];
+                    const bf16x4 y = __builtin_bit_cast(bf16x4, yv[nf]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)y[e];
+                    if (live) *(f32x4*)(xr + nf * 16) = v;
+                }
+            });
+        });
+        PSTAMP(4);
+        if (DBG & 1) __syncthreads();  // (no ring barriers in this debug build)
+        int nt;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nt) : "v"(tsbase + 4 * ((seq + 1) & 1)) : "memory");
+        tile = __builtin_amdgcn_readfirstlane(nt);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (continuous stream: pieces of a pass that never runs)
+    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+}
+
+}  // namespace
+
+bool hipt_mlp_pipe_supported(int dtype, int D_, int hidden) {
+    return dtype == HIPT_BF16 && D_ == 384 && hidden % 128 == 0 && hidden >= 256 && hidden <= 1536;
+}
+
+template <int DBG>
+int hipt_mlp_pipe_launch_dbg(const MlpParams& p_in, hipStream_t st) {
+    MlpParams p = p_in;
+    const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16;
+    auto k = mlp_pipe_kernel<DBG>;
+    static bool attr = false;
+    static int ncu = 0;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            hipt_set_error("hipFuncSetAttribute(mlp_pipe) failed");
+            return HIPT_E_LAUNCH;
+        }
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            hipt_set_error("mlp_pipe: cannot query the device");
+            return HIPT_E_LAUNCH;
+        }
+        ncu = prop.multiProcessorCount;
+        attr = true;
+    }
+    // whole rounds of #CU workgroups take 128 rows each; a last partial round that would be less than an
+    // eighth full is cut into 16-row tiles (one active wave each: such a tile costs about half a full one)
+    const int tiles = (p.M + TMR - 1) / TMR;
+    const int rem = tiles % ncu;
+    const int tail_tiles = (tiles > ncu && rem > 0 && rem <= ncu / 8) ? rem : 0;
+    p.full_tiles = tiles - tail_tiles;
+    const int tail_rows = p.M - p.full_tiles * TMR;
+    p.ntiles = p.full_tiles + (tail_rows > 0 ? (tail_rows + 15) / 16 : 0);
+    const int grid = p.ntiles < ncu ? p.ntiles : ncu;
+    p.stagger = 0;
+    if (hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
+        hipt_set_error("mlp_pipe: hipMemsetAsync(counter) failed");
+        return HIPT_E_LAUNCH;
+    }
+    static const bool want_stamps = getenv("HIPT_SEQGEMM_STAMPS") != nullptr;
+    static unsigned long long* dbuf = nullptr;
+    if (want_stamps) {
+        if (!dbuf) (void)hipMalloc(&dbuf, 4096 * 16 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbuf, 0, 4096 * 16 * sizeof(unsigned long long), st);
+        p.stamps = dbuf;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
+    HIPT_CHECK_LAUNCH();
+    if (want_stamps && grid <= 4096) {
+        static unsigned long long h[4096 * 16];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, dbuf, (size_t)grid * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t4 = 0;
+        for (int b = 0; b < grid; ++b) {
+            if (h[b * 16 + 11] < t0) t0 = h[b * 16 + 11];
+            if (h[b * 16 + 10] > t4) t4 = h[b * 16 + 10];
+        }
+        double pro = 0, chunks = 0, epi = 0, ghz = 0;
+        for (int b = 0; b < grid; ++b) {
+            pro += (double)(h[b * 16 + 2] - h[b * 16 + 0]) * 0.01 / grid;
+            chunks += (double)(h[b * 16 + 3] - h[b * 16 + 2]) * 0.01 / grid;
+            epi += (double)(h[b * 16 + 4] - h[b * 16 + 3]) * 0.01 / grid;
+            ghz += (double)(h[b * 16 + 9] - h[b * 16 + 8]) / (double)(h[b * 16 + 3] - h[b * 16 + 2]) * 0.1 / grid;
+        }
+        fprintf(stderr, "[mlp_pipe dbg=%d hidden=%d grid=%d tiles=%d(+%d)] total %.1f us | first tiles: rows+LN %.1f, chunks %.1f (%.2f GHz), epilogue %.1f\n",
+                DBG, p.hidden, grid, p.full_tiles, p.ntiles - p.full_tiles, (double)(t4 - t0) * 0.01, pro, chunks, ghz, epi);
+    }
+    return HIPT_OK;
+}
+
+int hipt_mlp_pipe_launch(const MlpParams& p, hipStream_t st) { return hipt_mlp_pipe_launch_dbg<0>(p, st); }

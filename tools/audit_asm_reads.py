@@ -1,0 +1,53 @@
+"""Audit of a -save-temps .s: between an inline-asm ds_read and the inline-asm s_waitcnt lgkmcnt(N) that retires it,
+no compiler-generated instruction may read or write its destination registers (the data lands asynchronously;
+hipcc treats the destination as written at ;;#ASMEND).  usage: audit_asm_reads.py file.s [kernel-symbol-substring]"""
+import re
+import sys
+
+src = open(sys.argv[1]).read().split("\n")
+want = sys.argv[2] if len(sys.argv) > 2 else ""
+inside = want == ""
+queue = []  # [(line, set(regs))]
+inasm = False
+bad = 0
+for i, l in enumerate(src):
+    t = l.strip()
+    lab = re.match(r"^([A-Za-z_][\w.$]*):", l)
+    if want and lab:
+        inside = want in lab.group(1)
+        queue = []
+    if not inside:
+        continue
+    if t.startswith(";;#ASMSTART"):
+        inasm = True
+        continue
+    if t.startswith(";;#ASMEND"):
+        inasm = False
+        continue
+    if inasm:
+        m = re.match(r"ds_read\w* (v\[(\d+):(\d+)\]|v(\d+)),", t)
+        if m:
+            regs = set(range(int(m.group(2)), int(m.group(3)) + 1)) if m.group(2) else {int(m.group(4))}
+            queue.append((i + 1, regs))
+        for mm in re.finditer(r"lgkmcnt\((\d+)\)", t):
+            n = int(mm.group(1))
+            queue = queue[len(queue) - n:] if n > 0 else []
+        continue
+    if not t or t[0] in ";." or t.endswith(":"):
+        continue
+    if "s_waitcnt" in t and "lgkmcnt(0)" in t:
+        queue = []
+        continue
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", t):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", t))
+    for ln, rs in queue:
+        hit = regs & rs
+        if hit:
+            bad += 1
+            if bad <= 20 or "-v" in sys.argv:
+                print(f"line {i + 1}: `{t}` touches v{sorted(hit)} of the asm read at line {ln} still in flight")
+            break
+print("violations:", bad)
+sys.exit(1 if bad else 0)
