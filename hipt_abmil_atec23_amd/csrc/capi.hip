@@ -140,16 +140,19 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             q.M = M; q.K = D; q.ln_eps = w->ln_eps;
             q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.N = 3 * D; q.bias = b.qkv_b;
             q.out = s.qkv; q.ldc = 3 * D;
+            // (the hidden tensor is never materialised on this path: its slot holds the kernels' tile queues)
+            q.counter = (int*)s.hid + 16;
             PROF(PC_QKV, hipt_seqgemm_launch(q, true, 0, st));
             PROF(PC_ATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st));
             if (last_probs) break;
             q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
+            q.counter = (int*)s.hid + 32;
             PROF(PC_PROJ, hipt_seqgemm_launch(q, false, 0, st));
             MlpParams m;
             memset(&m, 0, sizeof(m));
             m.x = x; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
             m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.M = M; m.D = D; m.hidden = w->hidden;
-            m.counter = (int*)s.hid;  // (the hidden tensor is never materialised on this path: its slot holds the tile queue)
+            m.counter = (int*)s.hid;
             PROF(PC_MLP, hipt_mlp_launch(m, st));
             continue;
         } else {

@@ -45,9 +45,13 @@ struct SeqGemmParams {
     const float* bias;
     void* out;           // bf16 [M, ldc]
     int64_t ldc;
+    int* counter;        // (pipelined kernel) device int the launcher zeroes on the stream: the tile queue
+    int ntiles;          // (set by the launcher)
 };
 bool hipt_seqgemm_supported(int dtype, int K);
-int hipt_seqgemm_launch(const SeqGemmParams& p, bool ln, int flags, hipStream_t st);
+int hipt_seqgemm_launch(const SeqGemmParams& p, bool ln, int flags, hipStream_t st);  // dispatches to the pipelined kernel when it applies
+bool hipt_seqgemm_pipe_supported(int dtype, int K, int N, bool ln, int flags);
+int hipt_seqgemm_pipe_launch(const SeqGemmParams& p, bool ln, hipStream_t st);
 
 // Fused MLP sub-block (mlp.hip): x <- x + y1 + fc2(GELU(fc1(LN2(x + y1))))
 struct MlpParams {

@@ -24,80 +24,20 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include <type_traits>
-
 #include "common.h"
 #include "kernels.h"
 #include "mlp_common.h"
+#include "pipe_common.h"
 
 namespace {
 
 constexpr int D = 384, NCH = 12, NF2 = 24, TMR = 128;
 constexpr int SLAB = 16384, UNIT = 3 * SLAB;
 
-template <int I, int N, class F> __device__ __forceinline__ void sfor(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        sfor<I + 1, N>(f);
-    }
-}
-
-#define DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define DSR64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-// four / eight LDS reads AND their wait in ONE statement: the outputs are valid when the statement ends, so the
-// compiler may do what it likes with them (the split form -- reads, then a counted wait -- is only safe where
-// nothing makes hipcc copy or re-use the destinations in between: tools/audit_asm_reads.py checks the .s)
-#define DSR128X4_WAIT(d0, d1, d2, d3, addr, o0, o1, o2, o3)                                                      \
-    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t" \
-                 "ds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"                                           \
-                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)                                                     \
-                 : "v"(addr), "n"(o0), "n"(o1), "n"(o2), "n"(o3))
-#define LGKM(n)                                                 \
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); \
-    __builtin_amdgcn_sched_barrier(0)
 #define PSTAMP(k)                                                                                                    \
     do {                                                                                                             \
         if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
-
-// LayerNorm of the 16-row fragment a lane quartet holds (lanes sharing lane&15 own one row), result packed as MFMA
-// operand chunks.  gamma / beta come from LDS through asm reads with immediate offsets off ONE address register:
-// written as C++ loads, hipcc hoists the 48 per-chunk addresses out of the tile loop and spills every one of them.
-// gaddr = LDS byte address of gamma + 32 g;  beta sits D floats behind gamma.
-__device__ __forceinline__ void ln_rows_lds(f32x4 (&v)[NCH][2], uint32_t gaddr, float eps, u32x4 (&out)[NCH]) {
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s += v[c][0][e] + v[c][1][e];
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.0f / D);
-    float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float a = v[c][0][e] - mean, b = v[c][1][e] - mean;
-            q += a * a + b * b;
-        }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / D) + eps);
-    sfor<0, NCH>([&](auto C_) __attribute__((always_inline)) {
-        constexpr int c = decltype(C_)::value;
-        f32x4 g0, g1, b0, b1;
-        const uint32_t ga = gaddr;
-        DSR128X4_WAIT(g0, g1, b0, b1, ga, c * 128, c * 128 + 16, c * 128 + D * 4, c * 128 + D * 4 + 16);
-        const f32x4 y0 = (v[c][0] - mean) * rstd * g0 + b0, y1 = (v[c][1] - mean) * rstd * g1 + b1;
-        u32x4 o;
-        o[0] = pack_bf16x2(y0[0], y0[1]);
-        o[1] = pack_bf16x2(y0[2], y0[3]);
-        o[2] = pack_bf16x2(y1[0], y1[1]);
-        o[3] = pack_bf16x2(y1[2], y1[3]);
-        out[c] = o;
-    });
-}
 
 enum { KA = 0, KB = 1 };            // phase kind: fc1 half / fc2 half
 
@@ -287,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
                     }
                 }
             }
-            ln_rows_lds(v, gbase, p.ln_eps, af[mf]);
+            ln_rows_lds<D, NCH>(v, gbase, p.ln_eps, af[mf]);
         }
         PSTAMP(2);
         if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();

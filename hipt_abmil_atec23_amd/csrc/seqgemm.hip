@@ -339,6 +339,8 @@ int hipt_seqgemm_launch(const SeqGemmParams& p_in, bool ln, int flags, hipStream
     HIPT_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0 && ((uintptr_t)p.out % 16) == 0 && p.ldc % 4 == 0 &&
                        (p.lda * (ln ? 4 : 2)) % 16 == 0,
                    "seqgemm: 16-byte alignment required");
+    static const bool no_pipe = getenv("HIPT_NO_SEQGEMM_PIPE") != nullptr;
+    if (!no_pipe && p.counter && hipt_seqgemm_pipe_supported(HIPT_BF16, p.K, p.N, ln, flags)) return hipt_seqgemm_pipe_launch(p, ln, st);
     const int tiles_n = (p.N + 127) / 128, tiles_m = (p.M + TM - 1) / TM;
     // whole rounds of 256 CUs run one workgroup per row tile; the tiles of the last partial round are
     // split over their N tiles when that round would otherwise be mostly empty
