@@ -9,12 +9,14 @@
 // error, tools/fit_gelu.py) to -log2(e) * logit(Phi(x)) / x: |gelu error| <= 3.5e-6 for every finite fp32 x
 // (the bf16 rounding of the result is 4e-3 relative), tails exact (q's leading term keeps the sign), and
 // the arithmetic is all packed-fp32 (two elements per VALU instruction) plus one v_exp_f32 and one v_rcp_f32.
+// (every multiply-add written out, fp contract off: all unrolled instances must round alike -- see pipe_common.h)
 __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+#pragma clang fp contract(off)
     const f32x2 t = x * x;
-    f32x2 q = t * -3.228983431e-06f + 8.823808482e-05f;
-    q = q * t + 3.602743489e-04f;
-    q = q * t + -1.052266864e-01f;
-    q = q * t + -2.302045392e+00f;
+    f32x2 q = __builtin_elementwise_fma(t, f32x2{-3.228983431e-06f, -3.228983431e-06f}, f32x2{8.823808482e-05f, 8.823808482e-05f});
+    q = __builtin_elementwise_fma(q, t, f32x2{3.602743489e-04f, 3.602743489e-04f});
+    q = __builtin_elementwise_fma(q, t, f32x2{-1.052266864e-01f, -1.052266864e-01f});
+    q = __builtin_elementwise_fma(q, t, f32x2{-2.302045392e+00f, -2.302045392e+00f});
     const f32x2 pw = x * q;
     f32x2 d;
     d[0] = __builtin_amdgcn_exp2f(pw[0]);
@@ -29,6 +31,7 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
 template <int NCH>
 __device__ __forceinline__ void ln_rows(f32x4 (&v)[NCH][2], const float* gam, const float* bet, int K, float eps, int g,
                                         u32x4 (&out)[NCH]) {
+#pragma clang fp contract(off)
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
@@ -43,7 +46,8 @@ __device__ __forceinline__ void ln_rows(f32x4 (&v)[NCH][2], const float* gam, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a = v[c][0][e] - mean, b = v[c][1][e] - mean;
-            q += a * a + b * b;
+            q = __builtin_fmaf(a, a, q);
+            q = __builtin_fmaf(b, b, q);
         }
     q += __shfl_xor(q, 16, 64);
     q += __shfl_xor(q, 32, 64);
@@ -53,7 +57,12 @@ __device__ __forceinline__ void ln_rows(f32x4 (&v)[NCH][2], const float* gam, co
         const int k0 = (g + 4 * c) * 8;
         const f32x4 g0 = *(const f32x4*)(gam + k0), g1 = *(const f32x4*)(gam + k0 + 4);
         const f32x4 b0 = *(const f32x4*)(bet + k0), b1 = *(const f32x4*)(bet + k0 + 4);
-        const f32x4 y0 = (v[c][0] - mean) * rstd * g0 + b0, y1 = (v[c][1] - mean) * rstd * g1 + b1;
+        f32x4 y0, y1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y0[e] = __builtin_fmaf((v[c][0][e] - mean) * rstd, g0[e], b0[e]);
+            y1[e] = __builtin_fmaf((v[c][1][e] - mean) * rstd, g1[e], b1[e]);
+        }
         u32x4 o;
         o[0] = pack_bf16x2(y0[0], y0[1]);
         o[1] = pack_bf16x2(y0[2], y0[3]);

@@ -68,12 +68,18 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
     // unit U(rho) = 32(nf>>1) + 8g' + 4(nf&1) + e: lane g' then owns, over the fragment pair (2f, 2f+1), hidden
     // 32f + 8g' + (0..7).  U(rho + 32) = U(rho) + 32, so piece q still only adds a uniform offset.
     const int urow = 32 * (r0 >> 5) + 8 * ((r0 >> 2) & 3) + 4 * ((r0 >> 4) & 1) + (r0 & 3);
-    const uint32_t l1off = (uint32_t)(urow * D + ch0 * 8) * 2;  // per-lane BYTE offsets; everything else is wave-uniform
-    const uint32_t l2off = (uint32_t)(r0 * p.hidden + ch0 * 8) * 2;  // B slab: 128 outputs x 64 hidden -> R = output
+    // per-lane BYTE offsets into W1 (A slabs) and W2 (B slab: 128 outputs x 64 hidden, R = output), both multiples
+    // of 16 and < 2^20: packed into ONE register (two loop-invariant registers were being spilled and re-loaded from
+    // scratch, with a vmcnt(0), once per phase); everything else about a DMA address is wave-uniform
+    const uint32_t lanepack = ((uint32_t)(urow * D + ch0 * 8) >> 3) | (((uint32_t)(r0 * p.hidden + ch0 * 8) >> 3) << 16);
     // issue side of the ring: the unit whose 12 pieces per wave are being issued
-    const char* ibase = (const char*)W1;  // uniform: matrix base + unit offset (bytes)
-    uint32_t ilane = l1off;
-    int64_t ijoff = 0, iq1 = 0, iq2 = 0;   // bytes
+    // buffer-addressed LDS-DMA: resource = whole matrix (scalar registers), per-lane offset in ONE 32-bit register,
+    // everything else (unit, slab, piece) in the scalar offset -> no vector address arithmetic per piece
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)W1, 0, p.hidden * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)W2, 0, p.hidden * D * 2, 0x00020000);
+    bool ia = true;        // the unit being issued is an fc1 unit
+    uint32_t ilane = 0;    // per-lane byte offset
+    int ioff = 0, ijoff = 0, iq1 = 0, iq2 = 0;  // bytes, wave-uniform
     int islot = 0, ipos = 0;
     // position i of a tile pass -> which weights: A0(0) A1(0) B0(0) | A0(c) B1(c-1) A1(c) B0(c) ... | B1(n-1)
     auto set_issue = [&](int pos, int slot) {
@@ -94,25 +100,27 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
             h = r == 2 ? 1 : (r == 1 ? 1 : 0);
             if (r == 1) c -= 1;
         }
+        ia = is_a;
         if (is_a) {  // hidden rows [128c + 64h, +64) x all k; slab j covers k [128j, +128)
-            ibase = (const char*)(W1 + (int64_t)(c * 128 + 64 * h) * D);
-            ilane = l1off;
+            ioff = (c * 128 + 64 * h) * D * 2;
+            ilane = (lanepack & 0xffffu) << 4;
             ijoff = 128 * 2;
             iq1 = 32 * D * 2;
             iq2 = 64 * 2;
         } else {  // output rows [128j, +128) x hidden [128c + 64h, +64)
-            ibase = (const char*)(W2 + c * 128 + 64 * h);
-            ilane = l2off;
-            ijoff = (int64_t)128 * p.hidden * 2;
-            iq1 = (int64_t)32 * p.hidden * 2;
-            iq2 = (int64_t)64 * p.hidden * 2;
+            ioff = (c * 128 + 64 * h) * 2;
+            ilane = (lanepack >> 16) << 4;
+            ijoff = 128 * p.hidden * 2;
+            iq1 = 32 * p.hidden * 2;
+            iq2 = 64 * p.hidden * 2;
         }
         islot = slot;
     };
     auto dma_piece = [&](auto T_) __attribute__((always_inline)) {
         constexpr int t = decltype(T_)::value, j = t >> 2, q = t & 3;
         if constexpr ((DBG & 1) == 0)
-            glds16(ibase + (j * ijoff + (q & 1) * iq1 + (q >> 1) * iq2) + ilane, smem + islot * UNIT + j * SLAB + (q * 4 + wave) * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ia ? rs1 : rs2, (LDS_AS void*)(smem + islot * UNIT + j * SLAB + (q * 4 + wave) * 1024), 16, ilane,
+                                                     ioff + j * ijoff + (q & 1) * iq1 + (q >> 1) * iq2, 0, 0);
     };
 
     for (int i = tid; i < D; i += 256) {
@@ -228,6 +236,21 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
                 }
             }
             ln_rows_lds<D, NCH>(v, gbase, p.ln_eps, af[mf]);
+            if (mf == 0) {
+                // park the finished fragment in the accumulator file (idle during the row phase) while the other one
+                // is loaded and normalised: left alone, hipcc sends it to scratch and the reloads stall the first phase
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    u32x4& a2 = af[0][c];
+                    asm volatile("" : "+a"(a2));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            u32x4& a2 = af[0][c];
+            asm volatile("" : "+v"(a2));
         }
         PSTAMP(2);
         if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();

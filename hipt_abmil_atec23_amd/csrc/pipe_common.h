@@ -30,8 +30,12 @@ template <int I, int N, class F> __device__ __forceinline__ void sfor(F&& f) {
 // operand chunks.  gamma / beta come from LDS through asm reads with immediate offsets off ONE address register:
 // written as C++ loads, hipcc hoists the 48 per-chunk addresses out of the tile loop and spills every one of them.
 // gaddr = LDS byte address of gamma + 32 g;  beta sits D floats behind gamma.
+// Every multiply-add is written out (fp contract off): left to hipcc, the unrolled instances of this function get
+// DIFFERENT contractions (mul+add here, fma there), i.e. a row's result would depend on which fragment of a tile
+// it lands in -- the outputs must not depend on how rows are batched.
 template <int D, int NCH>
 __device__ __forceinline__ void ln_rows_lds(f32x4 (&v)[NCH][2], uint32_t gaddr, float eps, u32x4 (&out)[NCH]) {
+#pragma clang fp contract(off)
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
@@ -46,17 +50,24 @@ __device__ __forceinline__ void ln_rows_lds(f32x4 (&v)[NCH][2], uint32_t gaddr, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a = v[c][0][e] - mean, b = v[c][1][e] - mean;
-            q += a * a + b * b;
+            q = __builtin_fmaf(a, a, q);
+            q = __builtin_fmaf(b, b, q);
         }
     q += __shfl_xor(q, 16, 64);
     q += __shfl_xor(q, 32, 64);
     const float rstd = 1.0f / sqrtf(q * (1.0f / D) + eps);
     sfor<0, NCH>([&](auto C_) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
         constexpr int c = decltype(C_)::value;
         f32x4 g0, g1, b0, b1;
         const uint32_t ga = gaddr;
         DSR128X4_WAIT(g0, g1, b0, b1, ga, c * 128, c * 128 + 16, c * 128 + D * 4, c * 128 + D * 4 + 16);
-        const f32x4 y0 = (v[c][0] - mean) * rstd * g0 + b0, y1 = (v[c][1] - mean) * rstd * g1 + b1;
+        f32x4 y0, y1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y0[e] = __builtin_fmaf((v[c][0][e] - mean) * rstd, g0[e], b0[e]);
+            y1[e] = __builtin_fmaf((v[c][1][e] - mean) * rstd, g1[e], b1[e]);
+        }
         u32x4 o;
         o[0] = pack_bf16x2(y0[0], y0[1]);
         o[1] = pack_bf16x2(y0[2], y0[3]);
@@ -65,4 +76,3 @@ __device__ __forceinline__ void ln_rows_lds(f32x4 (&v)[NCH][2], uint32_t gaddr, 
         out[c] = o;
     });
 }
-

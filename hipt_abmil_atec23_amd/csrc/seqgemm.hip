@@ -67,6 +67,7 @@ __device__ __forceinline__ void seq_epilogue(const SeqGemmParams& p, uint32_t bi
 template <int NCH>
 __device__ __forceinline__ void ln_rows(f32x4 (&v)[NCH][2], const float* gam, const float* bet, int K, float eps, int g,
                                         u32x4 (&out)[NCH]) {
+#pragma clang fp contract(off)  // every multiply-add written out: all unrolled instances must round alike (pipe_common.h)
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
@@ -81,7 +82,8 @@ __device__ __forceinline__ void ln_rows(f32x4 (&v)[NCH][2], const float* gam, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a = v[c][0][e] - mean, b = v[c][1][e] - mean;
-            q += a * a + b * b;
+            q = __builtin_fmaf(a, a, q);
+            q = __builtin_fmaf(b, b, q);
         }
     q += __shfl_xor(q, 16, 64);
     q += __shfl_xor(q, 32, 64);
@@ -91,7 +93,12 @@ __device__ __forceinline__ void ln_rows(f32x4 (&v)[NCH][2], const float* gam, co
         const int k0 = (g + 4 * c) * 8;
         const f32x4 g0 = *(const f32x4*)(gam + k0), g1 = *(const f32x4*)(gam + k0 + 4);
         const f32x4 b0 = *(const f32x4*)(bet + k0), b1 = *(const f32x4*)(bet + k0 + 4);
-        const f32x4 y0 = (v[c][0] - mean) * rstd * g0 + b0, y1 = (v[c][1] - mean) * rstd * g1 + b1;
+        f32x4 y0, y1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y0[e] = __builtin_fmaf((v[c][0][e] - mean) * rstd, g0[e], b0[e]);
+            y1[e] = __builtin_fmaf((v[c][1][e] - mean) * rstd, g1[e], b1[e]);
+        }
         u32x4 o;
         o[0] = pack_bf16x2(y0[0], y0[1]);
         o[1] = pack_bf16x2(y0[2], y0[3]);

@@ -266,6 +266,20 @@ def test_hipt4k_small_region_fp32(hipt):
     assert md(hipt(xp), g["out"]) < TOL
 
 
+def test_vit256_bf16_is_batch_invariant_bitwise(vit256):
+    """A patch's tokens must not depend on how many patches share the call (which row tile / MFMA fragment a row
+    lands in): every layer output of 6 patches inside an 18-patch batch equals, bit for bit, that of the 6 alone."""
+    x = synth.hash_uniform_torch((18, 3, 256, 256), 33, device=DEV)
+    vit256.set_compute_dtype("bf16")
+    try:
+        a = vit256.get_intermediate_layers(x, n=12)
+        b = vit256.get_intermediate_layers(x[12:18], n=12)
+    finally:
+        vit256.set_compute_dtype("fp32")
+    for i, (p, q) in enumerate(zip(a, b)):
+        assert torch.equal(p[12:18], q), f"layer {i}: max diff {float((p[12:18] - q).abs().max())}"
+
+
 def test_hipt4k_region_batch_equals_single_regions(hipt):
     """R regions per call (throughput form) give the same features as R single-region calls."""
     x = synth.hash_uniform_torch((3, 3, 512, 768), 33, device=DEV)

@@ -130,6 +130,28 @@ int main(int argc, char** argv) {
                 if (e > 2e-2) { ++nbad; if (first_bad_row < 0) { first_bad_row = r; first_bad_col = n; } }
             }
         }
+        {   // batch invariance: the same rows at a different position inside the tiles must give the same bits
+            const int sh = argc > 3 ? atoi(argv[3]) : 12;
+            CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+            MlpParams p2 = p;
+            p2.x = (float*)x + (size_t)sh * D;
+            p2.y1 = (const uint16_t*)y + (size_t)sh * D;
+            p2.M = M - sh;
+            LAUNCH(0, p2);
+            CK(hipDeviceSynchronize());
+            std::vector<float> out2((size_t)M * D);
+            CK(hipMemcpy(out2.data(), x, out2.size() * 4, hipMemcpyDeviceToHost));
+            long ndiff = 0;
+            int fr = -1, fc = -1;
+            for (int r = sh; r < M; ++r)
+                for (int n = 0; n < D; ++n)
+                    if (memcmp(&out[(size_t)r * D + n], &out2[(size_t)r * D + n], 4) != 0) {
+                        ++ndiff;
+                        if (fr < 0) { fr = r; fc = n; }
+                    }
+            printf("shift-by-%d invariance: %ld elements differ bitwise, first (row %d, col %d)\n", sh, ndiff, fr, fc);
+            if (ndiff) nbad += ndiff;
+        }
         printf("check M=%d: max |err| %.3e, %ld elements off by > 2e-2, %ld NaN, first bad (row %d, col %d)\n", M, maxerr, nbad, nnan, first_bad_row, first_bad_col);
         return (nbad || nnan) ? 1 : 0;
     }

@@ -122,6 +122,27 @@ int main(int argc, char** argv) {
                 if (e > 2e-2 + 8e-3 * fabs(acc)) { ++nbad; if (br < 0) { br = r; bc = n; } }
             }
         }
+        {   // batch invariance: the same rows at a different position inside the tiles must give the same bits
+            const int sh = argc > 4 ? atoi(argv[3]) : 12;
+            SeqGemmParams p2 = p;
+            p2.A = proj ? (const void*)((const uint16_t*)a + (size_t)sh * K) : (const void*)((const float*)x + (size_t)sh * K);
+            p2.M = M - sh;
+            std::vector<uint16_t> ho2((size_t)M * N);
+            CK(hipMemset(out, 0, (size_t)M * N * 2));
+            if (LAUNCH(p2, !proj)) return 2;
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(ho2.data(), out, ho2.size() * 2, hipMemcpyDeviceToHost));
+            long ndiff = 0;
+            int fr = -1, fc = -1;
+            for (int r = sh; r < M; ++r)
+                for (int n = 0; n < N; ++n)
+                    if (ho[(size_t)r * N + n] != ho2[(size_t)(r - sh) * N + n]) {
+                        ++ndiff;
+                        if (fr < 0) { fr = r; fc = n; }
+                    }
+            printf("shift-by-%d invariance: %ld elements differ bitwise, first (row %d, col %d)\n", sh, ndiff, fr, fc);
+            nbad += ndiff;
+        }
         printf("check %s M=%d: max |err| %.3e, %ld elements off, first bad (row %d, col %d)\n", proj ? "proj" : "qkv", M, maxerr, nbad, br, bc);
         return nbad ? 1 : 0;
     }
