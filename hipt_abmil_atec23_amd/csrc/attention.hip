@@ -11,6 +11,8 @@
 // consistently on the V side).  V fragments come from row-major V through the hardware
 // transposing LDS read (ds_read_b64_tr_b16) in bf16 mode and through padded ds_read_b32 in fp32
 // mode.  Softmax runs in fp32 with exp2 and a pre-multiplied scale*log2(e).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -230,6 +232,8 @@ int hipt_attention_launch(const void* qkv, void* out, float* probs, int B, int n
         return HIPT_E_UNSUPPORTED;
     }
     HIPT_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "attention: 16-byte alignment required");
+    static const bool v1_only = getenv("HIPT_ATTN_V1") != nullptr;
+    if (!v1_only && hipt_attention64_supported(dtype, dh, ntok, probs != nullptr)) return hipt_attention64_launch(qkv, out, B, ntok, heads, scale, st);
     if (dtype == HIPT_F32) return dispatch<float>(qkv, out, probs, B, ntok, heads, dh, scale, st);
     if (dtype == HIPT_BF16) return dispatch<bf16_t>(qkv, out, probs, B, ntok, heads, dh, scale, st);
     hipt_set_error("attention: bad dtype %d", dtype);

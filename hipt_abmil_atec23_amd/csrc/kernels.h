@@ -80,7 +80,9 @@ int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, cons
                           int64_t out_stride, int rows, int D, float eps, hipStream_t st);
 
 int hipt_attention_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale,
-                          int dtype, hipStream_t st);
+                          int dtype, hipStream_t st);  // dispatches to the bf16 / head-dim-64 kernel when it applies
+bool hipt_attention64_supported(int dtype, int dh, int ntok, bool want_probs);
+int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st);
 
 // x[s, 0, :] = cls + pos[0]  for s in [0, nseq)
 int hipt_cls_init_launch(float* x, const float* cls, const float* pos, int nseq, int ntok, int D, hipStream_t st);
