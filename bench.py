@@ -62,8 +62,8 @@ def kernel_flops(cat, rows, D=384, H=1536, heads=6, ntok=257):
 
 
 # rocprofv3 kernel names of the categories (profiles/<tag>_traffic.json keys)
-TRAFFIC_KEYS = {"mlp_fused": "void mlp_kernel<6>", "qkv_gemm": "void seqgemm_kernel<6, true, 0>",
-                "proj_gemm": "void seqgemm_kernel<6, false, 0>", "attention": "attn_kernel<DF16bLi64ELi18ELb0E>",
+TRAFFIC_KEYS = {"mlp_fused": "void mlp_pipe_kernel<0>", "qkv_gemm": "void seqgemm_pipe_kernel<true, 0>",
+                "proj_gemm": "void seqgemm_pipe_kernel<false, 0>", "attention": "attn64_kernel",
                 "abmil_fused": "void abmil_stream_kernel<6>"}
 
 

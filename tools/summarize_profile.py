@@ -34,11 +34,11 @@ def short(name):
 
 
 def ours(name):
-    return any(k in name for k in ("seqgemm", "mlp_kernel", "gemm_kernel", "attn_kernel", "ln_kernel", "abmil",
+    return any(k in name for k in ("seqgemm", "mlp_kernel", "mlp_pipe_kernel", "gemm_kernel", "attn_kernel", "attn64_kernel", "ln_kernel", "abmil",
                                    "cls_init", "f32_to_bf16", "gate_kernel", "pool_kernel", "add_bf16"))
 
 
-stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "*", "*_kernel_stats.csv"))
+stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     rows = [r for r in csv.DictReader(open(stats[0])) if ours(r["Name"])]
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -52,7 +52,7 @@ if stats:
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for kind in ("fetch", "write", "sq", "grbm"):
-    for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{kind}_{tag}", "*", "*_counter_collection.csv")):
+    for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{kind}_{tag}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if ours(r["Kernel_Name"]):
                 agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
