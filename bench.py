@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--chunk", type=int, default=0, help="patches per ViT-256 pass (0 = library default)")
+    ap.add_argument("--u8", action="store_true", help="regions resident as uint8 RGB [R,W,H,3], normalised on the device (SURVEY 8f-1)")
     ap.add_argument("--regions", type=int, default=8, help="4096x4096 regions per HIPT_4K call (1 = the reference's batch_size)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,6 +163,8 @@ def main():
     model.chunk = args.chunk
     R = args.regions
     region = synth.hash_uniform_torch((R, 3, REGION, REGION), 3 + rank, device=dev)
+    if args.u8:  # the same pixels as decoded 8-bit RGB tiles (interleaved), 4x fewer bytes
+        region = ((region * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
     n_bags = 5  # 5 x 76.8 MB > 256 MiB Infinity Cache
     bag_dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     bags = [synth.hash_uniform_torch((BAG_N, BAG_S0), 40 + 10 * rank + i, device=dev).to(bag_dt) for i in range(n_bags)]
@@ -212,7 +215,7 @@ def main():
         "config": {"workload": "per step: HIPT_4K.forward on R resident [3,4096,4096] fp32 regions (R x 256 patches ViT-256 -> "
                                "ViT-4K over each 16x16 [CLS] grid, BASELINE configs[2]) + CLAM_SB gated-attention pooling over one "
                                "100000x384 bag (configs[3]); random-init weights of the reference architectures",
-                   "regions_per_step": R, "bag": [BAG_N, BAG_S0], "chunk_patches": args.chunk or 256 * R,
+                   "regions_per_step": R, "input": "uint8 RGB interleaved" if args.u8 else "fp32 normalised", "bag": [BAG_N, BAG_S0], "chunk_patches": args.chunk or 256 * R,
                    "parallelism": f"slide-sharded x{world}, one all-gather"},
         "abmil_fwd_ms": abmil_ms,
         "model_tflops": world * args.steps * R * FLOP_PER_REGION / dt / 1e12,

@@ -72,6 +72,9 @@ SIGNATURES = {
     "hipt_vit4k_forward": (_i, [_VW, _p, _i, _p, _p, _sz, _p]),
     "hipt_hipt4k_workspace_bytes": (_sz, [_VW, _VW, _i, _i, _i, _i]),
     "hipt_hipt4k_forward": (_i, [_VW, _VW, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "hipt_hipt4k_u8_workspace_bytes": (_sz, [_VW, _VW, _i, _i, _i, _i]),
+    "hipt_hipt4k_forward_u8": (_i, [_VW, _VW, _p, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "hipt_u8_normalize": (_i, [_p, _i, C.c_int64, C.c_int64, _p, _i, _p]),
     "hipt_clam_workspace_bytes": (_sz, [_CW, _i]),
     "hipt_clam_sb_forward": (_i, [_CW, _p, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "hipt_attn_net_gated": (_i, [_CW, _p, _i, _p, _p, _sz, _p]),

@@ -374,8 +374,17 @@ int hipt_vit_head(const hipt_vit_weights* w, const float* x, int nseq, int cls_o
     return hipt_layernorm_launch(x, D, w->norm_w, w->norm_b, out, HIPT_F32, D, nseq * w->ntok, D, w->ln_eps, S(stream));
 }
 
-int hipt_vit256_forward(const hipt_vit_weights* w, const float* images, const hipt_image_layout* lay, int nseq, int chunk,
-                        float* out, void* workspace, size_t ws_bytes, void* stream) {
+// images: fp32 [.., 3, W, H] (kind 0), or uint8 in the same layout (kind 1) / interleaved [.., W, H, 3] (kind 2), which
+// are normalised on device into the compute dtype
+enum { IMG_F32 = 0, IMG_U8_CHW = 1, IMG_U8_HWC = 2 };
+
+static size_t image_extra_bytes(const hipt_vit_weights* w, const hipt_image_layout* lay, int nseq, int kind) {
+    // bf16 mode already holds a bf16 image in its workspace; fp32 mode needs an fp32 one for uint8 input
+    return (kind != IMG_F32 && w->dtype == HIPT_F32) ? al256((size_t)image_elems(lay, nseq) * 4) : 0;
+}
+
+static int vit256_forward_impl(const hipt_vit_weights* w, const void* images, int kind, const hipt_image_layout* lay, int nseq, int chunk,
+                               float* out, void* workspace, size_t ws_bytes, void* stream) {
     int rc = check_vit(w);
     if (rc) return rc;
     HIPT_CHECK_ARG(images && lay && out && nseq > 0, "vit256_forward: null/empty argument");
@@ -389,12 +398,19 @@ int hipt_vit256_forward(const hipt_vit_weights* w, const float* images, const hi
     void* imgT = nullptr;
     const int64_t n_img = image_elems(lay, nseq);
     if (w->dtype == HIPT_BF16) imgT = c.take((size_t)n_img * 2);
+    else if (kind != IMG_F32) imgT = c.take((size_t)n_img * 4);
     if (!c.ok()) {
         hipt_set_error("vit256_forward: workspace %zu B too small / unaligned (need %zu)", ws_bytes, c.used);
         return HIPT_E_WORKSPACE;
     }
-    if (imgT) {
-        PROF(PC_OTHER, hipt_f32_to_bf16_launch(images, imgT, n_img, st));
+    if (kind != IMG_F32) {
+        const int per = lay->grid_w * lay->grid_h;
+        HIPT_CHECK_ARG(nseq % per == 0, "vit256_forward: uint8 input must hold whole regions");
+        const int64_t plane = lay->batch_stride / 3;
+        PROF(PC_OTHER, hipt_u8_normalize_launch(images, kind == IMG_U8_HWC, nseq / per, plane, imgT, w->dtype, st));
+        img = imgT;
+    } else if (imgT) {
+        PROF(PC_OTHER, hipt_f32_to_bf16_launch((const float*)images, imgT, n_img, st));
         img = imgT;
     }
     for (int s0 = 0; s0 < nseq; s0 += chunk) {
@@ -405,6 +421,11 @@ int hipt_vit256_forward(const hipt_vit_weights* w, const float* images, const hi
                                           w->dim, n, w->dim, w->ln_eps, st));
     }
     return HIPT_OK;
+}
+
+int hipt_vit256_forward(const hipt_vit_weights* w, const float* images, const hipt_image_layout* lay, int nseq, int chunk,
+                        float* out, void* workspace, size_t ws_bytes, void* stream) {
+    return vit256_forward_impl(w, images, IMG_F32, lay, nseq, chunk, out, workspace, ws_bytes, stream);
 }
 
 int hipt_vit4k_forward(const hipt_vit_weights* w, const float* tokens_in, int nseq, float* out, void* workspace,
@@ -451,8 +472,8 @@ size_t hipt_hipt4k_workspace_bytes(const hipt_vit_weights* w256, const hipt_vit_
            al256((size_t)nseq * w256->dim * 4);
 }
 
-int hipt_hipt4k_forward(const hipt_vit_weights* w256, const hipt_vit_weights* w4k, const float* regions, int nreg, int W, int H,
-                        int chunk, float* cls256_out, float* out, void* workspace, size_t ws_bytes, void* stream) {
+static int hipt4k_forward_impl(const hipt_vit_weights* w256, const hipt_vit_weights* w4k, const void* regions, int kind, int nreg, int W,
+                               int H, int chunk, float* cls256_out, float* out, void* workspace, size_t ws_bytes, void* stream) {
     HIPT_CHECK_ARG(w256 && w4k && regions && out && nreg > 0, "hipt4k_forward: null/empty argument");
     HIPT_CHECK_ARG(W > 0 && H > 0 && W % 256 == 0 && H % 256 == 0, "hipt4k_forward: region %dx%d must be cropped to multiples of 256",
                    W, H);
@@ -460,7 +481,7 @@ int hipt_hipt4k_forward(const hipt_vit_weights* w256, const hipt_vit_weights* w4
     HIPT_CHECK_ARG(w4k->ntok == per + 1, "hipt4k_forward: ViT-4K weights prepared for %d tokens, region has %d", w4k->ntok, per + 1);
     HIPT_CHECK_ARG(w4k->embed_k == w256->dim, "hipt4k_forward: ViT-4K input width %d != ViT-256 width %d", w4k->embed_k, w256->dim);
     const hipt_image_layout lay = region_layout(W, H);
-    const size_t n256 = hipt_vit256_forward_workspace_bytes(w256, &lay, nseq, chunk);
+    const size_t n256 = hipt_vit256_forward_workspace_bytes(w256, &lay, nseq, chunk) + image_extra_bytes(w256, &lay, nseq, kind);
     const size_t n4k = hipt_vit4k_forward_workspace_bytes(w4k, nreg);
     const size_t ncls = al256((size_t)nseq * w256->dim * 4);
     if (ws_bytes < n256 + n4k + ncls || ((uintptr_t)workspace & 255)) {
@@ -470,9 +491,30 @@ int hipt_hipt4k_forward(const hipt_vit_weights* w256, const hipt_vit_weights* w4
     char* ws = (char*)workspace;
     // cls256 [nreg * per, 384] token-major = nreg sequences of `per` tokens: exactly phi's input (hipt_4k.py:72-74)
     float* cls = cls256_out ? cls256_out : (float*)ws;
-    int rc = hipt_vit256_forward(w256, regions, &lay, nseq, chunk, cls, ws + ncls, n256, stream);
+    int rc = vit256_forward_impl(w256, regions, kind, &lay, nseq, chunk, cls, ws + ncls, n256, stream);
     if (rc) return rc;
     return hipt_vit4k_forward(w4k, cls, nreg, out, ws + ncls + n256, n4k, stream);
+}
+
+int hipt_hipt4k_forward(const hipt_vit_weights* w256, const hipt_vit_weights* w4k, const float* regions, int nreg, int W, int H,
+                        int chunk, float* cls256_out, float* out, void* workspace, size_t ws_bytes, void* stream) {
+    return hipt4k_forward_impl(w256, w4k, regions, IMG_F32, nreg, W, H, chunk, cls256_out, out, workspace, ws_bytes, stream);
+}
+
+size_t hipt_hipt4k_u8_workspace_bytes(const hipt_vit_weights* w256, const hipt_vit_weights* w4k, int nreg, int w_256, int h_256, int chunk) {
+    if (!w256 || !w4k || nreg <= 0 || w_256 <= 0 || h_256 <= 0) return 0;
+    const hipt_image_layout lay = region_layout(w_256 * 256, h_256 * 256);
+    return hipt_hipt4k_workspace_bytes(w256, w4k, nreg, w_256, h_256, chunk) + image_extra_bytes(w256, &lay, nreg * w_256 * h_256, IMG_U8_CHW);
+}
+
+int hipt_hipt4k_forward_u8(const hipt_vit_weights* w256, const hipt_vit_weights* w4k, const uint8_t* regions, int interleaved, int nreg,
+                           int W, int H, int chunk, float* cls256_out, float* out, void* workspace, size_t ws_bytes, void* stream) {
+    return hipt4k_forward_impl(w256, w4k, regions, interleaved ? IMG_U8_HWC : IMG_U8_CHW, nreg, W, H, chunk, cls256_out, out, workspace,
+                               ws_bytes, stream);
+}
+
+int hipt_u8_normalize(const void* src, int interleaved, int64_t n_images, int64_t plane, void* dst, int dst_dtype, void* stream) {
+    return hipt_u8_normalize_launch(src, interleaved, n_images, plane, dst, dst_dtype, S(stream));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -88,6 +88,8 @@ int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int hea
 int hipt_cls_init_launch(float* x, const float* cls, const float* pos, int nseq, int ntok, int D, hipStream_t st);
 // out[i] = src[i] (+ (float)y[i] if y)  (fp32, bf16 branch, n % 8 == 0): lands the residual stream in the caller's buffer
 int hipt_add_bf16_launch(float* out, const float* src, const void* y, int64_t n, hipStream_t st);
+// uint8 image -> normalised compute-dtype image [n, 3, plane] (ToTensor + Normalize(0.5, 0.5)); hwc: src is [n, plane, 3]
+int hipt_u8_normalize_launch(const void* src, int hwc, int64_t nimg, int64_t plane, void* dst, int dst_dtype, hipStream_t st);
 // fp32 -> bf16 elementwise (n % 8 == 0)
 int hipt_f32_to_bf16_launch(const float* in, void* out, int64_t n, hipStream_t st);
 

@@ -86,6 +86,55 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restr
     }
 }
 
+// ToTensor + Normalize(mean 0.5, std 0.5) (hipt_model_utils.py:113-118): (x / 255 - 0.5) / 0.5 in fp32, exactly the
+// torchvision arithmetic (true division, then subtract, then divide).  16 pixels of one channel per thread.
+// HWC = 0: src [n, 3, plane] ; HWC = 1: src [n, plane, 3] (interleaved RGB) -> dst [n, 3, plane].
+template <typename TO> __device__ __forceinline__ void store16(TO* dst, const float (&v)[16]);
+template <> __device__ __forceinline__ void store16<float>(float* dst, const float (&v)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+template <> __device__ __forceinline__ void store16<bf16_t>(bf16_t* dst, const float (&v)[16]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[8 * q + 2 * e], v[8 * q + 2 * e + 1]);
+        *(u32x4*)(dst + 8 * q) = o;
+    }
+}
+__device__ __forceinline__ float u8_norm(uint32_t b) { return ((float)b / 255.0f - 0.5f) / 0.5f; }
+
+template <typename TO, int HWC>
+__global__ void u8_norm_kernel(const uint8_t* __restrict__ src, TO* __restrict__ dst, int64_t nimg, int64_t plane) {
+    const int64_t p16 = plane / 16;  // groups of 16 pixels per plane
+    const int64_t total = nimg * p16 * (HWC ? 1 : 3);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if constexpr (HWC == 0) {
+            const u32x4 raw = *(const u32x4*)(src + i * 16);
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = u8_norm((raw[e >> 2] >> (8 * (e & 3))) & 0xffu);
+            store16<TO>(dst + i * 16, v);
+        } else {
+            const int64_t img = i / p16, g16 = i % p16;
+            const uint8_t* sp = src + (img * plane + g16 * 16) * 3;
+            const u32x4 r0 = *(const u32x4*)sp, r1 = *(const u32x4*)(sp + 16), r2 = *(const u32x4*)(sp + 32);
+            const uint32_t w[12] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3], r2[0], r2[1], r2[2], r2[3]};
+            float v[3][16];
+#pragma unroll
+            for (int px = 0; px < 16; ++px)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int byte = 3 * px + c;
+                    v[c][px] = u8_norm((w[byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+                }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) store16<TO>(dst + (img * 3 + c) * plane + g16 * 16, v[c]);
+        }
+    }
+}
+
 __global__ void add_bf16_kernel(float* __restrict__ out, const float* __restrict__ src, const bf16_t* __restrict__ y, int64_t n8) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         f32x4 a = *(const f32x4*)(src + i * 8), c = *(const f32x4*)(src + i * 8 + 4);
@@ -141,6 +190,27 @@ int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, cons
 int hipt_cls_init_launch(float* x, const float* cls, const float* pos, int nseq, int ntok, int D, hipStream_t st) {
     const int n = nseq * D;
     hipLaunchKernelGGL(cls_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, cls, pos, nseq, ntok, D);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}
+
+int hipt_u8_normalize_launch(const void* src, int hwc, int64_t nimg, int64_t plane, void* dst, int dst_dtype, hipStream_t st) {
+    HIPT_CHECK_ARG(src && dst && nimg > 0 && plane > 0 && plane % 16 == 0, "u8_normalize: empty input or W*H %% 16 != 0");
+    HIPT_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "u8_normalize: 16-byte alignment required");
+    const int64_t total = nimg * (plane / 16) * (hwc ? 1 : 3);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const dim3 grid((unsigned)blocks), block(256);
+    const uint8_t* s8 = (const uint8_t*)src;
+    if (dst_dtype == HIPT_F32) {
+        if (hwc) hipLaunchKernelGGL((u8_norm_kernel<float, 1>), grid, block, 0, st, s8, (float*)dst, nimg, plane);
+        else hipLaunchKernelGGL((u8_norm_kernel<float, 0>), grid, block, 0, st, s8, (float*)dst, nimg, plane);
+    } else if (dst_dtype == HIPT_BF16) {
+        if (hwc) hipLaunchKernelGGL((u8_norm_kernel<bf16_t, 1>), grid, block, 0, st, s8, (bf16_t*)dst, nimg, plane);
+        else hipLaunchKernelGGL((u8_norm_kernel<bf16_t, 0>), grid, block, 0, st, s8, (bf16_t*)dst, nimg, plane);
+    } else {
+        HIPT_CHECK_ARG(false, "u8_normalize: bad dst dtype %d", dst_dtype);
+    }
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }

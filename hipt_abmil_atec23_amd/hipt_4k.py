@@ -42,12 +42,19 @@ class HIPT_4K(torch.nn.Module):
 
     # ---- hipt_4k.py:308-330 -------------------------------------------------------------
     def prepare_img_tensor(self, img: torch.Tensor, patch_size=256):
-        b, c, w, h = img.shape
+        if self._interleaved(img):  # uint8 [R, W, H, 3] (decoded RGB tiles): same crop on the two middle axes
+            b, w, h, c = img.shape
+        else:
+            b, c, w, h = img.shape
         W, H = w - w % patch_size, h - h % patch_size
         if (W, H) != (w, h):
             t, l = center_crop_box(w, W), center_crop_box(h, H)
-            img = img[:, :, t:t + W, l:l + H]
+            img = img[:, t:t + W, l:l + H, :] if self._interleaved(img) else img[:, :, t:t + W, l:l + H]
         return img, w // patch_size, h // patch_size
+
+    @staticmethod
+    def _interleaved(img: torch.Tensor) -> bool:
+        return img.dtype == torch.uint8 and img.dim() == 4 and img.shape[-1] == 3 and img.shape[1] != 3
 
     def _same_device(self) -> bool:
         d256 = next(self.model256.parameters()).device
@@ -61,11 +68,30 @@ class HIPT_4K(torch.nn.Module):
         nreg = batch.shape[0]  # the reference takes 1 (hipt_4k.py:73); R > 1 regions are independent -> stacked
         d256 = next(self.model256.parameters()).device
         d4k = next(self.model4k.parameters()).device
-        region = batch.to(d256, non_blocking=True).detach().float().contiguous()
+        u8 = batch.dtype == torch.uint8  # raw RGB bytes: ToTensor + Normalize(0.5, 0.5) happen on the device
+        hwc = self._interleaved(batch)
+        region = batch.to(d256, non_blocking=True).detach()
+        region = region.contiguous() if u8 else region.float().contiguous()
         N.require_cuda(region, "HIPT_4K")
         per = w_256 * h_256
         nseq = nreg * per
-        W, H = region.shape[2], region.shape[3]
+        W, H = (region.shape[1], region.shape[2]) if hwc else (region.shape[2], region.shape[3])
+        if u8 and d256 != d4k:  # two-device placement: normalise here, then the float path below
+            m256 = self.model256
+            buf = torch.empty((nreg, 3, W, H), dtype=torch.float32, device=d256)
+            N.call("hipt_u8_normalize", N.ptr(region), int(hwc), nreg, W * H, N.ptr(buf), N.HIPT_F32, N.stream_ptr(d256))
+            region, u8 = buf, False
+        if d256 == d4k and u8:
+            m256, m4k = self.model256, self.model4k
+            pk256 = m256._packed_for(m256._pos_for(256, 256, 256))
+            pk4k = m4k._packed_for(m4k._pos_for(per, w_256, h_256))
+            out = torch.empty((nreg, pk4k.w.dim), dtype=torch.float32, device=d4k)
+            cls256 = torch.empty((nseq, pk256.w.dim), dtype=torch.float32, device=d256) if want_cls256 else None
+            need = N.lib().hipt_hipt4k_u8_workspace_bytes(pk256.ref, pk4k.ref, nreg, w_256, h_256, self.chunk)
+            ws = Fn.workspace(d256, need)
+            N.call("hipt_hipt4k_forward_u8", pk256.ref, pk4k.ref, N.ptr(region), int(hwc), nreg, W, H, self.chunk, N.ptr(cls256),
+                   N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(d256))
+            return out, cls256
         if d256 == d4k:
             m256, m4k = self.model256, self.model4k
             pk256 = m256._packed_for(m256._pos_for(256, 256, 256))
@@ -84,7 +110,9 @@ class HIPT_4K(torch.nn.Module):
         return self.model4k.forward_tokens(tokens, w_256, h_256), cls256
 
     def forward(self, x):
-        """[R,3,W',H'] -> [R,192] ViT-4K [CLS] features (hipt_4k.py:48-76; the reference takes R = 1)."""
+        """[R,3,W',H'] float -> [R,192] ViT-4K [CLS] features (hipt_4k.py:48-76; the reference takes R = 1).
+        uint8 input ([R,3,W',H'] or interleaved [R,W',H',3]) is raw RGB: eval_transforms (ToTensor + Normalize(0.5, 0.5),
+        hipt_model_utils.py:113-118) is applied on the device."""
         return self._run(x, want_cls256=False)[0]
 
     def forward_asset_dict(self, x: torch.Tensor):

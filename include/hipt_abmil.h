@@ -185,6 +185,23 @@ int hipt_hipt4k_forward(const hipt_vit_weights* w256, const hipt_vit_weights* w4
                         const float* regions, int nreg, int W, int H, int chunk, float* cls256_out, float* out,
                         void* workspace, size_t ws_bytes, void* stream);
 
+/* uint8 input (replaces eval_transforms = ToTensor + Normalize(0.5, 0.5),
+ * HIPT_4K/hipt_model_utils.py:113-118, and the float H2D copy of extract_features_fp.py:166): regions are
+ * uint8 [nreg, 3, W, H] (interleaved = 0) or [nreg, W, H, 3] (interleaved = 1, the layout of a decoded RGB
+ * tile); they are normalised on device, (x / 255 - 0.5) / 0.5 in fp32 exactly as torchvision, into the compute
+ * dtype.  Same outputs as hipt_hipt4k_forward on the normalised float tensor, bit for bit.
+ * workspace >= hipt_hipt4k_u8_workspace_bytes(). */
+size_t hipt_hipt4k_u8_workspace_bytes(const hipt_vit_weights* w256, const hipt_vit_weights* w4k,
+                                      int nreg, int w_256, int h_256, int chunk);
+int hipt_hipt4k_forward_u8(const hipt_vit_weights* w256, const hipt_vit_weights* w4k,
+                           const uint8_t* regions, int interleaved, int nreg, int W, int H, int chunk,
+                           float* cls256_out, float* out, void* workspace, size_t ws_bytes, void* stream);
+
+/* The normalisation alone: src uint8 [n_images, 3, plane] or [n_images, plane, 3] -> dst [n_images, 3, plane]
+ * in dst_dtype (HIPT_F32 / HIPT_BF16); plane = W*H must be a multiple of 16. */
+int hipt_u8_normalize(const void* src, int interleaved, int64_t n_images, int64_t plane, void* dst,
+                      int dst_dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * CLAM_SB / ABMIL gated-attention pooling (models/model_clam.py:41-64, 77-191)
  * ---------------------------------------------------------------------------------- */

@@ -295,6 +295,33 @@ def test_hipt4k_region_batch_equals_single_regions(hipt):
         hipt.forward_asset_dict(x)
 
 
+def test_hipt4k_uint8_input_equals_normalised_float(hipt):
+    """uint8 RGB regions (planar and interleaved) normalised on the device give the bits of the float path fed with
+    torch's own ToTensor + Normalize(0.5, 0.5) arithmetic (hipt_model_utils.py:113-118)."""
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (2, 512, 768, 3), dtype=torch.uint8, generator=g)  # two decoded [W, H, RGB] tiles
+    planar = u8.permute(0, 3, 1, 2).contiguous()
+    ref_in = planar.float().div(255).sub(0.5).div(0.5)  # ToTensor then Normalize(mean 0.5, std 0.5)
+    for dt in ("fp32", "bf16"):
+        hipt.set_compute_dtype(dt)
+        try:
+            ref = hipt(ref_in.to(DEV))
+            a = hipt(planar.to(DEV))
+            b = hipt(u8.to(DEV))
+        finally:
+            hipt.set_compute_dtype("fp32")
+        assert torch.equal(a, ref) and torch.equal(b, ref), dt
+    # the normalisation alone, against torch on the CPU, bit for bit
+    out = torch.empty((2, 3, 512, 768), dtype=torch.float32, device=DEV)
+    src = u8.to(DEV)
+    N.call("hipt_u8_normalize", N.ptr(src), 1, 2, 512 * 768, N.ptr(out), N.HIPT_F32, N.stream_ptr(torch.device(DEV)))
+    assert torch.equal(out.cpu(), ref_in)
+    # crop of a non-multiple-of-256 interleaved tile
+    odd = torch.randint(0, 256, (1, 600, 300, 3), dtype=torch.uint8, generator=g)
+    img, w, h = hipt.prepare_img_tensor(odd)
+    assert img.shape == (1, 512, 256, 3) and (w, h) == (2, 1) and torch.equal(img, odd[:, 44:556, 22:278, :])
+
+
 def test_hipt4k_full_region_fp32_and_bf16(hipt):
     """BASELINE config 3 shape: one 4096x4096 region = 256 patches -> ViT-4K over the 16x16 grid."""
     g = golden("hipt4k_4096")
