@@ -41,6 +41,14 @@ __device__ __forceinline__ float sigm(float x) {  // 1 / (1 + 2^(-x log2 e)); sa
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -LOG2E));
 }
 
+// 16 bytes at an 8-byte-aligned offset through a buffer resource, sc1 (bypasses the L1: see the fused combine)
+__device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, int off) {
+    const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 16), hi = __builtin_amdgcn_raw_buffer_load_b64(r, off + 8, 0, 16);
+    // (bit-cast the whole vectors: __builtin_bit_cast on a vector-element lvalue reads element 0, common.h)
+    const f32x2 l = __builtin_bit_cast(f32x2, lo), h = __builtin_bit_cast(f32x2, hi);
+    return f32x4{l[0], l[1], h[0], h[1]};
+}
+
 #define DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 #define DSR64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 #define LGKM(n)                                             \
@@ -53,12 +61,19 @@ __global__ __launch_bounds__(256, 1) void abmil_stream_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ wab, const float* __restrict__ bab,
                                                               const float* __restrict__ wc, const float* __restrict__ bc,
                                                               float* __restrict__ A_raw, float* __restrict__ partials,
-                                                              int attention_only, unsigned long long* stamps) {
+                                                              int attention_only, unsigned long long* stamps,
+                                                              unsigned* __restrict__ ticket, const float* __restrict__ wcls,
+                                                              const float* __restrict__ bcls, int C, float* __restrict__ M,
+                                                              float* __restrict__ logits, float* __restrict__ Y_prob,
+                                                              int64_t* __restrict__ Y_hat) {
 #define ASTAMP(k)                                                                                          \
     do {                                                                                                   \
         if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
     ASTAMP(0);
+    // finish ticket of the fused combine: workgroup 0 (dispatched first) clears it with its first instruction; every
+    // workgroup adds to it only when its rows are done, tens of microseconds later (a stream memset costs ~10 us)
+    if (ticket && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr int S0 = KS * 64;
     constexpr int NC = KS * 2;  // 16-byte chunks per lane per row
     extern __shared__ __attribute__((aligned(16))) char smem[];  // W1 image (KS slabs) | [Wa;Wb] image (2 slabs)
@@ -66,6 +81,28 @@ __global__ __launch_bounds__(256, 1) void abmil_stream_kernel(const bf16_t* __re
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
+
+    // ---- my rows ----
+    const int gw = blockIdx.x * 4 + wave;
+    const int rbeg = gw * rows_per_wave;
+    int rend = rbeg + rows_per_wave;
+    rend = rend < N ? rend : N;
+    const int nstep = rend > rbeg ? (rend - rbeg + 31) / 32 : 0;
+
+    auto load_rows = [&](u32x4 (&xf)[2][NC], int s) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            int r = rbeg + s * 32 + m * 16 + li;
+            r = r < rend ? r : rend - 1;
+            const bf16_t* xr = bag + (int64_t)r * S0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) xf[m][c] = *(const u32x4*)(xr + (g + 4 * c) * 8);
+        }
+    };
+
+    // the first rows are requested BEFORE the weights: both latencies overlap (the loads were 5.7 us of a 36 us kernel)
+    u32x4 xa[2][NC], xb[2][NC];
+    if (nstep > 0) load_rows(xa, 0);
 
     // ---- stage the weights (LDS-DMA, swizzle on the source address) ----
     {
@@ -96,13 +133,6 @@ __global__ __launch_bounds__(256, 1) void abmil_stream_kernel(const bf16_t* __re
     __syncthreads();  // weights are in LDS; from here on the waves never synchronise again
     ASTAMP(1);
 
-    // ---- my rows ----
-    const int gw = blockIdx.x * 4 + wave;
-    const int rbeg = gw * rows_per_wave;
-    int rend = rbeg + rows_per_wave;
-    rend = rend < N ? rend : N;
-    const int nstep = rend > rbeg ? (rend - rbeg + 31) / 32 : 0;
-
     const uint32_t lbase = lds_addr(smem);
     uint32_t foff[2], fhi[2], f2off[2][2];  // ds_read immediates are 16-bit: slabs 3.. use a second base
 #pragma unroll
@@ -122,17 +152,6 @@ __global__ __launch_bounds__(256, 1) void abmil_stream_kernel(const bf16_t* __re
     f32x4 pool[8];
 #pragma unroll
     for (int nf = 0; nf < 8; ++nf) pool[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto load_rows = [&](u32x4 (&xf)[2][NC], int s) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            int r = rbeg + s * 32 + m * 16 + li;
-            r = r < rend ? r : rend - 1;
-            const bf16_t* xr = bag + (int64_t)r * S0;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) xf[m][c] = *(const u32x4*)(xr + (g + 4 * c) * 8);
-        }
-    };
 
     auto compute = [&](u32x4 (&xf)[2][NC], int s) {
         // ================= phase 1: acc1[m][nf] = x W1^T  (lane: row li of fragment m, hidden 16nf + 4g + e) =================
@@ -271,8 +290,6 @@ __global__ __launch_bounds__(256, 1) void abmil_stream_kernel(const bf16_t* __re
     };
 
     // ---- double-buffered stream over my rows ----
-    u32x4 xa[2][NC], xb[2][NC];
-    if (nstep > 0) load_rows(xa, 0);
     for (int s = 0; s < nstep; s += 2) {
         if (s + 1 < nstep) load_rows(xb, s + 1);
         if (s == 0) ASTAMP(2);
@@ -316,14 +333,96 @@ __global__ __launch_bounds__(256, 1) void abmil_stream_kernel(const bf16_t* __re
             const float m0 = red[0], m1 = red[132], m2 = red[264], m3 = red[396];
             const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
             float* pw = partials + (int64_t)blockIdx.x * (2 + S1);
+            // (agent-scope relaxed stores = global_store sc0 sc1: they leave the XCD's L2, so the merging workgroup can
+            //  read them with sc1 loads and no fence -- a device-scope release would write back the whole L2, 12 us here)
             if (tid == 0) {
-                pw[0] = mm;
+                __hip_atomic_store(&pw[0], mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 const float f0 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m0 - mm) * LOG2E);
                 const float f1 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m1 - mm) * LOG2E);
                 const float f2 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m2 - mm) * LOG2E);
                 const float f3 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m3 - mm) * LOG2E);
-                pw[tid] = red[tid] * f0 + red[132 + tid] * f1 + red[264 + tid] * f2 + red[396 + tid] * f3;
+                __hip_atomic_store(&pw[tid], red[tid] * f0 + red[132 + tid] * f1 + red[264 + tid] * f2 + red[396 + tid] * f3, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- fused combine (model_clam.py:180-183): the workgroup whose ticket is the last one merges all partials,
+        //      applies the bag classifier, softmax and argmax -- no second launch.  Hand-off without fences
+        //      (MI355X_MICROARCH.md, hand-off table row 1): sc1 stores, every storing wave waits vmcnt(0), workgroup
+        //      barrier, ONE agent-scope atomic per workgroup; the workgroup whose
+        //      add came last reads with sc1 loads after a workgroup barrier.
+        if (ticket) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = (int*)(red + 600);
+            if (tid == 0) *flag = atomicAdd(ticket, 1u) == gridDim.x - 1;
+            __syncthreads();
+            if (*flag) {
+                const int G = gridDim.x, stride = 2 + S1;
+                float* Fs = red + 640;    // [256] rescale factors
+                float* Cs = red + 1024;   // [8][128] column partial sums
+                float* Ms = red + 2048;   // [128]
+                float* Ls = red + 2176;   // [C <= 64]
+                float* wr = red + 2240;   // [4] wave reductions
+                // every load of the partials is an sc1 load (buffer loads with the sc1 cache-policy bit)
+                const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)partials, 0, G * stride * 4, 0x00020000);
+                constexpr int SC1 = 16;
+                f32x2 ml = {-INFINITY, 0.f};  // (max, sum)
+                if (tid < G) {
+                    ml[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, tid * stride * 4, 0, SC1));
+                    ml[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, tid * stride * 4 + 4, 0, SC1));
+                }
+                float mx = wave_max(ml[0]);
+                if (lane == 0) wr[wave] = mx;
+                __syncthreads();
+                mx = fmaxf(fmaxf(wr[0], wr[1]), fmaxf(wr[2], wr[3]));
+                __syncthreads();
+                const float f = tid < G ? expf(ml[0] - mx) : 0.f;
+                Fs[tid] = f;
+                float ls = wave_sum(ml[1] * f);
+                if (lane == 0) wr[wave] = ls;
+                __syncthreads();
+                const float L = wr[0] + wr[1] + wr[2] + wr[3];
+                {   // column sums: 32 threads x 16 B cover one partial row, 8 rows per pass, 8 passes in flight
+                    const int c4 = tid & 31, part = tid >> 5;
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+                    for (int gi = part; gi < G; gi += 8)  // (rows are 520 B apart: 8-byte aligned -> two 8-byte loads)
+                        a += f32x4{0.f, 0.f, 0.f, 0.f} + ld4(prs, (gi * stride + 2 + 4 * c4) * 4) * Fs[gi];
+                    *(f32x4*)(Cs + part * S1 + 4 * c4) = a;
+                }
+                __syncthreads();
+                if (tid < S1) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int part = 0; part < 8; ++part) a += Cs[part * S1 + tid];
+                    a /= L;
+                    Ms[tid] = a;
+                    M[tid] = a;
+                }
+                __syncthreads();
+                for (int k = wave; k < C; k += 4) {
+                    float a = Ms[lane] * wcls[(int64_t)k * S1 + lane] + Ms[lane + 64] * wcls[(int64_t)k * S1 + lane + 64];
+                    a = wave_sum(a);
+                    if (lane == 0) Ls[k] = a + bcls[k];
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    float lm = -INFINITY;
+                    int arg = 0;
+                    for (int k = 0; k < C; ++k)
+                        if (Ls[k] > lm) {
+                            lm = Ls[k];
+                            arg = k;
+                        }
+                    float se = 0.f;
+                    for (int k = 0; k < C; ++k) se += expf(Ls[k] - lm);
+                    for (int k = 0; k < C; ++k) {
+                        logits[k] = Ls[k];
+                        Y_prob[k] = expf(Ls[k] - lm) / se;
+                    }
+                    Y_hat[0] = arg;
+                }
             }
         }
     }
@@ -332,7 +431,7 @@ __global__ __launch_bounds__(256, 1) void abmil_stream_kernel(const bf16_t* __re
 
 template <int KS>
 int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, float* partials,
-           int* n_partials, hipStream_t st) {
+           int* n_partials, unsigned* ticket, float* M, float* logits, float* Y_prob, int64_t* Y_hat, hipStream_t st) {
     constexpr int lds = (KS + 2) * SLAB + (S1 + 3 * S2) * 4;
     auto k = abmil_stream_kernel<KS>;
     static bool attr = false;
@@ -351,8 +450,10 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
     static const bool want_stamps = getenv("HIPT_ABMIL_STAMPS") != nullptr;
     static unsigned long long* dbuf = nullptr;
     if (want_stamps && !dbuf) (void)hipMalloc(&dbuf, 512 * 8 * sizeof(unsigned long long));
+    const bool fuse = !attention_only && ticket && M && w->n_classes <= 64 && grid <= 256;
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (const bf16_t*)bag, N, rows, (const bf16_t*)w->w1, w->b1,
-                       (const bf16_t*)w->wab, w->bab, w->wc, w->bc, A_raw, partials, attention_only, want_stamps ? dbuf : nullptr);
+                       (const bf16_t*)w->wab, w->bab, w->wc, w->bc, A_raw, partials, attention_only, want_stamps ? dbuf : nullptr,
+                       fuse ? ticket : nullptr, w->wcls, w->bcls, w->n_classes, M, logits, Y_prob, Y_hat);
     HIPT_CHECK_LAUNCH();
     if (want_stamps && grid <= 512) {
         static unsigned long long h[512 * 8];
@@ -372,7 +473,7 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
         fprintf(stderr, "[abmil stream N=%d grid=%d rows/wave=%d] total %.1f us | start<=%.1f; weights->LDS %.1f; issue loads %.1f; step0 %.1f; step1 %.1f; steps2+ %.1f; final %.1f\n",
                 N, grid, rows, (double)(t6 - t0) * 0.01, smax, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
     }
-    *n_partials = grid;
+    *n_partials = fuse ? 0 : grid;  // 0: the kernel has already produced M / logits / Y_prob / Y_hat
     return HIPT_OK;
 }
 
@@ -384,9 +485,10 @@ bool hipt_clam_stream_supported(const hipt_clam_weights* w) {
 }
 
 int hipt_clam_stream_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw,
-                            float* partials, int* n_partials, hipStream_t st) {
-    if (w->s0 == 384) return launch<6>(w, bag, N, attention_only, A_raw, partials, n_partials, st);
-    if (w->s0 == 192) return launch<3>(w, bag, N, attention_only, A_raw, partials, n_partials, st);
+                            float* partials, int* n_partials, unsigned* ticket, float* M, float* logits, float* Y_prob,
+                            int64_t* Y_hat, hipStream_t st) {
+    if (w->s0 == 384) return launch<6>(w, bag, N, attention_only, A_raw, partials, n_partials, ticket, M, logits, Y_prob, Y_hat, st);
+    if (w->s0 == 192) return launch<3>(w, bag, N, attention_only, A_raw, partials, n_partials, ticket, M, logits, Y_prob, Y_hat, st);
     hipt_set_error("clam stream: unsupported S0=%d", w->s0);
     return HIPT_E_UNSUPPORTED;
 }

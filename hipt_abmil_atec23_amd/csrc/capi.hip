@@ -579,7 +579,9 @@ int hipt_clam_sb_forward(const hipt_clam_weights* w, const void* bag, int N, int
     float* gmax = (float*)c.take(256);
     int G = 0;
     if (hipt_clam_stream_supported(w)) {  // bf16 [S0,128,64]: weight-stationary streaming kernel
-        PROF(PC_ABMIL, hipt_clam_stream_launch(w, bag, N, attention_only, A_raw, partials, &G, st));
+        // (the gmax slot is unused on this path: it holds the finish ticket of the fused combine)
+        PROF(PC_ABMIL, hipt_clam_stream_launch(w, bag, N, attention_only, A_raw, partials, &G, (unsigned*)gmax, M, logits, Y_prob, Y_hat, st));
+        if (!attention_only && G == 0) return HIPT_OK;
     } else if (hipt_clam_fused_supported(w)) {
         PROF(PC_ABMIL, hipt_clam_fused_launch(w, bag, N, attention_only, A_raw, partials, &G, st));
     } else {
