@@ -38,7 +38,11 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROA
 PEAK_HBM_GBS = 8000.0
 BAG_N, BAG_S0 = 100_000, 384
 REGION = 4096
-FLOP_PER_REGION = 3_146_029_797_888
+# 3 146 029 797 888 FLOP per region when every block runs on all 257 tokens.  The build runs the LAST
+# ViT-256 block for the [CLS] query only (nothing else of it is consumed, vision_transformer.py:253); §8d requires the
+# pruned figure then: per patch, block 12 keeps QKV (K and V of all tokens) and does QK^T / PV / proj / MLP for 1 of 257 rows.
+_BLOCK_TAIL = 50_725_632 + 50_725_632 + 75_792_384 + 606_339_072          # QK^T + PV + proj + MLP of one patch, one block
+FLOP_PER_REGION = 3_146_029_797_888 - 256 * (_BLOCK_TAIL - _BLOCK_TAIL // 257)
 
 
 def build_models(dev, dtype):
@@ -59,6 +63,15 @@ def kernel_flops(cat, rows, D=384, H=1536, heads=6, ntok=257):
     return {"qkv_gemm": 2 * rows * 3 * D * D, "proj_gemm": 2 * rows * D * D,
             "fc1_gemm": 2 * rows * D * H, "fc2_gemm": 2 * rows * D * H, "mlp_fused": 4 * rows * D * H,
             "attention": 4 * (rows // ntok) * heads * ntok * ntok * dh}.get(cat)
+
+
+def step_flops(cat, rows, passes, ntok=257):
+    """Algorithmic FLOPs of a category over one step: `passes` chunks of `rows` token rows through 12 blocks, the last
+    block pruned to the [CLS] row for everything after QKV (1 of ntok rows; attention: 1 of ntok queries)."""
+    full = kernel_flops(cat, rows)
+    if full is None:
+        return None
+    return passes * (12 * full if cat == "qkv_gemm" else 11 * full + full // ntok)
 
 
 # rocprofv3 kernel names of the categories (profiles/<tag>_traffic.json keys)
@@ -231,7 +244,7 @@ def main():
         prof = N.profile_read()
         N.profile_enable(False)
     chunk_rows = (args.chunk or 256 * R) * 257
-    n256 = 12 * ((256 * R) // (args.chunk or 256 * R))  # ViT-256 launches per step and category
+    passes = (256 * R) // (args.chunk or 256 * R)  # ViT-256 passes (chunks of patches) per step
     kernels = {}
     for cat, (ms, cnt) in prof.items():
         kernels[cat] = {"launches_per_step": cnt / args.profile_steps, "total_ms": ms, "avg_us": ms / cnt * 1e3,
@@ -239,16 +252,17 @@ def main():
     out["kernels"] = kernels
     mf = {c: v for c, v in kernels.items() if kernel_flops(c, chunk_rows)}
     if mf:
-        # dominant kernel = largest share of the step.  Each category holds the 12 ViT-256 launches of a step
-        # (R x 65 792 rows each): achieved = their algorithmic FLOPs / their HIP-event time.
+        # dominant kernel = largest share of the step.  Each category holds the 12 ViT-256 launches of a step (11 over
+        # R x 65 792 rows, the last block's over the R x 256 [CLS] rows): achieved = their algorithmic FLOPs / their
+        # HIP-event time; avg_launch_us is the average over the 12.
         dom = max(mf, key=lambda c: mf[c]["ms_per_step"])
-        fl_step = n256 * kernel_flops(dom, chunk_rows)  # (the ViT-4K launches are booked under 'vit4k_blocks')
+        fl_step = step_flops(dom, chunk_rows, passes)  # (the ViT-4K launches are booked under 'vit4k_blocks')
         ach = fl_step / (mf[dom]["ms_per_step"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                            "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": pmc_traffic(dom),
                            "flops_per_step": fl_step, "launches_per_step": mf[dom]["launches_per_step"],
                            "avg_launch_us": mf[dom]["avg_us"]}
-        out["roofline_all"] = {c: round((n256 * kernel_flops(c, chunk_rows)) /
+        out["roofline_all"] = {c: round(step_flops(c, chunk_rows, passes) /
                                         (v["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4) for c, v in mf.items()}
     if "abmil_fused" in kernels:
         esz = 2 if args.dtype == "bf16" else 4

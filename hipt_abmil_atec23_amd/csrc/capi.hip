@@ -175,6 +175,40 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     return HIPT_OK;
 }
 
+// Last block when only the [CLS] row is consumed afterwards (ViT.forward returns norm(x)[:, 0], vision_transformer.py:248-253):
+// K and V are needed for every token, everything after that only for token 0 of each sequence -- the attention of one
+// query per (sequence, head), then proj / residual / MLP on nseq rows instead of nseq * ntok (allowed, and
+// the pruned FLOP figure is the one the roofline uses).  Leaves the final residual rows compact in xc [nseq, D].
+static bool can_prune_last(const hipt_vit_weights* w) {
+    return w->dtype == HIPT_BF16 && w->dim == 384 && w->dim / w->heads == 64 && w->ntok <= 320 && hipt_seqgemm_supported(w->dtype, w->dim) &&
+           hipt_mlp_supported(w->dtype, w->dim, w->hidden) && getenv("HIPT_NO_SEQGEMM") == nullptr && getenv("HIPT_NO_PRUNE") == nullptr;
+}
+
+static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, const BlockScratch& s, float* xc, hipStream_t st) {
+    const int D = w->dim, M = nseq * w->ntok;
+    const hipt_block_weights& b = w->blocks[w->depth - 1];
+    int rc;
+    SeqGemmParams q;
+    memset(&q, 0, sizeof(q));
+    q.M = M; q.K = D; q.ln_eps = w->ln_eps;
+    q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.N = 3 * D; q.bias = b.qkv_b;
+    q.out = s.qkv; q.ldc = 3 * D;
+    q.counter = (int*)s.hid + 16;
+    PROF(PC_QKV, hipt_seqgemm_launch(q, true, 0, st));
+    PROF(PC_ATTN, hipt_attn_cls_launch(s.qkv, s.att, nseq, w->ntok, w->heads, D / w->heads, 1.0f / sqrtf((float)(D / w->heads)), st));
+    PROF(PC_OTHER, hipt_gather_cls_launch(x, xc, nseq, (int64_t)w->ntok * D, D, st));
+    q.M = nseq; q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
+    q.counter = (int*)s.hid + 32;
+    PROF(PC_PROJ, hipt_seqgemm_launch(q, false, 0, st));
+    MlpParams m;
+    memset(&m, 0, sizeof(m));
+    m.x = xc; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
+    m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.M = nseq; m.D = D; m.hidden = w->hidden;
+    m.counter = (int*)s.hid;
+    PROF(PC_MLP, hipt_mlp_launch(m, st));
+    return HIPT_OK;
+}
+
 int64_t image_elems(const hipt_image_layout* lay, int nseq_total) {
     const int per = lay->grid_w * lay->grid_h;
     return (int64_t)((nseq_total + per - 1) / per) * lay->batch_stride;
@@ -416,9 +450,17 @@ static int vit256_forward_impl(const hipt_vit_weights* w, const void* images, in
     for (int s0 = 0; s0 < nseq; s0 += chunk) {
         const int n = nseq - s0 < chunk ? nseq - s0 : chunk;
         if ((rc = embed256(w, img, lay, s0, n, x, st))) return rc;
-        if ((rc = run_blocks(w, x, n, 0, w->depth, nullptr, s, st))) return rc;
-        PROF(PC_LN, hipt_layernorm_launch(x, (int64_t)w->ntok * w->dim, w->norm_w, w->norm_b, out + (size_t)s0 * w->dim, HIPT_F32,
-                                          w->dim, n, w->dim, w->ln_eps, st));
+        if (can_prune_last(w)) {
+            float* xc = (float*)((char*)s.hid + 4096);  // (the hidden-tensor slot is free on this path; its head holds tile queues)
+            if ((rc = run_blocks(w, x, n, 0, w->depth - 1, nullptr, s, st))) return rc;
+            if ((rc = run_last_block_cls(w, x, n, s, xc, st))) return rc;
+            PROF(PC_LN, hipt_layernorm_launch(xc, w->dim, w->norm_w, w->norm_b, out + (size_t)s0 * w->dim, HIPT_F32, w->dim, n, w->dim,
+                                              w->ln_eps, st));
+        } else {
+            if ((rc = run_blocks(w, x, n, 0, w->depth, nullptr, s, st))) return rc;
+            PROF(PC_LN, hipt_layernorm_launch(x, (int64_t)w->ntok * w->dim, w->norm_w, w->norm_b, out + (size_t)s0 * w->dim, HIPT_F32,
+                                              w->dim, n, w->dim, w->ln_eps, st));
+        }
     }
     return HIPT_OK;
 }

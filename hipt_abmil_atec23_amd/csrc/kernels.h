@@ -84,6 +84,10 @@ int hipt_attention_launch(const void* qkv, void* out, float* probs, int B, int n
 bool hipt_attention64_supported(int dtype, int dh, int ntok, bool want_probs);
 int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st);
 
+// attention of the [CLS] query only (bf16, head dim 64): out[B, heads*64] bf16
+int hipt_attn_cls_launch(const void* qkv, void* out, int B, int ntok, int heads, int dh, float scale, hipStream_t st);
+// dst[s, :] = src[s * seq_stride ...] : the first row of every sequence (fp32)
+int hipt_gather_cls_launch(const float* src, float* dst, int nseq, int64_t seq_stride, int D, hipStream_t st);
 // x[s, 0, :] = cls + pos[0]  for s in [0, nseq)
 int hipt_cls_init_launch(float* x, const float* cls, const float* pos, int nseq, int ntok, int D, hipStream_t st);
 // out[i] = src[i] (+ (float)y[i] if y)  (fp32, bf16 branch, n % 8 == 0): lands the residual stream in the caller's buffer

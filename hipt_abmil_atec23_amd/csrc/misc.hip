@@ -151,7 +151,112 @@ __global__ void add_bf16_kernel(float* __restrict__ out, const float* __restrict
     }
 }
 
+// Attention of ONE query (token 0, the [CLS] token) per (sequence, head), bf16 qkv, head dim 64: what the last
+// ViT-256 block needs when only x[:, 0] is consumed afterwards (vision_transformer.py:253; SURVEY.md 8d allows the
+// pruning).  One wave per (b, h): lane l scores keys l, l + 64, ... (fp32 dot products of the bf16 values, exact
+// products), wave softmax, then lane d accumulates output dimension d over all keys.
+__global__ __launch_bounds__(256) void attn_cls_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int nbh, int ntok, int heads,
+                                                       float scale) {
+    constexpr int DH = 64, MAXK = 5;  // up to 320 keys
+    const int lane = threadIdx.x & 63;
+    const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bh >= nbh) return;
+    const int b = bh / heads, h = bh % heads, D = heads * DH;
+    const int64_t tokstride = 3 * (int64_t)D;
+    const bf16_t* qrow = qkv + (int64_t)b * ntok * tokstride + h * DH;  // token 0
+    const bf16_t* kbase = qrow + D;
+    const bf16_t* vbase = qrow + 2 * D;
+    float q[DH];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const bf16x8 v = __builtin_bit_cast(bf16x8, *(const u32x4*)(qrow + c * 8));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[c * 8 + e] = (float)v[e];
+    }
+    float sc[MAXK];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        const int key = j * 64 + lane;
+        sc[j] = -INFINITY;
+        if (key < ntok) {
+            const bf16_t* kr = kbase + key * tokstride;
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const bf16x8 v = __builtin_bit_cast(bf16x8, *(const u32x4*)(kr + c * 8));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a = __builtin_fmaf(q[c * 8 + e], (float)v[e], a);
+            }
+            sc[j] = a * scale;
+        }
+        m = fmaxf(m, sc[j]);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        sc[j] = expf(sc[j] - m);  // exp(-inf) = 0 for the keys past the end
+        l += sc[j];
+    }
+    l = wave_sum(l);
+    // O = sum_key p[key] * V[key]: lane (kg = lane >> 3, dc = lane & 7) takes keys kg, kg + 8, ... and the 8 dimensions
+    // 8 dc .. (one 16-byte load per key: 8 keys x 128 B per wave instruction, all loads independent), then the 8 key
+    // groups are summed with three xor-shuffles
+    const int kg = lane >> 3, dc = lane & 7;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j)
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            const int key = j * 64 + ii * 8 + kg;
+            const float pk = __shfl(sc[j], ii * 8 + kg, 64);  // 0 for keys past the end
+            const int kc = key < ntok ? key : ntok - 1;
+            const bf16x8 v = __builtin_bit_cast(bf16x8, *(const u32x4*)(vbase + (int64_t)kc * tokstride + dc * 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(pk, (float)v[e], o[e]);
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o[e] += __shfl_xor(o[e], 8, 64);
+        o[e] += __shfl_xor(o[e], 16, 64);
+        o[e] += __shfl_xor(o[e], 32, 64);
+    }
+    if (kg == 0) {
+        const float inv = 1.0f / l;
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack_bf16x2(o[2 * e] * inv, o[2 * e + 1] * inv);
+        *(u32x4*)(out + (int64_t)b * D + h * DH + dc * 8) = w;
+    }
+}
+
+// dst[s, :] = src[s * ntok, :]  (fp32 rows of D floats: the [CLS] rows of the residual stream)
+__global__ void gather_cls_kernel(const float* __restrict__ src, float* __restrict__ dst, int nseq, int64_t seq_stride, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one float4
+    const int per = D / 4;
+    if (i >= nseq * per) return;
+    const int s = i / per, c = i % per;
+    *(f32x4*)(dst + (int64_t)s * D + 4 * c) = *(const f32x4*)(src + (int64_t)s * seq_stride + 4 * c);
+}
+
 }  // namespace
+
+int hipt_attn_cls_launch(const void* qkv, void* out, int B, int ntok, int heads, int dh, float scale, hipStream_t st) {
+    HIPT_CHECK_ARG(dh == 64 && ntok > 0 && ntok <= 320, "attn_cls: head dim 64 and <= 320 tokens only (dh=%d ntok=%d)", dh, ntok);
+    const int nbh = B * heads;
+    hipLaunchKernelGGL(attn_cls_kernel, dim3((nbh + 3) / 4), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, nbh, ntok, heads, scale);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}
+
+int hipt_gather_cls_launch(const float* src, float* dst, int nseq, int64_t seq_stride, int D, hipStream_t st) {
+    HIPT_CHECK_ARG(D % 4 == 0, "gather_cls: D %% 4");
+    const int n = nseq * (D / 4);
+    hipLaunchKernelGGL(gather_cls_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, dst, nseq, seq_stride, D);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}
 
 int hipt_add_bf16_launch(float* out, const float* src, const void* y, int64_t n, hipStream_t st) {
     HIPT_CHECK_ARG(n % 8 == 0, "add_bf16: n %% 8 required");

@@ -280,6 +280,21 @@ def test_vit256_bf16_is_batch_invariant_bitwise(vit256):
         assert torch.equal(p[12:18], q), f"layer {i}: max diff {float((p[12:18] - q).abs().max())}"
 
 
+def test_vit256_bf16_cls_pruned_last_block_matches_full(vit256):
+    """forward() runs the last block for the [CLS] query only (nothing else of it is consumed, vision_transformer.py:253);
+    get_intermediate_layers() runs every block in full.  Same [CLS] feature up to the rounding of the two attention
+    kernels (one-query fp32 dot products vs MFMA tiles with bf16 probabilities)."""
+    x = synth.hash_uniform_torch((5, 3, 256, 256), 71, device=DEV)
+    vit256.set_compute_dtype("bf16")
+    try:
+        pruned = vit256(x)
+        full = vit256.get_intermediate_layers(x, n=1)[-1][:, 0]
+    finally:
+        vit256.set_compute_dtype("fp32")
+    assert pruned.shape == (5, 384)
+    assert rel_l2(pruned, full.cpu().numpy()) < 3e-3 and cosine(pruned, full.cpu().numpy()) > 0.99999
+
+
 def test_hipt4k_region_batch_equals_single_regions(hipt):
     """R regions per call (throughput form) give the same features as R single-region calls."""
     x = synth.hash_uniform_torch((3, 3, 512, 768), 33, device=DEV)
