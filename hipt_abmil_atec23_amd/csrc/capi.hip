@@ -123,8 +123,10 @@ int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* 
     return hipt_gemm_launch(p, dtype, ALOAD_PLAIN, flags, st);
 }
 
+// emit_last: the MLP of block b1-1 also writes LayerNorm-1 of block b1 on its output rows (bf16, s.att), for a caller
+// that runs block b1 itself (the [CLS]-pruned last block); *have_xn tells it whether that happened
 int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, float* probs, const BlockScratch& s,
-               hipStream_t st) {
+               hipStream_t st, bool emit_last = false, bool* have_xn_out = nullptr) {
     const int D = w->dim, M = nseq * w->ntok, dt = w->dtype, dh = D / w->heads;
     const float scale = 1.0f / sqrtf((float)dh);  // head_dim ** -0.5 (vision_transformer.py:112)
     int rc;
@@ -133,6 +135,11 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     // so that the per-kernel categories hold only the ViT-256 launches the roofline is computed on
     const bool big = D >= 384;
     const int cQKV = big ? PC_QKV : PC_VIT4K, cATTN = big ? PC_ATTN : PC_VIT4K, cPROJ = big ? PC_PROJ : PC_VIT4K, cMLP = big ? PC_MLP : PC_VIT4K;
+    // pipelined path: the MLP of block i applies LayerNorm-1 of block i+1 to the rows it finishes and leaves them in
+    // s.att as bf16 operands; block i+1's QKV GEMM then skips the fp32 row load + LayerNorm
+    const bool chain = seq && hipt_mlp_pipe_supported(dt, D, w->hidden) && hipt_seqgemm_pipe_supported(dt, D, 3 * D, false, 0) &&
+                       getenv("HIPT_NO_LN_CHAIN") == nullptr;
+    bool have_xn = false;
     for (int i = b0; i < b1; ++i) {
         const hipt_block_weights& b = w->blocks[i];
         const bool last_probs = probs != nullptr && i == b1 - 1;
@@ -147,7 +154,12 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             q.out = s.qkv; q.ldc = 3 * D;
             // (the hidden tensor is never materialised on this path: its slot holds the kernels' tile queues)
             q.counter = (int*)s.hid + 16;
-            PROF(cQKV, hipt_seqgemm_launch(q, true, 0, st));
+            if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue
+                q.A = s.att; q.ln_w = q.ln_b = nullptr;
+                PROF(cQKV, hipt_seqgemm_launch(q, false, 0, st));
+            } else {
+                PROF(cQKV, hipt_seqgemm_launch(q, true, 0, st));
+            }
             PROF(cATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st));
             if (last_probs) break;
             q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
@@ -158,6 +170,12 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             m.x = x; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
             m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.M = M; m.D = D; m.hidden = w->hidden;
             m.counter = (int*)s.hid;
+            have_xn = chain && (i + 1 < b1 || emit_last) && i + 1 < w->depth;
+            if (have_xn) {
+                m.ln_next_w = w->blocks[i + 1].ln1_w;
+                m.ln_next_b = w->blocks[i + 1].ln1_b;
+                m.xn_out = s.att;
+            }
             PROF(cMLP, hipt_mlp_launch(m, st));
             continue;
         } else {
@@ -172,6 +190,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
         PROF(PC_FC2, linear(s.hid, w->hidden, b.fc2_w, w->hidden, b.fc2_b, x, x, D, M, D, w->hidden, dt,
                             HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st, w->ntok));
     }
+    if (have_xn_out) *have_xn_out = have_xn;
     return HIPT_OK;
 }
 
@@ -184,7 +203,7 @@ static bool can_prune_last(const hipt_vit_weights* w) {
            hipt_mlp_supported(w->dtype, w->dim, w->hidden) && getenv("HIPT_NO_SEQGEMM") == nullptr && getenv("HIPT_NO_PRUNE") == nullptr;
 }
 
-static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, const BlockScratch& s, float* xc, hipStream_t st) {
+static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, const BlockScratch& s, float* xc, bool have_xn, hipStream_t st) {
     const int D = w->dim, M = nseq * w->ntok;
     const hipt_block_weights& b = w->blocks[w->depth - 1];
     int rc;
@@ -194,7 +213,12 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
     q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.N = 3 * D; q.bias = b.qkv_b;
     q.out = s.qkv; q.ldc = 3 * D;
     q.counter = (int*)s.hid + 16;
-    PROF(PC_QKV, hipt_seqgemm_launch(q, true, 0, st));
+    if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue (bf16 operands in s.att)
+        q.A = s.att; q.ln_w = q.ln_b = nullptr;
+        PROF(PC_QKV, hipt_seqgemm_launch(q, false, 0, st));
+    } else {
+        PROF(PC_QKV, hipt_seqgemm_launch(q, true, 0, st));
+    }
     PROF(PC_ATTN, hipt_attn_cls_launch(s.qkv, s.att, nseq, w->ntok, w->heads, D / w->heads, 1.0f / sqrtf((float)(D / w->heads)), st));
     PROF(PC_OTHER, hipt_gather_cls_launch(x, xc, nseq, (int64_t)w->ntok * D, D, st));
     q.M = nseq; q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
@@ -452,8 +476,9 @@ static int vit256_forward_impl(const hipt_vit_weights* w, const void* images, in
         if ((rc = embed256(w, img, lay, s0, n, x, st))) return rc;
         if (can_prune_last(w)) {
             float* xc = (float*)((char*)s.hid + 4096);  // (the hidden-tensor slot is free on this path; its head holds tile queues)
-            if ((rc = run_blocks(w, x, n, 0, w->depth - 1, nullptr, s, st))) return rc;
-            if ((rc = run_last_block_cls(w, x, n, s, xc, st))) return rc;
+            bool have_xn = false;
+            if ((rc = run_blocks(w, x, n, 0, w->depth - 1, nullptr, s, st, true, &have_xn))) return rc;
+            if ((rc = run_last_block_cls(w, x, n, s, xc, have_xn, st))) return rc;
             PROF(PC_LN, hipt_layernorm_launch(xc, w->dim, w->norm_w, w->norm_b, out + (size_t)s0 * w->dim, HIPT_F32, w->dim, n, w->dim,
                                               w->ln_eps, st));
         } else {

@@ -66,6 +66,11 @@ struct MlpParams {
     const float* b2;
     int M, D, hidden;
     int* counter;        // device int the launcher zeroes on the stream: the kernel's tile queue
+    // optional (pipelined kernel only): LayerNorm-1 of the NEXT block applied to the updated rows, written as bf16
+    // [M, D] -- the next block's QKV GEMM then loads operands directly instead of fp32 rows + LayerNorm
+    const float* ln_next_w;
+    const float* ln_next_b;
+    void* xn_out;
     int full_tiles;      // (set by the launcher) 128-row tiles; tiles beyond are 16-row tail tiles
     int ntiles;          // (set by the launcher)
     int stagger;         // (set by the launcher) start offset between workgroup groups, 10 ns ticks (0 = none)

@@ -19,6 +19,10 @@
 //     row) chosen so that the 8 fc2 K slots a lane owns after GELU are 8 CONSECUTIVE hidden units: the fc2
 //     weight fragment is then one plain 16-byte LDS read, exactly like the fc1 fragment.
 //   * the fc1 bias enters as the C operand of a half's first MFMA (no add, no accumulator init).
+//   * the fc2 weight rows (= output columns) are permuted the same way: a lane ends with 8 CONSECUTIVE output columns per
+//     fragment pair -> 32-byte row pieces for the fp32 residual stream, 16-byte ones for bf16.
+//   * optionally the epilogue also applies the NEXT block's LayerNorm-1 to the rows it has just finished and writes
+//     them as bf16: the next QKV GEMM then needs neither the fp32 row load nor the LayerNorm (a third of its time).
 //   * persistent workgroups pull tiles from an atomic counter; the weight stream is tile-independent and
 //     runs continuously across tiles.
 #include <stdio.h>
@@ -51,6 +55,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
     float* b2s = bet + D;
     float* b1s = b2s + D;                  // [hidden]
     int* tile_s = (int*)(b1s + p.hidden);  // [2] tile handed to this workgroup, double-buffered by parity
+    float* gam1 = (float*)(tile_s + 4);    // next block's LayerNorm-1 (gamma | beta), if p.xn_out
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,10 +73,10 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
     // unit U(rho) = 32(nf>>1) + 8g' + 4(nf&1) + e: lane g' then owns, over the fragment pair (2f, 2f+1), hidden
     // 32f + 8g' + (0..7).  U(rho + 32) = U(rho) + 32, so piece q still only adds a uniform offset.
     const int urow = 32 * (r0 >> 5) + 8 * ((r0 >> 2) & 3) + 4 * ((r0 >> 4) & 1) + (r0 & 3);
-    // per-lane BYTE offsets into W1 (A slabs) and W2 (B slab: 128 outputs x 64 hidden, R = output), both multiples
+    // per-lane BYTE offsets into W1 (A slabs) and W2 (B slab: 128 outputs x 64 hidden, LDS row R = output U(R)), both multiples
     // of 16 and < 2^20: packed into ONE register (two loop-invariant registers were being spilled and re-loaded from
     // scratch, with a vmcnt(0), once per phase); everything else about a DMA address is wave-uniform
-    const uint32_t lanepack = ((uint32_t)(urow * D + ch0 * 8) >> 3) | (((uint32_t)(r0 * p.hidden + ch0 * 8) >> 3) << 16);
+    const uint32_t lanepack = ((uint32_t)(urow * D + ch0 * 8) >> 3) | (((uint32_t)(urow * p.hidden + ch0 * 8) >> 3) << 16);
     // issue side of the ring: the unit whose 12 pieces per wave are being issued
     // buffer-addressed LDS-DMA: resource = whole matrix (scalar registers), per-lane offset in ONE 32-bit register,
     // everything else (unit, slab, piece) in the scalar offset -> no vector address arithmetic per piece
@@ -126,7 +131,11 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
     for (int i = tid; i < D; i += 256) {
         gam[i] = p.ln_w[i];
         bet[i] = p.ln_b[i];
-        b2s[i] = p.b2[i];
+        b2s[i] = p.b2[(i & ~31) + 8 * ((i >> 2) & 3) + 4 * ((i >> 4) & 1) + (i & 3)];  // permuted like the fc2 weight rows
+        if (p.xn_out) {
+            gam1[i] = p.ln_next_w[i];
+            gam1[D + i] = p.ln_next_b[i];
+        }
     }
     for (int i = tid; i < p.hidden; i += 256) {  // same permutation inside every 64-half: b1s[base + rho] = b1[base + U(rho)]
         const int rho = i & 63;
@@ -146,6 +155,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
     const uint32_t tsbase = (uint32_t)(uintptr_t)(LDS_AS char*)tile_s;
     const uint32_t gbase = (uint32_t)(uintptr_t)(LDS_AS char*)gam + 32 * g;
     const uint32_t b2base = (uint32_t)(uintptr_t)(LDS_AS char*)b2s + 16 * g;
+    const uint32_t g1base = (uint32_t)(uintptr_t)(LDS_AS char*)gam1 + 32 * g;
 
     // ---- prime the ring: units 0 and 1 of the pass ----
     int cons = 0;  // units consumed since kernel start (slot = cons % 3)
@@ -378,7 +388,11 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
             phase(TA{}, I1{}, I0{}, I1{}, I0{}, 0);             // A1(c)   + second eight of half 0
             phase(TB{}, I0{}, I1{}, I0{}, I1{}, c + 1 < nchunk ? (c + 1) * 128 : 0);  // B0(c) + first eight of half 1
         }
-        LGKM(0);  // (the last B0 read a bias nobody uses: let it land before its registers are re-used)
+        LGKM(0);  // (the last B0 read a bias nobody uses: let it land before its registers are re-used ...
+        {         //  ... and keep those registers allocated up to here: a fake use AFTER the wait)
+            f32x4 &q0 = bq[0], &q1 = bq[1], &q2 = bq[2], &q3 = bq[3];
+            asm volatile("" ::"v"(q0), "v"(q1), "v"(q2), "v"(q3));
+        }
         // tail: second eight of the last half 1, then B1(last); its prefetch is the next tile's A0(0)
         sfor<8, 16>([&](auto U_) __attribute__((always_inline)) { gelu_unit(I1{}, U_); });
         __builtin_amdgcn_sched_barrier(0);
@@ -387,24 +401,28 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
         if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
 
         // ---- epilogue: x <- x + y1 + acc2 + b2 (this workgroup owns its rows: in place, no other reader).
+        //      acc2[mf][nf][e] is output column 16(nf & ~1) + 8g + 4(nf & 1) + e of row li (permuted fc2 rows): fragment
+        //      pair pr = nf >> 1 holds the 8 consecutive columns 32 pr + 8g + (0..7).
         //      All row loads of a fragment are issued before the first asm statement (nothing moves across those).
         sfor<0, 2>([&](auto MF_) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
             constexpr int mf = decltype(MF_)::value;
             const int r = (wave * 2 + mf) * 16 + li;
             const bool live = r < nrows;
-            float* xr = p.x + (int64_t)(row0 + (live ? r : 0)) * D + 4 * g;
-            const bf16_t* yr = (const bf16_t*)p.y1 + (int64_t)(row0 + (live ? r : 0)) * D + 4 * g;
-            f32x4 xv[NF2];
-            u32x2 yv[NF2];
+            float* xr = p.x + (int64_t)(row0 + (live ? r : 0)) * D + 8 * g;
+            const bf16_t* yr = (const bf16_t*)p.y1 + (int64_t)(row0 + (live ? r : 0)) * D + 8 * g;
+            f32x4 xv[NF2];  // the row's old values, then (in place) its new ones
+            u32x4 yv[NF2 / 2];
 #pragma unroll
-            for (int nf = 0; nf < NF2; ++nf) xv[nf] = *(const f32x4*)(xr + nf * 16);
+            for (int nf = 0; nf < NF2; ++nf) xv[nf] = *(const f32x4*)(xr + 32 * (nf >> 1) + 4 * (nf & 1));
             if (p.y1) {
 #pragma unroll
-                for (int nf = 0; nf < NF2; ++nf) yv[nf] = *(const u32x2*)(yr + nf * 16);
+                for (int pr = 0; pr < NF2 / 2; ++pr) yv[pr] = *(const u32x4*)(yr + 32 * pr);
             } else {
 #pragma unroll
-                for (int nf = 0; nf < NF2; ++nf) yv[nf] = u32x2{0u, 0u};
+                for (int pr = 0; pr < NF2 / 2; ++pr) yv[pr] = u32x4{0u, 0u, 0u, 0u};
             }
+            float rs = 0.f;
             sfor<0, NF2 / 4>([&](auto Q_) __attribute__((always_inline)) {  // 4 output fragments at a time
                 constexpr int q4 = decltype(Q_)::value;
                 f32x4 bb[4];
@@ -415,12 +433,50 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
                 for (int j = 0; j < 4; ++j) {
                     const int nf = 4 * q4 + j;
                     f32x4 v = acc2[mf][nf] + bb[j] + xv[nf];
-                    const bf16x4 y = __builtin_bit_cast(bf16x4, yv[nf]);
+                    const bf16x8 y = __builtin_bit_cast(bf16x8, yv[nf >> 1]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)y[e];
-                    if (live) *(f32x4*)(xr + nf * 16) = v;
+                    for (int e = 0; e < 4; ++e) v[e] += (float)y[4 * (nf & 1) + e];
+                    if (live) *(f32x4*)(xr + 32 * (nf >> 1) + 4 * (nf & 1)) = v;
+                    xv[nf] = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rs += v[e];
                 }
             });
+            if (p.xn_out) {
+                // LayerNorm-1 of the next block on the finished row (the 4 g-lanes of a row hold all of it), as bf16
+                rs += __shfl_xor(rs, 16, 64);
+                rs += __shfl_xor(rs, 32, 64);
+                const float mean = rs * (1.0f / D);
+                float q = 0.f;
+#pragma unroll
+                for (int nf = 0; nf < NF2; ++nf)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = xv[nf][e] - mean;
+                        q = __builtin_fmaf(a, a, q);
+                    }
+                q += __shfl_xor(q, 16, 64);
+                q += __shfl_xor(q, 32, 64);
+                const float rstd = 1.0f / sqrtf(q * (1.0f / D) + p.ln_eps);
+                bf16_t* nr = (bf16_t*)p.xn_out + (int64_t)(row0 + (live ? r : 0)) * D + 8 * g;
+                sfor<0, NF2 / 2>([&](auto P_) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+                    constexpr int pr = decltype(P_)::value;
+                    f32x4 g0, g1, b0, b1;
+                    const uint32_t ga = g1base;
+                    DSR128X4_WAIT(g0, g1, b0, b1, ga, pr * 128, pr * 128 + 16, pr * 128 + D * 4, pr * 128 + D * 4 + 16);
+                    float y[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y[e] = __builtin_fmaf((xv[2 * pr][e] - mean) * rstd, g0[e], b0[e]);
+                        y[4 + e] = __builtin_fmaf((xv[2 * pr + 1][e] - mean) * rstd, g1[e], b1[e]);
+                    }
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(y[2 * e], y[2 * e + 1]);
+                    if (live) *(u32x4*)(nr + 32 * pr) = o;
+                });
+            }
         });
         PSTAMP(4);
         if (DBG & 1) __syncthreads();  // (no ring barriers in this debug build)
@@ -441,7 +497,7 @@ bool hipt_mlp_pipe_supported(int dtype, int D_, int hidden) {
 template <int DBG>
 int hipt_mlp_pipe_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     MlpParams p = p_in;
-    const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16;
+    const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4;
     auto k = mlp_pipe_kernel<DBG>;
     static bool attr = false;
     static int ncu = 0;

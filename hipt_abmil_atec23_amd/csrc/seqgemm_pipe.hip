@@ -311,7 +311,12 @@ __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParam
             phase(I0{}, I0{}, I0{}, I0{}, 0, ncol(t + 1) + 64, ncol(t));
             phase(I0{}, I1{}, I1{}, I1{}, ncol(t + 2 < NT ? t + 2 : 0), 0, ncol(t));
         }
-        LGKM(0);  // (the last phase may have read a bias quad nobody uses: let it land before its registers are re-used)
+        LGKM(0);  // (the last phase read fragments / a bias quad nobody uses: let them land before their registers are
+        {         //  re-used, and keep those registers allocated up to here: a fake use AFTER the wait)
+            f32x4 &q0 = bq[0], &q1 = bq[1], &q2 = bq[2], &q3 = bq[3];
+            u32x4 &w0 = wA[0][0], &w1 = wA[0][1], &w2 = wA[0][2], &w3 = wA[0][3];
+            asm volatile("" ::"v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+        }
         int nlast;
         if (t < NT) {  // odd one left: accumulator 1
             rd_frag(I0{}, I0{}, lbase + (cons % 3) * UNIT);

@@ -38,6 +38,9 @@ for i, l in enumerate(src):
     if "s_waitcnt" in t and "lgkmcnt(0)" in t:
         queue = []
         continue
+    if t.startswith("s_branch") or t.startswith("s_endpgm"):  # (control flow is not followed: the fall-through code
+        queue = []                                             #  below an unconditional branch is another path)
+        continue
     regs = set()
     for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", t):
         regs.update(range(int(a), int(b) + 1))
