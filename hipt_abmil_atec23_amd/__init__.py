@@ -20,6 +20,8 @@ _LAZY = {
     "VisionTransformer": ("vision_transformer", "VisionTransformer"), "vit_small": ("vision_transformer", "vit_small"),
     "VisionTransformer4K": ("vision_transformer4k", "VisionTransformer4K"), "vit4k_xs": ("vision_transformer4k", "vit4k_xs"),
     "install": ("dropin", "install"), "build_native": ("_native", "build"),
+    "FeatureWriter": ("feature_store", "FeatureWriter"), "extract_slide": ("feature_store", "extract_slide"),
+    "load_bag": ("feature_store", "load_bag"),
 }
 
 

@@ -152,3 +152,45 @@ def test_eval_transforms_matches_totensor_normalize():
     t = eval_transforms()(a.astype(np.uint8))
     ref = (torch.from_numpy(a.astype(np.float32) / 255.0).permute(2, 0, 1) - 0.5) / 0.5
     assert torch.allclose(t, ref)
+
+
+def test_feature_store_roundtrip_and_subsampling(tmp_path):
+    """pt_files/{slide}.pt writer (extract_features_fp.py:169-171,255) and the bag loader with max_patches_per_slide
+    (datasets/dataset_generic.py:512-520: np.random.choice WITH replacement)."""
+    from hipt_abmil_atec23_amd.feature_store import FeatureWriter, extract_slide, load_bag
+    w = FeatureWriter(str(tmp_path), "slide_a", write_h5=False)
+    f1, f2 = torch.randn(3, 192), torch.randn(2, 192)
+    w.append(f1, torch.tensor([[0, 0], [0, 4096], [4096, 0]]))
+    w.append(f2.numpy(), np.array([[4096, 4096], [8192, 0]]))
+    assert len(w) == 5
+    pt = w.close()
+    assert pt.endswith(os.path.join("pt_files", "slide_a.pt"))
+    stored = torch.load(pt)
+    assert torch.is_tensor(stored) and stored.dtype == torch.float32 and torch.equal(stored, torch.cat([f1, f2]))
+    assert torch.equal(load_bag(str(tmp_path), "slide_a"), stored)                   # no cap
+    assert torch.equal(load_bag(str(tmp_path), "slide_a", 5), stored)                # cap not exceeded: untouched
+    sub = load_bag(str(tmp_path), "slide_a", 3, rng=np.random.RandomState(0))
+    idx = np.random.RandomState(0).choice(5, 3)
+    assert sub.shape == (3, 192) and torch.equal(sub, stored[torch.as_tensor(idx)])
+    many = load_bag(str(tmp_path), "slide_a", 4, rng=np.random.RandomState(7))       # with replacement: duplicates allowed
+    assert many.shape == (4, 192)
+    with pytest.raises(AssertionError, match="slide_missing"):
+        load_bag(str(tmp_path), "slide_missing")
+    with pytest.raises(ValueError):
+        FeatureWriter(str(tmp_path), "bad", write_h5=False).append(torch.zeros(3, 192), torch.zeros(2, 2))
+    # the driver loop with a stand-in model (any callable regions -> [R, d])
+    model = lambda r: r.float().mean(dim=(1, 2, 3)).unsqueeze(1).repeat(1, 4)
+    batches = [(torch.ones(2, 3, 8, 8) * k, torch.tensor([[k, 0], [k, 1]])) for k in (1, 2)]
+    out = torch.load(extract_slide(model, batches, str(tmp_path), "slide_b"))
+    assert out.shape == (4, 4) and torch.equal(out[:, 0], torch.tensor([1., 1., 2., 2.]))
+
+
+def test_prepare_img_tensor_uint8_interleaved():
+    from hipt_abmil_atec23_amd import HIPT_4K
+    h = HIPT_4K(None, None, "cpu", "cpu")
+    x = torch.randint(0, 256, (2, 600, 1000, 3), dtype=torch.uint8)
+    img, w, hh = h.prepare_img_tensor(x)
+    assert (w, hh) == (2, 3) and img.shape == (2, 512, 768, 3) and torch.equal(img, x[:, 44:556, 116:884, :])
+    planar = x.permute(0, 3, 1, 2).contiguous()
+    img2, _, _ = h.prepare_img_tensor(planar)
+    assert img2.shape == (2, 3, 512, 768) and torch.equal(img2, planar[:, :, 44:556, 116:884])
