@@ -219,7 +219,7 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
     } else {
         PROF(PC_QKV, hipt_seqgemm_launch(q, true, 0, st));
     }
-    PROF(PC_ATTN, hipt_attn_cls_launch(s.qkv, s.att, nseq, w->ntok, w->heads, D / w->heads, 1.0f / sqrtf((float)(D / w->heads)), st));
+    PROF(PC_ATTN, hipt_attn_cls_launch(s.qkv, s.att, nullptr, nseq, w->ntok, w->heads, D / w->heads, 1.0f / sqrtf((float)(D / w->heads)), st));
     PROF(PC_OTHER, hipt_gather_cls_launch(x, xc, nseq, (int64_t)w->ntok * D, D, st));
     q.M = nseq; q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
     q.counter = (int*)s.hid + 32;
@@ -421,6 +421,41 @@ int hipt_vit_blocks(const hipt_vit_weights* w, float* x, int nseq, int blk_begin
         return HIPT_E_WORKSPACE;
     }
     return run_blocks(w, x, nseq, blk_begin, blk_end, probs, s, S(stream));
+}
+
+// the [CLS] row of the last block's attention map, probs_cls[nseq, heads, ntok], without the
+// [nseq, heads, ntok, ntok] tensor (heat-maps read attention[:, :, 0, 1:], hipt_4k.py:143-158).  x = prepared tokens
+// (modified: it ends as the input of the last block).  bf16 / head dim 64 only: HIPT_E_UNSUPPORTED otherwise.
+int hipt_vit_cls_attention(const hipt_vit_weights* w, float* x, int nseq, float* probs_cls, void* workspace, size_t ws_bytes, void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(x && probs_cls && nseq > 0, "vit_cls_attention: null/empty argument");
+    const int D = w->dim, dh = D / w->heads;
+    if (!(w->dtype == HIPT_BF16 && dh == 64 && w->ntok <= 320 && hipt_seqgemm_supported(w->dtype, D))) {
+        hipt_set_error("vit_cls_attention: bf16 weights with head dim 64 only");
+        return HIPT_E_UNSUPPORTED;
+    }
+    Carver c(workspace, ws_bytes);
+    BlockScratch s = carve_blocks(c, w, nseq);
+    if (!c.ok()) {
+        hipt_set_error("vit_cls_attention: workspace %zu B too small / unaligned (need %zu)", ws_bytes, c.used);
+        return HIPT_E_WORKSPACE;
+    }
+    hipStream_t st = S(stream);
+    bool have_xn = false;
+    if ((rc = run_blocks(w, x, nseq, 0, w->depth - 1, nullptr, s, st, true, &have_xn))) return rc;
+    const hipt_block_weights& b = w->blocks[w->depth - 1];
+    SeqGemmParams q;
+    memset(&q, 0, sizeof(q));
+    q.M = nseq * w->ntok; q.K = D; q.ln_eps = w->ln_eps;
+    q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.N = 3 * D; q.bias = b.qkv_b;
+    q.out = s.qkv; q.ldc = 3 * D;
+    q.counter = (int*)s.hid + 16;
+    if (have_xn) {
+        q.A = s.att; q.ln_w = q.ln_b = nullptr;
+    }
+    if ((rc = hipt_seqgemm_launch(q, !have_xn, 0, st))) return rc;
+    return hipt_attn_cls_launch(s.qkv, nullptr, probs_cls, nseq, w->ntok, w->heads, dh, 1.0f / sqrtf((float)dh), st);
 }
 
 int hipt_vit_head(const hipt_vit_weights* w, const float* x, int nseq, int cls_only, float* out, void* stream) {

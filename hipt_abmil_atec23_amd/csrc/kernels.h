@@ -89,8 +89,8 @@ int hipt_attention_launch(const void* qkv, void* out, float* probs, int B, int n
 bool hipt_attention64_supported(int dtype, int dh, int ntok, bool want_probs);
 int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st);
 
-// attention of the [CLS] query only (bf16, head dim 64): out[B, heads*64] bf16
-int hipt_attn_cls_launch(const void* qkv, void* out, int B, int ntok, int heads, int dh, float scale, hipStream_t st);
+// attention of the [CLS] query only (bf16, head dim 64): out[B, heads*64] bf16 and/or probs[B, heads, ntok] fp32 (either may be null)
+int hipt_attn_cls_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale, hipStream_t st);
 // dst[s, :] = src[s * seq_stride ...] : the first row of every sequence (fp32)
 int hipt_gather_cls_launch(const float* src, float* dst, int nseq, int64_t seq_stride, int D, hipStream_t st);
 // x[s, 0, :] = cls + pos[0]  for s in [0, nseq)

@@ -155,8 +155,8 @@ __global__ void add_bf16_kernel(float* __restrict__ out, const float* __restrict
 // ViT-256 block needs when only x[:, 0] is consumed afterwards (vision_transformer.py:253; SURVEY.md 8d allows the
 // pruning).  One wave per (b, h): lane l scores keys l, l + 64, ... (fp32 dot products of the bf16 values, exact
 // products), wave softmax, then lane d accumulates output dimension d over all keys.
-__global__ __launch_bounds__(256) void attn_cls_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int nbh, int ntok, int heads,
-                                                       float scale) {
+__global__ __launch_bounds__(256) void attn_cls_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ probs,
+                                                       int nbh, int ntok, int heads, float scale) {
     constexpr int DH = 64, MAXK = 5;  // up to 320 keys
     const int lane = threadIdx.x & 63;
     const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -200,6 +200,13 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const bf16_t* __restrict_
         l += sc[j];
     }
     l = wave_sum(l);
+    if (probs) {  // attention of the [CLS] query over all keys (heat-maps read [:, :, 0, 1:] of the last block's map)
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j)
+            if (j * 64 + lane < ntok) probs[(int64_t)bh * ntok + j * 64 + lane] = sc[j] * inv;
+        if (!out) return;
+    }
     // O = sum_key p[key] * V[key]: lane (kg = lane >> 3, dc = lane & 7) takes keys kg, kg + 8, ... and the 8 dimensions
     // 8 dc .. (one 16-byte load per key: 8 keys x 128 B per wave instruction, all loads independent), then the 8 key
     // groups are summed with three xor-shuffles
@@ -242,10 +249,11 @@ __global__ void gather_cls_kernel(const float* __restrict__ src, float* __restri
 
 }  // namespace
 
-int hipt_attn_cls_launch(const void* qkv, void* out, int B, int ntok, int heads, int dh, float scale, hipStream_t st) {
+int hipt_attn_cls_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale, hipStream_t st) {
     HIPT_CHECK_ARG(dh == 64 && ntok > 0 && ntok <= 320, "attn_cls: head dim 64 and <= 320 tokens only (dh=%d ntok=%d)", dh, ntok);
     const int nbh = B * heads;
-    hipLaunchKernelGGL(attn_cls_kernel, dim3((nbh + 3) / 4), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, nbh, ntok, heads, scale);
+    hipLaunchKernelGGL(attn_cls_kernel, dim3((nbh + 3) / 4), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, probs, nbh, ntok, heads,
+                       scale);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }

@@ -143,6 +143,22 @@ class _HipVitMixin:
         self._blocks(pk, tok, 0, pk.w.depth, probs)
         return probs
 
+    def get_last_selfattention_cls(self, x):
+        """[B, heads, N]: the [CLS] query's row of the last block's attention map, i.e. ``get_last_selfattention(x)[:, :, 0, :]``,
+        which is all the heat-maps use (hipt_4k.py:143-158) -- without the [B, heads, N, N] tensor where the fused
+        one-query kernel applies (bf16, head dim 64); elsewhere the slice of the full map."""
+        pk, tok = self._tokens(x)
+        B, ntok, _ = tok.shape
+        if pk.w.dtype == N.HIPT_BF16 and pk.w.dim // pk.w.heads == 64 and ntok <= 320:
+            out = torch.empty((B, pk.w.heads, ntok), dtype=torch.float32, device=tok.device)
+            need = N.lib().hipt_vit_workspace_bytes(pk.ref, B)
+            ws = Fn.workspace(tok.device, need)
+            N.call("hipt_vit_cls_attention", pk.ref, N.ptr(tok), B, N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(tok.device))
+            return out
+        probs = torch.empty((B, pk.w.heads, ntok, ntok), dtype=torch.float32, device=tok.device)
+        self._blocks(pk, tok, 0, pk.w.depth, probs)
+        return probs[:, :, 0, :].contiguous()
+
     def get_intermediate_layers(self, x, n=1):
         """Normed outputs of the ``n`` last blocks (vision_transformer.py:264-272)."""
         pk, tok = self._tokens(x)

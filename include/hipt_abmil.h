@@ -160,6 +160,14 @@ int hipt_vit4k_prepare_tokens(const hipt_vit_weights* w, const float* tokens_in,
 int hipt_vit_blocks(const hipt_vit_weights* w, float* x, int nseq, int blk_begin, int blk_end,
                     float* probs, void* workspace, size_t ws_bytes, void* stream);
 
+/* [CLS] row of the last block's attention map: probs_cls[nseq, heads, ntok] fp32 =
+ * get_last_selfattention(x)[:, :, 0, :] (vision_transformer.py:255-262 as consumed by the heat-maps,
+ * HIPT_4K/hipt_4k.py:143-158) without materialising [nseq, heads, ntok, ntok].  x = prepared tokens, modified.
+ * bf16 weights with head dim 64 only (HIPT_E_UNSUPPORTED otherwise: slice hipt_vit_blocks' probabilities).
+ * workspace >= hipt_vit_workspace_bytes(). */
+int hipt_vit_cls_attention(const hipt_vit_weights* w, float* x, int nseq, float* probs_cls,
+                           void* workspace, size_t ws_bytes, void* stream);
+
 /* Final LayerNorm; cls_only=1 -> out[nseq, D] = norm(x)[:,0] (:252-253), else out[nseq, ntok, D]
  * (get_intermediate_layers :264-272). */
 int hipt_vit_head(const hipt_vit_weights* w, const float* x, int nseq, int cls_only, float* out,

@@ -280,6 +280,25 @@ def test_vit256_bf16_is_batch_invariant_bitwise(vit256):
         assert torch.equal(p[12:18], q), f"layer {i}: max diff {float((p[12:18] - q).abs().max())}"
 
 
+def test_vit256_cls_attention_row_matches_full_map(vit256, vit4k):
+    """get_last_selfattention_cls = [:, :, 0, :] of the full map (what the heat-maps consume, hipt_4k.py:143-158): exact in
+    fp32 (same kernels, sliced), bf16 through the fused one-query kernel within 1e-3 absolute; rows sum to 1."""
+    x = synth.hash_uniform_torch((3, 3, 256, 256), 12, device=DEV)
+    vit256.set_compute_dtype("fp32")
+    full = vit256.get_last_selfattention(x)
+    assert torch.equal(vit256.get_last_selfattention_cls(x), full[:, :, 0, :])
+    vit256.set_compute_dtype("bf16")
+    try:
+        row = vit256.get_last_selfattention_cls(x)
+        full16 = vit256.get_last_selfattention(x)[:, :, 0, :]
+    finally:
+        vit256.set_compute_dtype("fp32")
+    assert row.shape == (3, 6, 257) and md(row, full16.cpu().numpy()) < 1e-3 and md(row, full[:, :, 0, :].cpu().numpy()) < 5e-3
+    assert float((row.sum(-1) - 1).abs().max()) < 1e-5
+    g16 = synth.hash_uniform_torch((1, 384, 16, 16), 4, device=DEV)  # head dim 32: the sliced fallback
+    assert torch.equal(vit4k.get_last_selfattention_cls(g16), vit4k.get_last_selfattention(g16)[:, :, 0, :])
+
+
 def test_vit256_bf16_cls_pruned_last_block_matches_full(vit256):
     """forward() runs the last block for the [CLS] query only (nothing else of it is consumed, vision_transformer.py:253);
     get_intermediate_layers() runs every block in full.  Same [CLS] feature up to the rounding of the two attention
