@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--chunk", type=int, default=0, help="patches per ViT-256 pass (0 = library default)")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the regions of a step are spread over (tail filling)")
     ap.add_argument("--u8", action="store_true", help="regions resident as uint8 RGB [R,W,H,3], normalised on the device (SURVEY 8f-1)")
     ap.add_argument("--regions", type=int, default=8, help="4096x4096 regions per HIPT_4K call (1 = the reference's batch_size)")
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -173,6 +174,7 @@ def main():
     N.lib()  # fail loudly before doing anything if the native library is missing
 
     model, clam = build_models(dev, args.dtype)
+    model.streams = args.streams
     model.chunk = args.chunk
     R = args.regions
     region = synth.hash_uniform_torch((R, 3, REGION, REGION), 3 + rank, device=dev)
@@ -228,7 +230,7 @@ def main():
         "config": {"workload": "per step: HIPT_4K.forward on R resident [3,4096,4096] fp32 regions (R x 256 patches ViT-256 -> "
                                "ViT-4K over each 16x16 [CLS] grid, BASELINE configs[2]) + CLAM_SB gated-attention pooling over one "
                                "100000x384 bag (configs[3]); random-init weights of the reference architectures",
-                   "regions_per_step": R, "input": "uint8 RGB interleaved" if args.u8 else "fp32 normalised", "bag": [BAG_N, BAG_S0], "chunk_patches": args.chunk or 256 * R,
+                   "regions_per_step": R, "streams": args.streams, "input": "uint8 RGB interleaved" if args.u8 else "fp32 normalised", "bag": [BAG_N, BAG_S0], "chunk_patches": args.chunk or 256 * R,
                    "parallelism": f"slide-sharded x{world}, one all-gather"},
         "abmil_fwd_ms": abmil_ms,
         "model_tflops": world * args.steps * R * FLOP_PER_REGION / dt / 1e12,
@@ -237,6 +239,7 @@ def main():
     # ---- per-kernel roofline leg: same workload, HIP events around every launch ----
     prof = {}
     if args.profile_steps > 0:
+        model.streams = 1  # per-launch HIP events: one stream, so that a kernel's time is its own (no other kernel on the CUs)
         N.profile_enable(True)
         for i in range(args.profile_steps):
             step(i, False)

@@ -18,9 +18,9 @@ def torch_dtype(code: int):
     return _TORCH_DT[code]
 
 
-def workspace(device, nbytes: int) -> torch.Tensor:
-    """Grow-only per-device scratch (the library itself never allocates)."""
-    key = (device.type, device.index)
+def workspace(device, nbytes: int, slot: int = 0) -> torch.Tensor:
+    """Grow-only per-device scratch (the library itself never allocates).  ``slot``: one scratch per concurrent stream."""
+    key = (device.type, device.index, slot)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

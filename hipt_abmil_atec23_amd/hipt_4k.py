@@ -32,6 +32,11 @@ class HIPT_4K(torch.nn.Module):
         self.device256 = torch.device(device256)
         self.device4k = torch.device(device4k)
         self.chunk = 0  # patches per ViT-256 pass (0 = library default)
+        # > 1: a batch of regions is cut into that many parts, each run on its own HIP stream with its own workspace.
+        # Every kernel of the path occupies whole CUs (one persistent workgroup each), so the parts do not share CUs:
+        # the second stream's kernels fill the CUs the first one's kernel frees in its last, partial round of tiles.
+        self.streams = 1
+        self._side_streams = {}
         if compute_dtype is not None:
             self.set_compute_dtype(compute_dtype)
 
@@ -81,27 +86,45 @@ class HIPT_4K(torch.nn.Module):
             buf = torch.empty((nreg, 3, W, H), dtype=torch.float32, device=d256)
             N.call("hipt_u8_normalize", N.ptr(region), int(hwc), nreg, W * H, N.ptr(buf), N.HIPT_F32, N.stream_ptr(d256))
             region, u8 = buf, False
-        if d256 == d4k and u8:
-            m256, m4k = self.model256, self.model4k
-            pk256 = m256._packed_for(m256._pos_for(256, 256, 256))
-            pk4k = m4k._packed_for(m4k._pos_for(per, w_256, h_256))
-            out = torch.empty((nreg, pk4k.w.dim), dtype=torch.float32, device=d4k)
-            cls256 = torch.empty((nseq, pk256.w.dim), dtype=torch.float32, device=d256) if want_cls256 else None
-            need = N.lib().hipt_hipt4k_u8_workspace_bytes(pk256.ref, pk4k.ref, nreg, w_256, h_256, self.chunk)
-            ws = Fn.workspace(d256, need)
-            N.call("hipt_hipt4k_forward_u8", pk256.ref, pk4k.ref, N.ptr(region), int(hwc), nreg, W, H, self.chunk, N.ptr(cls256),
-                   N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(d256))
-            return out, cls256
         if d256 == d4k:
             m256, m4k = self.model256, self.model4k
             pk256 = m256._packed_for(m256._pos_for(256, 256, 256))
             pk4k = m4k._packed_for(m4k._pos_for(per, w_256, h_256))
             out = torch.empty((nreg, pk4k.w.dim), dtype=torch.float32, device=d4k)
             cls256 = torch.empty((nseq, pk256.w.dim), dtype=torch.float32, device=d256) if want_cls256 else None
-            need = N.lib().hipt_hipt4k_workspace_bytes(pk256.ref, pk4k.ref, nreg, w_256, h_256, self.chunk)
-            ws = Fn.workspace(d256, need)
-            N.call("hipt_hipt4k_forward", pk256.ref, pk4k.ref, N.ptr(region), nreg, W, H, self.chunk, N.ptr(cls256), N.ptr(out),
-                   N.ptr(ws), ws.numel(), N.stream_ptr(d256))
+
+            def launch(lo, hi, slot):
+                n = hi - lo
+                sub_cls = cls256[lo * per:hi * per] if cls256 is not None else None
+                if u8:
+                    need = N.lib().hipt_hipt4k_u8_workspace_bytes(pk256.ref, pk4k.ref, n, w_256, h_256, self.chunk)
+                    ws = Fn.workspace(d256, need, slot)
+                    N.call("hipt_hipt4k_forward_u8", pk256.ref, pk4k.ref, N.ptr(region[lo:hi]), int(hwc), n, W, H, self.chunk,
+                           N.ptr(sub_cls), N.ptr(out[lo:hi]), N.ptr(ws), ws.numel(), N.stream_ptr(d256))
+                else:
+                    need = N.lib().hipt_hipt4k_workspace_bytes(pk256.ref, pk4k.ref, n, w_256, h_256, self.chunk)
+                    ws = Fn.workspace(d256, need, slot)
+                    N.call("hipt_hipt4k_forward", pk256.ref, pk4k.ref, N.ptr(region[lo:hi]), n, W, H, self.chunk, N.ptr(sub_cls),
+                           N.ptr(out[lo:hi]), N.ptr(ws), ws.numel(), N.stream_ptr(d256))
+
+            parts = max(1, min(int(self.streams), nreg))
+            if parts == 1:
+                launch(0, nreg, 0)
+                return out, cls256
+            cur = torch.cuda.current_stream(d256)
+            key = (d256.index, parts)
+            if key not in self._side_streams:
+                self._side_streams[key] = [torch.cuda.Stream(device=d256) for _ in range(parts)]
+            bounds = [nreg * k // parts for k in range(parts + 1)]
+            for k, st in enumerate(self._side_streams[key]):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    launch(bounds[k], bounds[k + 1], 1 + k)
+                for t in (region, out, cls256):
+                    if t is not None:
+                        t.record_stream(st)
+            for st in self._side_streams[key]:
+                cur.wait_stream(st)
             return out, cls256
         # two-device placement (hipt_4k.py:39-46): ViT-256 on device256, grid copied to device4k
         lay = N.ImageLayout(w_256, h_256, 256, 256, H, W * H, 3 * W * H)

@@ -325,6 +325,16 @@ def test_hipt4k_region_batch_equals_single_regions(hipt):
         finally:
             hipt.set_compute_dtype("fp32")
         assert batched.shape == (3, 192) and md(batched, singles.cpu().numpy()) < tol, dt
+    # the same batch cut over two HIP streams (own workspace each): identical bits
+    hipt.set_compute_dtype("bf16")
+    try:
+        one = hipt(x)
+        hipt.streams = 2
+        two = hipt(x)
+    finally:
+        hipt.streams = 1
+        hipt.set_compute_dtype("fp32")
+    assert torch.equal(one, two)
     with pytest.raises(ValueError):
         hipt.forward_asset_dict(x)
 
