@@ -155,7 +155,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="patches per ViT-256 pass (0 = library default)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the regions of a step are spread over (tail filling)")
     ap.add_argument("--u8", action="store_true", help="regions resident as uint8 RGB [R,W,H,3], normalised on the device (SURVEY 8f-1)")
-    ap.add_argument("--regions", type=int, default=8, help="4096x4096 regions per HIPT_4K call (1 = the reference's batch_size)")
+    ap.add_argument("--regions", type=int, default=16, help="4096x4096 regions per HIPT_4K call (1 = the reference's batch_size)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
