@@ -114,6 +114,10 @@ def lib():
                 raise NativeLibraryError(
                     f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                     f"(or `make -C {CSRC}`).  This package has no non-HIP execution path.")
+            # PyTorch-ROCm ships its own libamdhip64: it must be in the process BEFORE this library is loaded, so that
+            # the library's kernels register with the HIP runtime that owns torch's streams and memory.  Loaded the
+            # other way round, the system runtime comes in first and every launch fails (hipFuncSetAttribute error).
+            import torch  # noqa: F401
             h = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(h, name)  # AttributeError if the .so does not export a declared symbol

@@ -194,3 +194,14 @@ def test_prepare_img_tensor_uint8_interleaved():
     planar = x.permute(0, 3, 1, 2).contiguous()
     img2, _, _ = h.prepare_img_tensor(planar)
     assert img2.shape == (2, 3, 512, 768) and torch.equal(img2, planar[:, :, 44:556, 116:884])
+
+
+def test_library_load_brings_torch_in_first():
+    """Loading the library in a fresh interpreter must import torch (its bundled HIP runtime) before dlopen: kernels
+    registered with the system runtime instead cannot be launched on torch's streams."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from hipt_abmil_atec23_amd import _native as N; "
+            "assert 'torch' not in sys.modules; N.lib(); assert 'torch' in sys.modules; print('ok')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
