@@ -19,6 +19,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -54,6 +56,139 @@ __device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, int off) {
 #define LGKM(n)                                             \
     asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
     __builtin_amdgcn_sched_barrier(0)
+
+// End of a workgroup's stream: 16-lane reduction of the per-lane pools, merge of the 4 waves through LDS, partial
+// (max, sum, acc[128]) to HBM and -- with a ticket -- the fused combine by the workgroup that finishes last.
+__device__ __forceinline__ void finish_bag(char* smem, f32x4 (&pool)[8], float m_run, float l_lane, int nstep,
+                                           float* __restrict__ partials, unsigned* __restrict__ ticket,
+                                           const float* __restrict__ wcls, const float* __restrict__ bcls, int C,
+                                           float* __restrict__ M, float* __restrict__ logits, float* __restrict__ Y_prob,
+                                           int64_t* __restrict__ Y_hat) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    // every lane (li, g) holds the contribution of its rows to columns 16nf + 4g + e: sum over li (16 lanes);
+    // l: the 4 g-lanes of a row hold the same p, count each row once (g == 0) and sum over li
+    float l = g == 0 ? l_lane : 0.f;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        l += __shfl_xor(l, o, 64);
+#pragma unroll
+        for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pool[nf][e] += __shfl_xor(pool[nf][e], o, 64);
+    }
+    // merge the 4 waves of this workgroup through LDS (the weight images are dead now): slot w = (m, l, acc[128])
+    __syncthreads();
+    float* red = (float*)smem;
+    if (lane == 0) {
+        red[wave * 132] = nstep > 0 ? m_run : -INFINITY;
+        red[wave * 132 + 1] = l;
+    }
+    if (li == 0) {
+#pragma unroll
+        for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave * 132 + 2 + 16 * nf + 4 * g + e] = pool[nf][e];
+    }
+    __syncthreads();
+    if (tid < S1 + 2) {
+        const float m0 = red[0], m1 = red[132], m2 = red[264], m3 = red[396];
+        const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        float* pw = partials + (int64_t)blockIdx.x * (2 + S1);
+        // (agent-scope relaxed stores = global_store sc0 sc1: they leave the XCD's L2, so the merging workgroup can
+        //  read them with sc1 loads and no fence -- a device-scope release would write back the whole L2, 12 us here)
+        if (tid == 0) {
+            __hip_atomic_store(&pw[0], mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const float f0 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m0 - mm) * LOG2E);
+            const float f1 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m1 - mm) * LOG2E);
+            const float f2 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m2 - mm) * LOG2E);
+            const float f3 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m3 - mm) * LOG2E);
+            __hip_atomic_store(&pw[tid], red[tid] * f0 + red[132 + tid] * f1 + red[264 + tid] * f2 + red[396 + tid] * f3, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- fused combine (model_clam.py:180-183): the workgroup whose ticket is the last one merges all partials,
+    //      applies the bag classifier, softmax and argmax -- no second launch.  Hand-off without fences
+    //      (MI355X_MICROARCH.md, hand-off table row 1): sc1 stores, every storing wave waits vmcnt(0), workgroup
+    //      barrier, ONE agent-scope atomic per workgroup; the workgroup whose
+    //      add came last reads with sc1 loads after a workgroup barrier.
+    if (ticket) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = (int*)(red + 600);
+        if (tid == 0) *flag = atomicAdd(ticket, 1u) == gridDim.x - 1;
+        __syncthreads();
+        if (*flag) {
+            const int G = gridDim.x, stride = 2 + S1;
+            float* Fs = red + 640;    // [256] rescale factors
+            float* Cs = red + 1024;   // [8][128] column partial sums
+            float* Ms = red + 2048;   // [128]
+            float* Ls = red + 2176;   // [C <= 64]
+            float* wr = red + 2240;   // [4] wave reductions
+            // every load of the partials is an sc1 load (buffer loads with the sc1 cache-policy bit)
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)partials, 0, G * stride * 4, 0x00020000);
+            constexpr int SC1 = 16;
+            f32x2 ml = {-INFINITY, 0.f};  // (max, sum)
+            if (tid < G) {
+                ml[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, tid * stride * 4, 0, SC1));
+                ml[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, tid * stride * 4 + 4, 0, SC1));
+            }
+            float mx = wave_max(ml[0]);
+            if (lane == 0) wr[wave] = mx;
+            __syncthreads();
+            mx = fmaxf(fmaxf(wr[0], wr[1]), fmaxf(wr[2], wr[3]));
+            __syncthreads();
+            const float f = tid < G ? expf(ml[0] - mx) : 0.f;
+            Fs[tid] = f;
+            float ls = wave_sum(ml[1] * f);
+            if (lane == 0) wr[wave] = ls;
+            __syncthreads();
+            const float L = wr[0] + wr[1] + wr[2] + wr[3];
+            {   // column sums: 32 threads x 16 B cover one partial row, 8 rows per pass, 8 passes in flight
+                const int c4 = tid & 31, part = tid >> 5;
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+                for (int gi = part; gi < G; gi += 8)  // (rows are 520 B apart: 8-byte aligned -> two 8-byte loads)
+                    a += f32x4{0.f, 0.f, 0.f, 0.f} + ld4(prs, (gi * stride + 2 + 4 * c4) * 4) * Fs[gi];
+                *(f32x4*)(Cs + part * S1 + 4 * c4) = a;
+            }
+            __syncthreads();
+            if (tid < S1) {
+                float a = 0.f;
+#pragma unroll
+                for (int part = 0; part < 8; ++part) a += Cs[part * S1 + tid];
+                a /= L;
+                Ms[tid] = a;
+                M[tid] = a;
+            }
+            __syncthreads();
+            for (int k = wave; k < C; k += 4) {
+                float a = Ms[lane] * wcls[(int64_t)k * S1 + lane] + Ms[lane + 64] * wcls[(int64_t)k * S1 + lane + 64];
+                a = wave_sum(a);
+                if (lane == 0) Ls[k] = a + bcls[k];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float lm = -INFINITY;
+                int arg = 0;
+                for (int k = 0; k < C; ++k)
+                    if (Ls[k] > lm) {
+                        lm = Ls[k];
+                        arg = k;
+                    }
+                float se = 0.f;
+                for (int k = 0; k < C; ++k) se += expf(Ls[k] - lm);
+                for (int k = 0; k < C; ++k) {
+                    logits[k] = Ls[k];
+                    Y_prob[k] = expf(Ls[k] - lm) / se;
+                }
+                Y_hat[0] = arg;
+            }
+        }
+    }
+}
 
 template <int KS>  // S0 = 64 * KS
 __global__ __launch_bounds__(256, 1) void abmil_stream_kernel(const bf16_t* __restrict__ bag, int N, int rows_per_wave,
@@ -303,129 +438,352 @@ __global__ __launch_bounds__(256, 1) void abmil_stream_kernel(const bf16_t* __re
     }
     ASTAMP(5);
 
-    if (!attention_only) {
-        // every lane (li, g) holds the contribution of its rows to columns 16nf + 4g + e: sum over li (16 lanes);
-        // l: the 4 g-lanes of a row hold the same p, count each row once (g == 0) and sum over li
-        float l = g == 0 ? l_lane : 0.f;
+    if (!attention_only) finish_bag(smem, pool, m_run, l_lane, nstep, partials, ticket, wcls, bcls, C, M, logits, Y_prob, Y_hat);
+    ASTAMP(6);
+}
+
+
+// ======================================================================================================================
+// Software-pipelined form for S0 = 384 (the bench bag): the gate + pooling arithmetic of step s-1 (transcendental VALU
+// work, as long as the MFMAs of phase 1) runs UNDER the phase-1 MFMAs of step s.
+//   * phase 1 = 24 groups of 8 MFMAs (one W1 fragment set each, read one group ahead); group G < 16 carries gate unit G
+//     (2 rows x 2 gate pairs) of the previous step, group 16 the row logits / running max, groups 16-23 the pooling
+//     update of one 16-column block each;
+//   * the h1 accumulators therefore live for two steps: two sets, alternated by unrolling the loop twice;
+//   * the rows stream through ONE register image: the 16-byte chunks of k-step c are re-loaded for the next step as
+//     soon as step s has used them (buffer loads: rows past the wave's range read as zero without HBM traffic), so
+//     HBM requests spread over the whole step instead of bursting;
+//   * b1 and [ba;bb] enter as the C operands of the first MFMAs, wc through the same counted-wait LDS reads as W1.
+#define DSRN128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define DSRN64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define LGKMN(n)                                                \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); \
+    __builtin_amdgcn_sched_barrier(0)
+
+template <int I, int N, class F> __device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+
+// one gate unit: 2 gate pairs of one row; v = (a_j, a_j+1, b_j, b_j+1) with the biases already in, cw = wc[j], wc[j+1]
+__device__ __forceinline__ f32x2 gate_pair(const f32x4& v, const f32x2& cw) {
+    f32x2 x = {__builtin_amdgcn_fmed3f(v[0], -15.0f, 15.0f), __builtin_amdgcn_fmed3f(v[1], -15.0f, 15.0f)};
+    f32x2 y = {v[2], v[3]};
+    x *= 2.0f * LOG2E;
+    y *= -LOG2E;
+    const f32x2 E = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+    const f32x2 F = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+    const f32x2 num = (E - 1.0f) * cw, den = (E + 1.0f) * (F + 1.0f);
+    const f32x2 r = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    return num * r;
+}
+
+__global__ __launch_bounds__(256, 1) void abmil_pipe_kernel(const bf16_t* __restrict__ bag, int N, int rows_per_wave,
+                                                            const bf16_t* __restrict__ w1, const float* __restrict__ b1,
+                                                            const bf16_t* __restrict__ wab, const float* __restrict__ bab,
+                                                            const float* __restrict__ wc, const float* __restrict__ bc,
+                                                            float* __restrict__ A_raw, float* __restrict__ partials,
+                                                            int attention_only, unsigned long long* stamps, unsigned* __restrict__ ticket,
+                                                            const float* __restrict__ wcls, const float* __restrict__ bcls, int C,
+                                                            float* __restrict__ M, float* __restrict__ logits,
+                                                            float* __restrict__ Y_prob, int64_t* __restrict__ Y_hat) {
+    ASTAMP(0);
+    if (ticket && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    constexpr int KS = 6, S0 = 384, NC = 12;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // W1 image (6 slabs) | [Wa;Wb] image (2 slabs) | constants
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+
+    const int gw = blockIdx.x * 4 + wave;
+    const int rbeg = gw * rows_per_wave;
+    int rend = rbeg + rows_per_wave;
+    rend = rend < N ? rend : N;
+    const int nrows = rend > rbeg ? rend - rbeg : 0;
+    const int nstep = (nrows + 31) / 32;
+
+    // my rows through a buffer resource that ends with them: a chunk of a row past the end reads as zero, no traffic
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(bag + (int64_t)(nrows ? rbeg : 0) * S0), 0, nrows * S0 * 2, 0x00020000);
+    int voff[2];
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            l += __shfl_xor(l, o, 64);
+    for (int m = 0; m < 2; ++m) voff[m] = (m * 16 + li) * (S0 * 2) + g * 16;
+    u32x4 xf[2][NC];
 #pragma unroll
-            for (int nf = 0; nf < 8; ++nf)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pool[nf][e] += __shfl_xor(pool[nf][e], o, 64);
+        for (int m = 0; m < 2; ++m) xf[m][c] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[m] + c * 64, 0, 0);
+
+    // ---- stage the weights (LDS-DMA, swizzle on the source address) ----
+    {
+        const int r0 = wave * 8 + (lane >> 3);
+        const int ch0 = (lane & 7) ^ ((r0 >> 1) & 7);
+#pragma unroll
+        for (int kt = 0; kt < KS; ++kt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                glds16(w1 + (int64_t)(q * 32 + r0) * S0 + (kt * 8 + ch0) * 8, smem + kt * SLAB + (q * 4 + wave) * 1024);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = q * 32 + r0;  // packed gate row -> source row ((r&3)>>1)*S2 + (r>>2)*2 + (r&1)
+                const int srow = ((r & 3) >> 1) * S2 + (r >> 2) * 2 + (r & 1);
+                glds16(wab + (int64_t)srow * S1 + (sl * 8 + ch0) * 8, smem + (KS + sl) * SLAB + (q * 4 + wave) * 1024);
+            }
+    }
+    // constants -> LDS: b1[128] | gate bias in accumulator order [n2][g][(ba_j, ba_j+1, bb_j, bb_j+1)], j = 8 n2 + 2 g | wc[64]
+    float* cst = (float*)(smem + (KS + 2) * SLAB);
+    if (tid < S1) {
+        cst[tid] = b1[tid];
+        const int j = 8 * (tid >> 4) + 2 * ((tid >> 2) & 3) + (tid & 1);
+        cst[S1 + tid] = bab[(tid & 2) ? S2 + j : j];
+    } else if (tid < S1 + S2) {
+        cst[S1 + tid] = wc[tid - S1];
+    }
+    const float bcv = bc[0];
+    wait_vm0();
+    __syncthreads();  // weights are in LDS; from here on the waves never synchronise again
+    ASTAMP(1);
+
+    const uint32_t lbase = lds_addr(smem);
+    uint32_t foff[2], fhi[2], f2off[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        foff[ks] = lbase + li * 128 + (((g + 4 * ks) ^ ((lane >> 1) & 7)) << 4);
+        fhi[ks] = foff[ks] + 3 * SLAB;
+    }
+#pragma unroll
+    for (int fl = 0; fl < 2; ++fl)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int byte = 64 * fl + 32 * h + 8 * g;
+            f2off[fl][h] = lbase + KS * SLAB + li * 128 + (((byte >> 4) ^ ((lane >> 1) & 7)) << 4) + (byte & 8);
         }
-        // merge the 4 waves of this workgroup through LDS (the weight images are dead now): slot w = (m, l, acc[128])
-        __syncthreads();
-        float* red = (float*)smem;
-        if (lane == 0) {
-            red[wave * 132] = nstep > 0 ? m_run : -INFINITY;
-            red[wave * 132 + 1] = l;
-        }
-        if (li == 0) {
+    const uint32_t cwaddr = lbase + (KS + 2) * SLAB + (2 * S1 + 2 * g) * 4;  // wc[8 n2 + 2 g]: + 32 n2 bytes
+    const float* b1f = cst + 4 * g;                                            // b1[16 nf + 4 g ..]: + 16 nf floats
+    const float* gbf = cst + S1 + 4 * g;                                       // gate bias of (n2, g): + 16 n2 floats
+
+    float m_run = -INFINITY, l_lane = 0.f;
+    f32x4 pool[8];
 #pragma unroll
-            for (int nf = 0; nf < 8; ++nf)
+    for (int nf = 0; nf < 8; ++nf) pool[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accA[2][8], accB[2][8], acc2[2][8];
+    u32x4 hf[2][4];
+    f32x2 gs2[2];   // per-row logit partial sums of the step being gated
+    float p_row[2]; // softmax weights of its two rows
+    float resc = 0.f;
+
+    // logits of step sp from the finished gate sums; running max, rescale factor, the two softmax weights
+    auto gate_finish = [&](int sp) __attribute__((always_inline)) {
+        float a_row[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) red[wave * 132 + 2 + 16 * nf + 4 * g + e] = pool[nf][e];
+        for (int m = 0; m < 2; ++m) {
+            float gs = gs2[m][0] + gs2[m][1];
+            gs += __shfl_xor(gs, 16, 64);
+            gs += __shfl_xor(gs, 32, 64);
+            const int r = sp * 32 + m * 16 + li;
+            const bool valid = r < nrows;
+            a_row[m] = valid ? gs + bcv : -INFINITY;
+            if (valid && g == 0) A_raw[rbeg + r] = a_row[m];
         }
-        __syncthreads();
-        if (tid < S1 + 2) {
-            const float m0 = red[0], m1 = red[132], m2 = red[264], m3 = red[396];
-            const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-            float* pw = partials + (int64_t)blockIdx.x * (2 + S1);
-            // (agent-scope relaxed stores = global_store sc0 sc1: they leave the XCD's L2, so the merging workgroup can
-            //  read them with sc1 loads and no fence -- a device-scope release would write back the whole L2, 12 us here)
-            if (tid == 0) {
-                __hip_atomic_store(&pw[0], mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float mt = wave_max(fmaxf(a_row[0], a_row[1]));  // finite: every step has at least one valid row
+        const float m_new = fmaxf(m_run, mt);
+        resc = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);  // 0 on the first step
+        m_run = m_new;
+        p_row[0] = __builtin_amdgcn_exp2f((a_row[0] - m_new) * LOG2E);
+        p_row[1] = __builtin_amdgcn_exp2f((a_row[1] - m_new) * LOG2E);
+        l_lane = l_lane * resc + p_row[0] + p_row[1];
+    };
+
+    // phase 1 of step s into cur; with PIPE the gate / pooling of step s - 1 (acc2, prev) rides along
+    auto phase1 = [&](auto PIPE_, f32x4 (&cur)[2][8], f32x4 (&prev)[2][8], int s) __attribute__((always_inline)) {
+        constexpr bool PIPE = decltype(PIPE_)::value;
+#pragma unroll
+        for (int nf = 0; nf < 8; ++nf) {
+            const f32x4 b = *(const f32x4*)(b1f + 16 * nf);
+            cur[0][nf] = b;
+            cur[1][nf] = b;
+        }
+        if constexpr (PIPE) gs2[0] = gs2[1] = f32x2{0.f, 0.f};
+        // (the step offset travels in the VGPR offset: that is the part the range check certainly covers)
+        const int vnext[2] = {voff[0] + (s + 1) * 32 * S0 * 2, voff[1] + (s + 1) * 32 * S0 * 2};
+        u32x4 w[2][4];
+        f32x2 cw[2];
+        const uint32_t a00 = foff[0], a01 = foff[1], a10 = fhi[0], a11 = fhi[1], cwa = cwaddr;
+        // fragment set of group G: slab kt = G >> 2, k-step half ks = (G >> 1) & 1, hidden half q = G & 1
+#define RDG(G)                                                                       \
+    do {                                                                             \
+        constexpr int kt_ = (G) >> 2, ks_ = ((G) >> 1) & 1, q_ = (G)&1;              \
+        constexpr int o_ = (kt_ % 3) * 16384 + q_ * 8192;                            \
+        const uint32_t ad_ = kt_ < 3 ? (ks_ ? a01 : a00) : (ks_ ? a11 : a10);        \
+        DSRN128(w[(G)&1][0], ad_, o_);                                               \
+        DSRN128(w[(G)&1][1], ad_, o_ + 2048);                                        \
+        DSRN128(w[(G)&1][2], ad_, o_ + 4096);                                        \
+        DSRN128(w[(G)&1][3], ad_, o_ + 6144);                                        \
+        if constexpr (PIPE && (G) < 16) DSRN64(cw[(G)&1], cwa, ((G)&7) * 32);        \
+    } while (0)
+        RDG(0);
+        sfor<0, 24>([&](auto G_) __attribute__((always_inline)) {
+            constexpr int G = decltype(G_)::value;
+            constexpr int c = G >> 1, q = G & 1;
+            // fragment set G + 1 is requested before set G is waited for (counted: only its reads may be outstanding)
+            if constexpr (G + 1 < 24) {
+                RDG(G + 1);
+                if constexpr (PIPE && G + 1 < 16) {
+                    LGKMN(5);
+                } else {
+                    LGKMN(4);
+                }
             } else {
-                const float f0 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m0 - mm) * LOG2E);
-                const float f1 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m1 - mm) * LOG2E);
-                const float f2 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m2 - mm) * LOG2E);
-                const float f3 = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m3 - mm) * LOG2E);
-                __hip_atomic_store(&pw[tid], red[tid] * f0 + red[132 + tid] * f1 + red[264 + tid] * f2 + red[396 + tid] * f3, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+                LGKMN(0);
+            }
+            if constexpr (PIPE) {
+                if constexpr (G < 16) {
+                    gs2[G >> 3] += gate_pair(acc2[G >> 3][G & 7], cw[G & 1]);
+                } else {
+                    if constexpr (G == 16) gate_finish(s - 1);
+                    constexpr int nf = G - 16;
+                    pool[nf] = pool[nf] * resc + prev[0][nf] * p_row[0] + prev[1][nf] * p_row[1];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Tr<bf16_t>::mma16(cur[0][4 * q + j], w[G & 1][j], xf[0][c]);
+                Tr<bf16_t>::mma16(cur[1][4 * q + j], w[G & 1][j], xf[1][c]);
+            }
+            if constexpr (q == 1) {  // k-step c is done with its rows: request the next step's
+                xf[0][c] = __builtin_amdgcn_raw_buffer_load_b128(rs, vnext[0] + c * 64, 0, 0);
+                xf[1][c] = __builtin_amdgcn_raw_buffer_load_b128(rs, vnext[1] + c * 64, 0, 0);
+            }
+            if constexpr (PIPE) {  // an MFMA leaves 8 of its 16 cycles to other vector instructions: deal them out evenly
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#undef RDG
+    };
+
+    // h1 = ReLU(cur) in place (fp32, for the pooling one step later) and as operand fragments of the gate GEMM
+    auto relu_pack = [&](f32x4 (&cur)[2][8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cur[m][nf][e] = fmaxf(cur[m][nf][e], 0.f);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                u32x4 o;
+                o[0] = pack_bf16x2(cur[m][2 * f][0], cur[m][2 * f][1]);
+                o[1] = pack_bf16x2(cur[m][2 * f][2], cur[m][2 * f][3]);
+                o[2] = pack_bf16x2(cur[m][2 * f + 1][0], cur[m][2 * f + 1][1]);
+                o[3] = pack_bf16x2(cur[m][2 * f + 1][2], cur[m][2 * f + 1][3]);
+                hf[m][f] = o;
             }
         }
-        // ---- fused combine (model_clam.py:180-183): the workgroup whose ticket is the last one merges all partials,
-        //      applies the bag classifier, softmax and argmax -- no second launch.  Hand-off without fences
-        //      (MI355X_MICROARCH.md, hand-off table row 1): sc1 stores, every storing wave waits vmcnt(0), workgroup
-        //      barrier, ONE agent-scope atomic per workgroup; the workgroup whose
-        //      add came last reads with sc1 loads after a workgroup barrier.
-        if (ticket) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            int* flag = (int*)(red + 600);
-            if (tid == 0) *flag = atomicAdd(ticket, 1u) == gridDim.x - 1;
-            __syncthreads();
-            if (*flag) {
-                const int G = gridDim.x, stride = 2 + S1;
-                float* Fs = red + 640;    // [256] rescale factors
-                float* Cs = red + 1024;   // [8][128] column partial sums
-                float* Ms = red + 2048;   // [128]
-                float* Ls = red + 2176;   // [C <= 64]
-                float* wr = red + 2240;   // [4] wave reductions
-                // every load of the partials is an sc1 load (buffer loads with the sc1 cache-policy bit)
-                const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)partials, 0, G * stride * 4, 0x00020000);
-                constexpr int SC1 = 16;
-                f32x2 ml = {-INFINITY, 0.f};  // (max, sum)
-                if (tid < G) {
-                    ml[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, tid * stride * 4, 0, SC1));
-                    ml[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, tid * stride * 4 + 4, 0, SC1));
-                }
-                float mx = wave_max(ml[0]);
-                if (lane == 0) wr[wave] = mx;
-                __syncthreads();
-                mx = fmaxf(fmaxf(wr[0], wr[1]), fmaxf(wr[2], wr[3]));
-                __syncthreads();
-                const float f = tid < G ? expf(ml[0] - mx) : 0.f;
-                Fs[tid] = f;
-                float ls = wave_sum(ml[1] * f);
-                if (lane == 0) wr[wave] = ls;
-                __syncthreads();
-                const float L = wr[0] + wr[1] + wr[2] + wr[3];
-                {   // column sums: 32 threads x 16 B cover one partial row, 8 rows per pass, 8 passes in flight
-                    const int c4 = tid & 31, part = tid >> 5;
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-                    for (int gi = part; gi < G; gi += 8)  // (rows are 520 B apart: 8-byte aligned -> two 8-byte loads)
-                        a += f32x4{0.f, 0.f, 0.f, 0.f} + ld4(prs, (gi * stride + 2 + 4 * c4) * 4) * Fs[gi];
-                    *(f32x4*)(Cs + part * S1 + 4 * c4) = a;
-                }
-                __syncthreads();
-                if (tid < S1) {
-                    float a = 0.f;
+    };
+
+    // phase 2: acc2 = [ba;bb] + h1 [Wa;Wb]^T (8 groups of 8 MFMAs; fragment f = 2 slab + fl covers hidden [32f, 32f+32))
+    auto phase2 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-                    for (int part = 0; part < 8; ++part) a += Cs[part * S1 + tid];
-                    a /= L;
-                    Ms[tid] = a;
-                    M[tid] = a;
-                }
-                __syncthreads();
-                for (int k = wave; k < C; k += 4) {
-                    float a = Ms[lane] * wcls[(int64_t)k * S1 + lane] + Ms[lane + 64] * wcls[(int64_t)k * S1 + lane + 64];
-                    a = wave_sum(a);
-                    if (lane == 0) Ls[k] = a + bcls[k];
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    float lm = -INFINITY;
-                    int arg = 0;
-                    for (int k = 0; k < C; ++k)
-                        if (Ls[k] > lm) {
-                            lm = Ls[k];
-                            arg = k;
-                        }
-                    float se = 0.f;
-                    for (int k = 0; k < C; ++k) se += expf(Ls[k] - lm);
-                    for (int k = 0; k < C; ++k) {
-                        logits[k] = Ls[k];
-                        Y_prob[k] = expf(Ls[k] - lm) / se;
-                    }
-                    Y_hat[0] = arg;
-                }
+        for (int n2 = 0; n2 < 8; ++n2) {
+            const f32x4 b = *(const f32x4*)(gbf + 16 * n2);
+            acc2[0][n2] = b;
+            acc2[1][n2] = b;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        u32x2 wl[2][4], wh[2][4];
+        const uint32_t b00 = f2off[0][0], b01 = f2off[0][1], b10 = f2off[1][0], b11 = f2off[1][1];
+#define RD2(G)                                                                     \
+    do {                                                                           \
+        constexpr int f_ = (G) >> 1, q_ = (G)&1;                                   \
+        constexpr int o_ = (f_ >> 1) * 16384 + q_ * 8192;                          \
+        const uint32_t lo_ = (f_ & 1) ? b10 : b00, hi_ = (f_ & 1) ? b11 : b01;     \
+        DSRN64(wl[(G)&1][0], lo_, o_);        DSRN64(wh[(G)&1][0], hi_, o_);        \
+        DSRN64(wl[(G)&1][1], lo_, o_ + 2048); DSRN64(wh[(G)&1][1], hi_, o_ + 2048); \
+        DSRN64(wl[(G)&1][2], lo_, o_ + 4096); DSRN64(wh[(G)&1][2], hi_, o_ + 4096); \
+        DSRN64(wl[(G)&1][3], lo_, o_ + 6144); DSRN64(wh[(G)&1][3], hi_, o_ + 6144); \
+    } while (0)
+        RD2(0);
+        sfor<0, 8>([&](auto G_) __attribute__((always_inline)) {
+            constexpr int G = decltype(G_)::value;
+            constexpr int f = G >> 1, q = G & 1;
+            if constexpr (G + 1 < 8) {
+                RD2(G + 1);
+                LGKMN(8);
+            } else {
+                LGKMN(0);
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x4 wf;
+                wf[0] = wl[G & 1][j][0]; wf[1] = wl[G & 1][j][1]; wf[2] = wh[G & 1][j][0]; wf[3] = wh[G & 1][j][1];
+                Tr<bf16_t>::mma16(acc2[0][4 * q + j], wf, hf[0][f]);
+                Tr<bf16_t>::mma16(acc2[1][4 * q + j], wf, hf[1][f]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#undef RD2
+    };
+
+    // gate + pooling of the last step: nothing left to hide it under
+    auto drain = [&](f32x4 (&prev)[2][8], int sp) __attribute__((always_inline)) {
+        // (all 16 units first, then the sums: summed as it goes, the chain of transcendentals runs at its latency)
+        f32x2 u[2][8];
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) {
+            const f32x2 cwv = *(const f32x2*)(cst + 2 * S1 + 8 * n2 + 2 * g);
+            u[0][n2] = gate_pair(acc2[0][n2], cwv);
+            u[1][n2] = gate_pair(acc2[1][n2], cwv);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {  // same order of additions as the overlapped form: bit-identical logits
+            gs2[m] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) gs2[m] += u[m][n2];
+        }
+        gate_finish(sp);
+#pragma unroll
+        for (int nf = 0; nf < 8; ++nf) pool[nf] = pool[nf] * resc + prev[0][nf] * p_row[0] + prev[1][nf] * p_row[1];
+    };
+
+    constexpr std::false_type PLAIN{};
+    constexpr std::true_type OVERLAP{};
+    if (nstep > 0) {
+        ASTAMP(2);
+        phase1(PLAIN, accA, accB, 0);
+        ASTAMP(3);
+        relu_pack(accA);
+        phase2();
+        ASTAMP(4);
+        int s = 1;
+        for (; s + 1 < nstep; s += 2) {
+            phase1(OVERLAP, accB, accA, s);
+            relu_pack(accB);
+            phase2();
+            phase1(OVERLAP, accA, accB, s + 1);
+            relu_pack(accA);
+            phase2();
+        }
+        if (s < nstep) {
+            phase1(OVERLAP, accB, accA, s);
+            relu_pack(accB);
+            phase2();
+            drain(accB, s);
+        } else {
+            drain(accA, s - 1);
         }
     }
+    ASTAMP(5);
+    // (attention_only runs the same arithmetic -- its logits are bit-identical to a full forward's -- and stops here)
+    if (!attention_only) finish_bag(smem, pool, m_run, l_lane, nstep, partials, ticket, wcls, bcls, C, M, logits, Y_prob, Y_hat);
     ASTAMP(6);
 }
 
@@ -451,6 +809,22 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
     static unsigned long long* dbuf = nullptr;
     if (want_stamps && !dbuf) (void)hipMalloc(&dbuf, 512 * 8 * sizeof(unsigned long long));
     const bool fuse = !attention_only && ticket && M && w->n_classes <= 64 && grid <= 256;
+    static const bool no_pipe = getenv("HIPT_NO_ABMIL_PIPE") != nullptr;
+    const bool piped = KS == 6 && !no_pipe;
+    if (piped) {
+        auto kp = abmil_pipe_kernel;
+        static bool attr_p = false;
+        if (!attr_p) {
+            if (hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+                hipt_set_error("hipFuncSetAttribute(abmil pipe) failed");
+                return HIPT_E_LAUNCH;
+            }
+            attr_p = true;
+        }
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(256), lds, st, (const bf16_t*)bag, N, rows, (const bf16_t*)w->w1, w->b1,
+                           (const bf16_t*)w->wab, w->bab, w->wc, w->bc, A_raw, partials, attention_only,
+                           want_stamps ? dbuf : nullptr, fuse ? ticket : nullptr, w->wcls, w->bcls, w->n_classes, M, logits, Y_prob, Y_hat);
+    } else
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (const bf16_t*)bag, N, rows, (const bf16_t*)w->w1, w->b1,
                        (const bf16_t*)w->wab, w->bab, w->wc, w->bc, A_raw, partials, attention_only, want_stamps ? dbuf : nullptr,
                        fuse ? ticket : nullptr, w->wcls, w->bcls, w->n_classes, M, logits, Y_prob, Y_hat);
@@ -470,8 +844,10 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
             const double s0 = (double)(h[b * 8] - t0) * 0.01;
             if (s0 > smax) smax = s0;
         }
-        fprintf(stderr, "[abmil stream N=%d grid=%d rows/wave=%d] total %.1f us | start<=%.1f; weights->LDS %.1f; issue loads %.1f; step0 %.1f; step1 %.1f; steps2+ %.1f; final %.1f\n",
-                N, grid, rows, (double)(t6 - t0) * 0.01, smax, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
+        fprintf(stderr, "[abmil %s N=%d grid=%d rows/wave=%d] total %.1f us | start<=%.1f; weights->LDS %.1f; %s %.1f / %.1f / %.1f / %.1f; final %.1f\n",
+                piped ? "pipe" : "stream", N, grid, rows, (double)(t6 - t0) * 0.01, smax, ph[0],
+                piped ? "- / step 0 phase 1 / its gate GEMM / steps 1.. + drain:" : "issue loads / step 0 / step 1 / steps 2..:", ph[1], ph[2], ph[3],
+                ph[4], ph[5]);
     }
     *n_partials = fuse ? 0 : grid;  // 0: the kernel has already produced M / logits / Y_prob / Y_hat
     return HIPT_OK;
