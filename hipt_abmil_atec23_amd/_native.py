@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 
 HIPT_F32, HIPT_BF16 = 0, 1
 EPI_GELU, EPI_RESID, EPI_OUT_F32, EPI_RELU = 1, 2, 4, 16
-ABI_VERSION = 1
+ABI_VERSION = 2
+PACK_QKV, PACK_PROJ, PACK_MLP = 0, 1, 2
 
 c_f32p = C.c_void_p  # device pointers travel as integers
 
@@ -25,7 +26,7 @@ c_f32p = C.c_void_p  # device pointers travel as integers
 class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
-        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "qkv_pk", "proj_pk", "mlp_pk")]
 
 
 class VitWeights(C.Structure):
@@ -62,6 +63,8 @@ SIGNATURES = {
     "hipt_linear": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "hipt_attention": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "hipt_vit_workspace_bytes": (_sz, [_VW, _i]),
+    "hipt_vit_packed_bytes": (_sz, [_VW, _i]),
+    "hipt_vit_pack_weights": (_i, [_VW, _i, _i, _p, _p]),
     "hipt_vit256_forward_workspace_bytes": (_sz, [_VW, _IL, _i, _i]),
     "hipt_vit4k_forward_workspace_bytes": (_sz, [_VW, _i]),
     "hipt_vit256_prepare_tokens": (_i, [_VW, _p, _IL, _i, _i, _p, _p, _sz, _p]),

@@ -150,7 +150,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             SeqGemmParams q;
             memset(&q, 0, sizeof(q));
             q.M = M; q.K = D; q.ln_eps = w->ln_eps;
-            q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.N = 3 * D; q.bias = b.qkv_b;
+            q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.wpk = b.qkv_pk; q.N = 3 * D; q.bias = b.qkv_b;
             q.out = s.qkv; q.ldc = 3 * D;
             // (the hidden tensor is never materialised on this path: its slot holds the kernels' tile queues)
             q.counter = (int*)s.hid + 16;
@@ -162,13 +162,13 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             }
             PROF(cATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st));
             if (last_probs) break;
-            q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
+            q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
             q.counter = (int*)s.hid + 32;
             PROF(cPROJ, hipt_seqgemm_launch(q, false, 0, st));
             MlpParams m;
             memset(&m, 0, sizeof(m));
             m.x = x; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
-            m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.M = M; m.D = D; m.hidden = w->hidden;
+            m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.M = M; m.D = D; m.hidden = w->hidden;
             m.counter = (int*)s.hid;
             have_xn = chain && (i + 1 < b1 || emit_last) && i + 1 < w->depth;
             if (have_xn) {
@@ -210,7 +210,7 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
     SeqGemmParams q;
     memset(&q, 0, sizeof(q));
     q.M = M; q.K = D; q.ln_eps = w->ln_eps;
-    q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.N = 3 * D; q.bias = b.qkv_b;
+    q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.wpk = b.qkv_pk; q.N = 3 * D; q.bias = b.qkv_b;
     q.out = s.qkv; q.ldc = 3 * D;
     q.counter = (int*)s.hid + 16;
     if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue (bf16 operands in s.att)
@@ -221,13 +221,13 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
     }
     PROF(PC_ATTN, hipt_attn_cls_launch(s.qkv, s.att, nullptr, nseq, w->ntok, w->heads, D / w->heads, 1.0f / sqrtf((float)(D / w->heads)), st));
     PROF(PC_OTHER, hipt_gather_cls_launch(x, xc, nseq, (int64_t)w->ntok * D, D, st));
-    q.M = nseq; q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
+    q.M = nseq; q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
     q.counter = (int*)s.hid + 32;
     PROF(PC_PROJ, hipt_seqgemm_launch(q, false, 0, st));
     MlpParams m;
     memset(&m, 0, sizeof(m));
     m.x = xc; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
-    m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.M = nseq; m.D = D; m.hidden = w->hidden;
+    m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.M = nseq; m.D = D; m.hidden = w->hidden;
     m.counter = (int*)s.hid;
     PROF(PC_MLP, hipt_mlp_launch(m, st));
     return HIPT_OK;
@@ -448,7 +448,7 @@ int hipt_vit_cls_attention(const hipt_vit_weights* w, float* x, int nseq, float*
     SeqGemmParams q;
     memset(&q, 0, sizeof(q));
     q.M = nseq * w->ntok; q.K = D; q.ln_eps = w->ln_eps;
-    q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.N = 3 * D; q.bias = b.qkv_b;
+    q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.wpk = b.qkv_pk; q.N = 3 * D; q.bias = b.qkv_b;
     q.out = s.qkv; q.ldc = 3 * D;
     q.counter = (int*)s.hid + 16;
     if (have_xn) {
@@ -456,6 +456,36 @@ int hipt_vit_cls_attention(const hipt_vit_weights* w, float* x, int nseq, float*
     }
     if ((rc = hipt_seqgemm_launch(q, !have_xn, 0, st))) return rc;
     return hipt_attn_cls_launch(s.qkv, nullptr, probs_cls, nseq, w->ntok, w->heads, dh, 1.0f / sqrtf((float)dh), st);
+}
+
+size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {
+    if (!w || w->dtype != HIPT_BF16) return 0;
+    const int D = w->dim;
+    switch (what) {
+        case HIPT_PACK_QKV: return hipt_seqgemm_pipe_supported(w->dtype, D, 3 * D, false, 0) ? (size_t)3 * D * D * 2 : 0;
+        case HIPT_PACK_PROJ: return hipt_seqgemm_pipe_supported(w->dtype, D, D, false, 0) ? (size_t)D * D * 2 : 0;
+        case HIPT_PACK_MLP: return hipt_mlp_pipe_supported(w->dtype, D, w->hidden) ? (size_t)2 * D * w->hidden * 2 : 0;
+        default: return 0;
+    }
+}
+
+int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* out, void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(block >= 0 && block < w->depth, "vit_pack_weights: block %d of %d", block, w->depth);
+    HIPT_CHECK_ARG(out != nullptr, "vit_pack_weights: null output");
+    if (hipt_vit_packed_bytes(w, what) == 0) {
+        hipt_set_error("vit_pack_weights: matrix %d of this ViT (dtype %d, D=%d, hidden=%d) has no packed form", what, w->dtype, w->dim, w->hidden);
+        return HIPT_E_UNSUPPORTED;
+    }
+    const hipt_block_weights& b = w->blocks[block];
+    const int D = w->dim;
+    hipStream_t st = S(stream);
+    switch (what) {
+        case HIPT_PACK_QKV: return hipt_seqgemm_pack_launch(b.qkv_w, 3 * D, D, out, st);
+        case HIPT_PACK_PROJ: return hipt_seqgemm_pack_launch(b.proj_w, D, D, out, st);
+        default: return hipt_mlp_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
+    }
 }
 
 int hipt_vit_head(const hipt_vit_weights* w, const float* x, int nseq, int cls_only, float* out, void* stream) {

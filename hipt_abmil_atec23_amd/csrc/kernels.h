@@ -37,6 +37,7 @@ struct SeqGemmParams {
     const float* ln_b;
     float ln_eps;
     const void* W;       // bf16 [N, K]
+    const void* wpk;     // optional (pipelined kernel only): W pre-packed in ring order (hipt_seqgemm_pack_launch)
     int M, N, K;
     unsigned long long* stamps;  // debug: per-workgroup phase timestamps (100 MHz), or null
     int debug;           // HIPT_SEQGEMM_DEBUG bits: 1 = skip epilogue stores, 2 = skip A load (zeros)
@@ -52,6 +53,9 @@ bool hipt_seqgemm_supported(int dtype, int K);
 int hipt_seqgemm_launch(const SeqGemmParams& p, bool ln, int flags, hipStream_t st);  // dispatches to the pipelined kernel when it applies
 bool hipt_seqgemm_pipe_supported(int dtype, int K, int N, bool ln, int flags);
 int hipt_seqgemm_pipe_launch(const SeqGemmParams& p, bool ln, hipStream_t st);
+// W as ONE contiguous image (N * K bf16, re-ordered): ring unit (N tile nt, k half kh) at byte (2 nt + kh) * 48 KiB,
+// byte for byte what its LDS slot holds -- a DMA piece reads 1 KiB of consecutive bytes (see hipt_mlp_pack_launch).
+int hipt_seqgemm_pack_launch(const void* W, int N, int K, void* packed, hipStream_t st);
 
 // Fused MLP sub-block (mlp.hip): x <- x + y1 + fc2(GELU(fc1(LN2(x + y1))))
 struct MlpParams {
@@ -65,6 +69,7 @@ struct MlpParams {
     const void* w2;      // bf16 [D, hidden]
     const float* b2;
     int M, D, hidden;
+    const void* wpk;     // optional (pipelined kernel only): both weights pre-packed in ring order (hipt_mlp_pack_launch)
     int* counter;        // device int the launcher zeroes on the stream: the kernel's tile queue
     // optional (pipelined kernel only): LayerNorm-1 of the NEXT block applied to the updated rows, written as bf16
     // [M, D] -- the next block's QKV GEMM then loads operands directly instead of fp32 rows + LayerNorm
@@ -80,6 +85,10 @@ bool hipt_mlp_supported(int dtype, int D, int hidden);
 int hipt_mlp_launch(const MlpParams& p, hipStream_t st);  // dispatches to the pipelined D = 384 kernel when it applies
 bool hipt_mlp_pipe_supported(int dtype, int D, int hidden);
 int hipt_mlp_pipe_launch(const MlpParams& p, hipStream_t st);
+// The pipelined kernel's weight stream as ONE contiguous image (2 * hidden * D bf16 = the two matrices, re-ordered):
+// unit after unit in the order a tile pass consumes them, each unit byte for byte what its LDS ring slot holds.
+// A DMA piece then reads 1 KiB of consecutive bytes instead of 8 row segments of 128 B (2.4x the L2 -> LDS rate).
+int hipt_mlp_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);
 
 int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, const float* b, void* out, int out_dtype,
                           int64_t out_stride, int rows, int D, float eps, hipStream_t st);

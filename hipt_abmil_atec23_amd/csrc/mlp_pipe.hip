@@ -33,6 +33,18 @@
 #include "mlp_common.h"
 #include "pipe_common.h"
 
+// activations are touched once per launch: loaded / stored with the non-temporal hint they do not push the weight image
+// (re-read by every workgroup, every tile) out of the L2
+#ifndef MLP_NT  // (measured: the hint makes the row phases 11 % SLOWER on MI355X -- kept as an experiment switch)
+#define NT_LD(p) (*(p))
+#define NT_ST(v, p) (*(p) = (v))
+#else
+#define NT_LD(p) __builtin_nontemporal_load(p)
+#define NT_ST(v, p) __builtin_nontemporal_store(v, p)
+#endif
+#ifndef MLP_DMA_SCHED
+#define MLP_DMA_SCHED 0
+#endif
 namespace {
 
 constexpr int D = 384, NCH = 12, NF2 = 24, TMR = 128;
@@ -45,9 +57,76 @@ constexpr int SLAB = 16384, UNIT = 3 * SLAB;
 
 enum { KA = 0, KB = 1 };            // phase kind: fc1 half / fc2 half
 
+// Where the weights of ring unit `pos` of a tile pass come from.  Positions: A0(0) A1(0) B0(0) | A0(c) B1(c-1) A1(c)
+// B0(c) ... | B1(n-1); an A unit = 64 hidden rows x all k of W1 (slab j: k [128j, +128)), a B unit = all 384 output rows
+// of W2 x 64 hidden (slab j: outputs [128j, +128)).  Byte offsets: piece (j, q) of the unit starts at
+// base + j * joff + (q & 1) * q1 + (q >> 1) * q2 (+ the per-lane part).
+struct UnitSrc {
+    bool is_a;
+    int base, joff, q1, q2;
+};
+__device__ __forceinline__ UnitSrc unit_src(int pos, int nchunk, int hidden) {
+    const int upt = 4 * nchunk;
+    bool is_a;
+    int c, h;
+    if (pos < 3) {
+        c = 0;
+        is_a = pos < 2;
+        h = pos == 1 ? 1 : 0;
+    } else if (pos == upt - 1) {
+        c = nchunk - 1;
+        is_a = false;
+        h = 1;
+    } else {
+        const int m = pos - 3, r = m & 3;
+        c = 1 + (m >> 2);
+        is_a = (r & 1) == 0;
+        h = r == 2 ? 1 : (r == 1 ? 1 : 0);
+        if (r == 1) c -= 1;
+    }
+    UnitSrc u;
+    u.is_a = is_a;
+    if (is_a) {  // hidden rows [128c + 64h, +64) x all k
+        u.base = (c * 128 + 64 * h) * D * 2;
+        u.joff = 128 * 2;
+        u.q1 = 32 * D * 2;
+        u.q2 = 64 * 2;
+    } else {  // output rows [128j, +128) x hidden [128c + 64h, +64)
+        u.base = (c * 128 + 64 * h) * 2;
+        u.joff = 128 * hidden * 2;
+        u.q1 = 32 * hidden * 2;
+        u.q2 = 64 * hidden * 2;
+    }
+    return u;
+}
+// per-lane part: LDS row R = wave*8 + (lane>>3) + 32q of a slab holds matrix row U(R) (the fragment-pair permutation,
+// see the kernel), and the lane's 16-byte chunk is its LDS chunk position XOR ((R>>1)&7)
+__device__ __forceinline__ void lane_src(int wave, int lane, int hidden, int& off_a, int& off_b) {
+    const int r0 = wave * 8 + (lane >> 3);
+    const int ch0 = (lane & 7) ^ ((r0 >> 1) & 7);
+    const int urow = 32 * (r0 >> 5) + 8 * ((r0 >> 2) & 3) + 4 * ((r0 >> 4) & 1) + (r0 & 3);
+    off_a = (urow * D + ch0 * 8) * 2;
+    off_b = (urow * hidden + ch0 * 8) * 2;
+}
+
+// one thread per 16-byte chunk of the packed image
+__global__ void mlp_pack_kernel(const char* __restrict__ w1, const char* __restrict__ w2, int hidden, char* __restrict__ out) {
+    const int nchunk = hidden / 128, upt = 4 * nchunk;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // chunk index
+    if (i >= (int64_t)upt * (UNIT / 16)) return;
+    const int pos = (int)(i / (UNIT / 16)), o = (int)(i % (UNIT / 16)) * 16;  // byte offset inside the unit
+    const int j = o / SLAB, pw = (o % SLAB) / 1024, q = pw >> 2, wave = pw & 3, lane = (o % 1024) / 16;
+    const UnitSrc u = unit_src(pos, nchunk, hidden);
+    int la, lb;
+    lane_src(wave, lane, hidden, la, lb);
+    const int src = u.base + j * u.joff + (q & 1) * u.q1 + (q >> 1) * u.q2 + (u.is_a ? la : lb);
+    *(u32x4*)(out + (int64_t)pos * UNIT + o) = *(const u32x4*)((u.is_a ? w1 : w2) + src);
+}
+
 // DBG (tools/mlp_probe.hip only): 1 = no weight DMA / ring syncs, 2 = GELU replaced by a plain pack,
 // 4 = no LDS fragment reads / MFMAs.
-template <int DBG = 0>
+// PACKED: the weights come from the pre-packed image p.wpk (a DMA piece = 1 KiB of consecutive bytes) instead of W1 / W2.
+template <int DBG = 0, bool PACKED = false>
 __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gam = (float*)(smem + 3 * UNIT);
@@ -67,57 +146,42 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
     //      16-byte chunk a lane fetches is its LDS chunk position XOR ((R>>1)&7) (same for every q) ----
     const bf16_t* W1 = (const bf16_t*)p.w1;
     const bf16_t* W2 = (const bf16_t*)p.w2;
-    const int r0 = wave * 8 + (lane >> 3);
-    const int ch0 = (lane & 7) ^ ((r0 >> 1) & 7);
     // A slab: 64 hidden x 128 k, LDS row R = 64*khalf + rho.  MFMA row rho = 16nf + 4g' + e of the half holds hidden
     // unit U(rho) = 32(nf>>1) + 8g' + 4(nf&1) + e: lane g' then owns, over the fragment pair (2f, 2f+1), hidden
     // 32f + 8g' + (0..7).  U(rho + 32) = U(rho) + 32, so piece q still only adds a uniform offset.
-    const int urow = 32 * (r0 >> 5) + 8 * ((r0 >> 2) & 3) + 4 * ((r0 >> 4) & 1) + (r0 & 3);
     // per-lane BYTE offsets into W1 (A slabs) and W2 (B slab: 128 outputs x 64 hidden, LDS row R = output U(R)), both multiples
     // of 16 and < 2^20: packed into ONE register (two loop-invariant registers were being spilled and re-loaded from
-    // scratch, with a vmcnt(0), once per phase); everything else about a DMA address is wave-uniform
-    const uint32_t lanepack = ((uint32_t)(urow * D + ch0 * 8) >> 3) | (((uint32_t)(urow * p.hidden + ch0 * 8) >> 3) << 16);
+    // scratch, with a vmcnt(0), once per phase); everything else about a DMA address is wave-uniform.
+    // With a pre-packed image (p.wpk) a piece is 1 KiB of consecutive bytes: the lane part is wave * 1024 + lane * 16.
+    int la_, lb_;
+    lane_src(wave, lane, p.hidden, la_, lb_);
+    constexpr bool packed = PACKED;
+    const uint32_t lanepack = packed ? (uint32_t)(wave * 64 + lane) : (((uint32_t)la_ >> 4) | (((uint32_t)lb_ >> 4) << 16));
     // issue side of the ring: the unit whose 12 pieces per wave are being issued
     // buffer-addressed LDS-DMA: resource = whole matrix (scalar registers), per-lane offset in ONE 32-bit register,
     // everything else (unit, slab, piece) in the scalar offset -> no vector address arithmetic per piece
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)W1, 0, p.hidden * D * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)W2, 0, p.hidden * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(packed ? (void*)p.wpk : (void*)W1, 0, (packed ? 2 : 1) * p.hidden * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(packed ? (void*)p.wpk : (void*)W2, 0, (packed ? 2 : 1) * p.hidden * D * 2, 0x00020000);
     bool ia = true;        // the unit being issued is an fc1 unit
     uint32_t ilane = 0;    // per-lane byte offset
     int ioff = 0, ijoff = 0, iq1 = 0, iq2 = 0;  // bytes, wave-uniform
     int islot = 0, ipos = 0;
-    // position i of a tile pass -> which weights: A0(0) A1(0) B0(0) | A0(c) B1(c-1) A1(c) B0(c) ... | B1(n-1)
     auto set_issue = [&](int pos, int slot) {
-        bool is_a;
-        int c, h;
-        if (pos < 3) {
-            c = 0;
-            is_a = pos < 2;
-            h = pos == 1 ? 1 : 0;
-        } else if (pos == upt - 1) {
-            c = nchunk - 1;
-            is_a = false;
-            h = 1;
+        if constexpr (packed) {  // unit pos of the image, laid out exactly like its ring slot
+            ia = true;
+            ioff = pos * UNIT;
+            ilane = lanepack << 4;
+            ijoff = SLAB;
+            iq1 = 4096;
+            iq2 = 8192;
         } else {
-            const int m = pos - 3, r = m & 3;
-            c = 1 + (m >> 2);
-            is_a = (r & 1) == 0;
-            h = r == 2 ? 1 : (r == 1 ? 1 : 0);
-            if (r == 1) c -= 1;
-        }
-        ia = is_a;
-        if (is_a) {  // hidden rows [128c + 64h, +64) x all k; slab j covers k [128j, +128)
-            ioff = (c * 128 + 64 * h) * D * 2;
-            ilane = (lanepack & 0xffffu) << 4;
-            ijoff = 128 * 2;
-            iq1 = 32 * D * 2;
-            iq2 = 64 * 2;
-        } else {  // output rows [128j, +128) x hidden [128c + 64h, +64)
-            ioff = (c * 128 + 64 * h) * 2;
-            ilane = (lanepack >> 16) << 4;
-            ijoff = 128 * p.hidden * 2;
-            iq1 = 32 * p.hidden * 2;
-            iq2 = 64 * p.hidden * 2;
+            const UnitSrc u = unit_src(pos, nchunk, p.hidden);
+            ia = u.is_a;
+            ioff = u.base;
+            ijoff = u.joff;
+            iq1 = u.q1;
+            iq2 = u.q2;
+            ilane = (u.is_a ? (lanepack & 0xffffu) : (lanepack >> 16)) << 4;
         }
         islot = slot;
     };
@@ -163,8 +227,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
         set_issue(0, 0);
         sfor<0, 12>(dma_piece);
         set_issue(1, 1);  // its other ten pieces go out in groups 0..4 of the first phase, as in steady state
-        dma_piece(std::integral_constant<int, 0>{});
-        dma_piece(std::integral_constant<int, 1>{});
+        sfor<0, (MLP_DMA_SCHED == 1 ? 4 : MLP_DMA_SCHED == 2 ? 3 : 2)>(dma_piece);
         ipos = 2;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -230,14 +293,14 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
             f32x4 v[NCH][2];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                v[c][0] = *(const f32x4*)(xr + (g + 4 * c) * 8);
-                v[c][1] = *(const f32x4*)(xr + (g + 4 * c) * 8 + 4);
+                v[c][0] = NT_LD((const f32x4*)(xr + (g + 4 * c) * 8));
+                v[c][1] = NT_LD((const f32x4*)(xr + (g + 4 * c) * 8 + 4));
             }
             if (p.y1) {
                 const bf16_t* yr = (const bf16_t*)p.y1 + (int64_t)(row0 + r) * D;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const bf16x8 y = __builtin_bit_cast(bf16x8, *(const u32x4*)(yr + (g + 4 * c) * 8));
+                    const bf16x8 y = __builtin_bit_cast(bf16x8, NT_LD((const u32x4*)(yr + (g + 4 * c) * 8)));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[c][0][e] += (float)y[e];
@@ -354,6 +417,19 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
                             for (int mf = 0; mf < 2; ++mf) Tr<bf16_t>::mma16(acc2[mf][8 * j + q0 + jj], wA[set][jj], hf[mf][2 * h + fl]);
                     }
                 }
+#if MLP_DMA_SCHED == 1
+                if constexpr (gg == 11) {
+                    sfor<0, 4>(dma_piece);
+                } else if constexpr (gg <= 1) {
+                    sfor<4 + 4 * gg, 8 + 4 * gg>(dma_piece);
+                }
+#elif MLP_DMA_SCHED == 2
+                if constexpr (gg == 11) {
+                    sfor<0, 3>(dma_piece);
+                } else if constexpr (gg <= 2) {
+                    sfor<3 + 3 * gg, 6 + 3 * gg>(dma_piece);
+                }
+#else
                 if constexpr (gg == 11) {
                     dma_piece(std::integral_constant<int, 0>{});
                     dma_piece(std::integral_constant<int, 1>{});
@@ -361,7 +437,10 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
                     dma_piece(std::integral_constant<int, 2 + 2 * gg>{});
                     dma_piece(std::integral_constant<int, 3 + 2 * gg>{});
                 }
-                if constexpr (gh >= 0 && gg >= 4) gelu_unit(std::integral_constant<int, (gh >= 0 ? gh : 0)>{}, std::integral_constant<int, 8 * gsec + gg - 4>{});
+#endif
+                if constexpr (gh >= 0 && gg >= 4) {
+                    gelu_unit(std::integral_constant<int, (gh >= 0 ? gh : 0)>{}, std::integral_constant<int, 8 * gsec + gg - 4>{});
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
             cons += 1;
@@ -414,10 +493,10 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
             f32x4 xv[NF2];  // the row's old values, then (in place) its new ones
             u32x4 yv[NF2 / 2];
 #pragma unroll
-            for (int nf = 0; nf < NF2; ++nf) xv[nf] = *(const f32x4*)(xr + 32 * (nf >> 1) + 4 * (nf & 1));
+            for (int nf = 0; nf < NF2; ++nf) xv[nf] = NT_LD((const f32x4*)(xr + 32 * (nf >> 1) + 4 * (nf & 1)));
             if (p.y1) {
 #pragma unroll
-                for (int pr = 0; pr < NF2 / 2; ++pr) yv[pr] = *(const u32x4*)(yr + 32 * pr);
+                for (int pr = 0; pr < NF2 / 2; ++pr) yv[pr] = NT_LD((const u32x4*)(yr + 32 * pr));
             } else {
 #pragma unroll
                 for (int pr = 0; pr < NF2 / 2; ++pr) yv[pr] = u32x4{0u, 0u, 0u, 0u};
@@ -436,7 +515,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
                     const bf16x8 y = __builtin_bit_cast(bf16x8, yv[nf >> 1]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += (float)y[4 * (nf & 1) + e];
-                    if (live) *(f32x4*)(xr + 32 * (nf >> 1) + 4 * (nf & 1)) = v;
+                    if (live) NT_ST(v, (f32x4*)(xr + 32 * (nf >> 1) + 4 * (nf & 1)));
                     xv[nf] = v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rs += v[e];
@@ -474,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
                     u32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(y[2 * e], y[2 * e + 1]);
-                    if (live) *(u32x4*)(nr + 32 * pr) = o;
+                    if (live) NT_ST(o, (u32x4*)(nr + 32 * pr));
                 });
             }
         });
@@ -494,15 +573,27 @@ bool hipt_mlp_pipe_supported(int dtype, int D_, int hidden) {
     return dtype == HIPT_BF16 && D_ == 384 && hidden % 128 == 0 && hidden >= 256 && hidden <= 1536;
 }
 
+int hipt_mlp_pack_launch(const void* w1, const void* w2, int D_, int hidden, void* packed, hipStream_t st) {
+    if (!hipt_mlp_pipe_supported(HIPT_BF16, D_, hidden)) {
+        hipt_set_error("mlp pack: unsupported D=%d hidden=%d", D_, hidden);
+        return HIPT_E_UNSUPPORTED;
+    }
+    const int64_t chunks = (int64_t)(hidden / 128) * 4 * (UNIT / 16);
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const char*)w1, (const char*)w2, hidden, (char*)packed);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}
+
 template <int DBG>
 int hipt_mlp_pipe_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     MlpParams p = p_in;
     const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4;
-    auto k = mlp_pipe_kernel<DBG>;
+    auto k = p.wpk ? mlp_pipe_kernel<DBG, true> : mlp_pipe_kernel<DBG, false>;
     static bool attr = false;
     static int ncu = 0;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)mlp_pipe_kernel<DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mlp_pipe_kernel<DBG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(mlp_pipe) failed");
             return HIPT_E_LAUNCH;
         }

@@ -37,7 +37,30 @@ typedef std::integral_constant<int, 1> I1;
 typedef std::integral_constant<int, -1> IM1;
 
 // DBG (tools/seqgemm_probe.hip only): 1 = no weight DMA / ring syncs, 2 = no output stores, 4 = no LDS reads / MFMAs
-template <bool LN, int DBG = 0>
+// per-lane part of a weight DMA address: LDS row R = wave*8 + (lane>>3) + 32q of a slab takes output column n0 + U(R),
+// U(16nf + 4g' + e) = 32(nf>>1) + 8g' + 4(nf&1) + e (lane g' then owns, over the fragment pair (2f, 2f+1), output columns
+// 32f + 8g' + (0..7); U(R + 32) = U(R) + 32: piece q only adds a uniform offset); the lane's 16-byte chunk is its LDS
+// chunk position XOR ((R>>1)&7)
+__device__ __forceinline__ uint32_t lane_src(int wave, int lane) {
+    const int r0 = wave * 8 + (lane >> 3);
+    const int ch0 = (lane & 7) ^ ((r0 >> 1) & 7);
+    const int urow = 8 * ((r0 >> 2) & 3) + 4 * ((r0 >> 4) & 1) + (r0 & 3);
+    return (uint32_t)(urow * K + ch0 * 8) * 2;
+}
+// byte offset in W of piece (j, q) of ring unit (nt, kh), without the lane part
+__device__ __forceinline__ int64_t piece_src(int nt, int kh, int j, int q) { return ((int64_t)nt * 128 * K + kh * 192 + j * 64 + q * 32 * K) * 2; }
+
+// one thread per 16-byte chunk of the packed image
+__global__ void seqgemm_pack_kernel(const char* __restrict__ W, int N, char* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)(N >> 7) * 2 * (UNIT / 16)) return;
+    const int u = (int)(i / (UNIT / 16)), o = (int)(i % (UNIT / 16)) * 16;
+    const int j = o / SLAB, pw = (o % SLAB) / 1024, q = pw >> 2, wave = pw & 3, lane = (o % 1024) / 16;
+    *(u32x4*)(out + (int64_t)u * UNIT + o) = *(const u32x4*)(W + piece_src(u >> 1, u & 1, j, q) + lane_src(wave, lane));
+}
+
+// PACKED: the weights come from the pre-packed image p.wpk (a DMA piece = 1 KiB of consecutive bytes) instead of p.W
+template <bool LN, int DBG = 0, bool PACKED = false>
 __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gam = (float*)(smem + 3 * UNIT);
@@ -52,26 +75,20 @@ __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParam
     const int upt = 2 * NT;     // ring units per pass over the weights
     const int rot = blockIdx.x % NT;  // this workgroup's first N tile: spreads the stores of the chip over all columns
 
-    // ---- weight DMA: LDS row R = wave*8 + (lane>>3) + 32q of a slab takes output column n0 + U(R) ----
-    // U(16nf + 4g' + e) = 32(nf>>1) + 8g' + 4(nf&1) + e: lane g' then owns, over the fragment pair (2f, 2f+1), output
-    // columns 32f + 8g' + (0..7).  U(R + 32) = U(R) + 32: piece q only adds a uniform offset.
-    const bf16_t* W = (const bf16_t*)p.W;
-    const int r0 = wave * 8 + (lane >> 3);
-    const int ch0 = (lane & 7) ^ ((r0 >> 1) & 7);
-    const int urow = 8 * ((r0 >> 2) & 3) + 4 * ((r0 >> 4) & 1) + (r0 & 3);
-    const uint32_t loff = (uint32_t)(urow * K + ch0 * 8) * 2;  // per-lane byte offset; everything else is wave-uniform
-    const char* ibase = (const char*)W;
+    // ---- weight DMA (address parts: lane_src / piece_src above) ----
+    const uint32_t loff = PACKED ? (uint32_t)(wave * 1024 + lane * 16) : lane_src(wave, lane);  // everything else is wave-uniform
+    const char* ibase = (const char*)(PACKED ? p.wpk : p.W);
     int islot = 0, ipos = 0;
     auto set_issue = [&](int pos, int slot) {  // unit pos of a pass: N tile (rot + pos/2) % NT, k slabs 3(pos&1) ..
         int nt = rot + (pos >> 1);
         nt = nt >= NT ? nt - NT : nt;
-        ibase = (const char*)(W + (int64_t)nt * 128 * K + (pos & 1) * 192);
+        ibase = PACKED ? (const char*)p.wpk + (int64_t)(2 * nt + (pos & 1)) * UNIT : (const char*)p.W + piece_src(nt, pos & 1, 0, 0);
         islot = slot;
     };
     auto dma_piece = [&](auto T_) __attribute__((always_inline)) {
         constexpr int t = decltype(T_)::value, j = t >> 2, q = t & 3;
         if constexpr ((DBG & 1) == 0)
-            glds16(ibase + (j * 64 * 2 + q * 32 * K * 2) + loff, smem + islot * UNIT + j * SLAB + (q * 4 + wave) * 1024);
+            glds16(ibase + (PACKED ? j * SLAB + q * 4096 : j * 64 * 2 + q * 32 * K * 2) + loff, smem + islot * UNIT + j * SLAB + (q * 4 + wave) * 1024);
     };
 
     for (int i = tid; i < p.N; i += 256)
@@ -348,14 +365,26 @@ bool hipt_seqgemm_pipe_supported(int dtype, int K_, int N, bool ln, int flags) {
     return dtype == HIPT_BF16 && K_ == 384 && N % 128 == 0 && N >= 256 && N <= MAXN && flags == 0;
 }
 
+int hipt_seqgemm_pack_launch(const void* W, int N, int K_, void* packed, hipStream_t st) {
+    if (!hipt_seqgemm_pipe_supported(HIPT_BF16, K_, N, false, 0)) {
+        hipt_set_error("seqgemm pack: unsupported K=%d N=%d", K_, N);
+        return HIPT_E_UNSUPPORTED;
+    }
+    const int64_t chunks = (int64_t)(N >> 7) * 2 * (UNIT / 16);
+    hipLaunchKernelGGL(seqgemm_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const char*)W, N, (char*)packed);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}
+
 template <bool LN, int DBG>
 int hipt_seqgemm_pipe_launch_dbg(const SeqGemmParams& p_in, hipStream_t st) {
     SeqGemmParams p = p_in;
-    auto k = seqgemm_pipe_kernel<LN, DBG>;
+    auto k = p.wpk ? seqgemm_pipe_kernel<LN, DBG, true> : seqgemm_pipe_kernel<LN, DBG, false>;
     static bool attr = false;
     static int ncu = 0;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<LN, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<LN, DBG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(seqgemm_pipe) failed");
             return HIPT_E_LAUNCH;
         }

@@ -77,6 +77,23 @@ class _PackedVit:
         w.blocks = C.cast(self.blocks, C.POINTER(N.BlockWeights))
         self.w = w
         self.device = dev
+        self._prepack(depth, dev)
+
+    def _prepack(self, depth: int, dev) -> None:
+        """Ring-ordered images of the block matrices for the streaming kernels (include/hipt_abmil.h, *_pk): one extra
+        copy of the bf16 weights, made once per set of weights (this object is rebuilt when a parameter changes)."""
+        if os.environ.get("HIPT_NO_PREPACK") or dev.type != "cuda":
+            return
+        lib = N.lib()
+        for what, field in ((N.PACK_QKV, "qkv_pk"), (N.PACK_PROJ, "proj_pk"), (N.PACK_MLP, "mlp_pk")):
+            nbytes = lib.hipt_vit_packed_bytes(C.byref(self.w), what)
+            if not nbytes:
+                continue
+            for i in range(depth):
+                img = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                N.call("hipt_vit_pack_weights", C.byref(self.w), i, what, N.ptr(img), N.stream_ptr(dev))
+                self.keep.append(img)
+                setattr(self.blocks[i], field, img.data_ptr())
 
     @property
     def ref(self):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HIPT_ABI_VERSION 1
+#define HIPT_ABI_VERSION 2
 
 enum { HIPT_F32 = 0, HIPT_BF16 = 1 };
 
@@ -68,7 +68,16 @@ typedef struct hipt_block_weights {
     const float* ln2_w;  const float* ln2_b;    /* blocks.i.norm2.{weight,bias}      [D]     */
     const void*  fc1_w;  const float* fc1_b;    /* blocks.i.mlp.fc1.{weight,bias}    [Dh,D]  */
     const void*  fc2_w;  const float* fc2_b;    /* blocks.i.mlp.fc2.{weight,bias}    [D,Dh]  */
+    /* Optional (NULL = absent) pre-packed images of the bf16 GEMM matrices, written by hipt_vit_pack_weights from the
+     * matrices above: the same values in the byte order of the streaming kernels' LDS ring, so that a 1 KiB DMA piece is
+     * one run of consecutive bytes instead of eight 128-byte row segments (2.4x the L2->LDS rate on MI355X).  They
+     * are a cache of qkv_w / proj_w / fc1_w+fc2_w: re-pack after the weights change. */
+    const void*  qkv_pk;  const void* proj_pk;  const void* mlp_pk;
 } hipt_block_weights;
+
+#define HIPT_PACK_QKV  0
+#define HIPT_PACK_PROJ 1
+#define HIPT_PACK_MLP  2   /* fc1 and fc2 in one image */
 
 /* One ViT (ViT-256 `vit_small` or ViT-4K `vit4k_xs`, or any width the classes are built with).
  * `pos` is the ALREADY INTERPOLATED positional table for this token grid
@@ -137,6 +146,13 @@ int hipt_attention(const void* qkv, void* out, float* probs, int B, int ntok, in
  * once (hipt_vit256_prepare_tokens additionally needs the bf16 copy of the image tensor in
  * HIPT_BF16 mode: + 2 bytes per image element it addresses). */
 size_t hipt_vit_workspace_bytes(const hipt_vit_weights* w, int nseq);
+
+/* Pre-packed weight images (hipt_block_weights.*_pk).  hipt_vit_packed_bytes: size of the image of matrix `what`
+ * (HIPT_PACK_*) of one block, 0 when this dtype / shape has no packed form (then leave the pointer NULL).
+ * hipt_vit_pack_weights: write the image of block `block` into `out` (device memory of that size) from w->blocks[block].
+ * Done once per set of weights by the module that owns them (vision_transformer.py:_PackedVit here). */
+size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what);
+int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* out, void* stream);
 /* Scratch of the whole-forward calls below (residual stream + block scratch + bf16 input copy). */
 size_t hipt_vit256_forward_workspace_bytes(const hipt_vit_weights* w, const hipt_image_layout* lay,
                                            int nseq, int chunk);

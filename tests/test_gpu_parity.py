@@ -314,6 +314,33 @@ def test_vit256_bf16_cls_pruned_last_block_matches_full(vit256):
     assert rel_l2(pruned, full.cpu().numpy()) < 3e-3 and cosine(pruned, full.cpu().numpy()) > 0.99999
 
 
+def test_vit256_prepacked_weight_images_change_nothing(vit256, monkeypatch):
+    """The ring-ordered weight images (hipt_block_weights.*_pk, made by hipt_vit_pack_weights) hold the same values as the
+    row-major matrices: forward() and the full-block path give identical bits with and without them."""
+    x = synth.hash_uniform_torch((4, 3, 256, 256), 19, device=DEV)
+    vit256.set_compute_dtype("bf16")
+    try:
+        pk = vit256._tokens(x)[0]
+        assert all(pk.blocks[i].mlp_pk and pk.blocks[i].qkv_pk and pk.blocks[i].proj_pk for i in range(pk.w.depth))
+        with_img = vit256(x), vit256.get_intermediate_layers(x, n=2)
+        monkeypatch.setenv("HIPT_NO_PREPACK", "1")
+        vit256._packed.clear()
+        pk0 = vit256._tokens(x)[0]
+        assert not any(pk0.blocks[i].mlp_pk or pk0.blocks[i].qkv_pk or pk0.blocks[i].proj_pk for i in range(pk0.w.depth))
+        without = vit256(x), vit256.get_intermediate_layers(x, n=2)
+    finally:
+        monkeypatch.delenv("HIPT_NO_PREPACK", raising=False)
+        vit256._packed.clear()
+        vit256.set_compute_dtype("fp32")
+    assert torch.equal(with_img[0], without[0])
+    assert all(torch.equal(a, b) for a, b in zip(with_img[1], without[1]))
+    # fp32 weights have no packed form: the size query says so and packing is refused
+    pk32 = vit256._tokens(x)[0]
+    assert N.lib().hipt_vit_packed_bytes(pk32.ref, N.PACK_MLP) == 0
+    with pytest.raises(RuntimeError):
+        N.call("hipt_vit_pack_weights", pk32.ref, 0, N.PACK_MLP, N.ptr(x), N.stream_ptr(x.device))
+
+
 def test_hipt4k_region_batch_equals_single_regions(hipt):
     """R regions per call (throughput form) give the same features as R single-region calls."""
     x = synth.hash_uniform_torch((3, 3, 512, 768), 33, device=DEV)

@@ -98,6 +98,15 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(bt, hbt.data(), D * 4, hipMemcpyHostToDevice));
     p.x = (float*)x; p.y1 = y; p.ln_w = (float*)g; p.ln_b = (float*)bt; p.ln_eps = 1e-6f;
     p.w1 = w1; p.b1 = (float*)b1; p.w2 = w2; p.b2 = (float*)b2; p.M = M; p.D = D; p.hidden = H; p.counter = (int*)ctr;
+#ifndef PROBE_OLD
+    if (!getenv("PROBE_UNPACKED")) {  // the weight stream as one pre-packed image (what the library does at load time)
+        void* pk;
+        CK(hipMalloc(&pk, (size_t)2 * H * D * 2));
+        if (hipt_mlp_pack_launch(w1, w2, D, H, pk, 0) != 0) { printf("pack failed\n"); return 1; }
+        CK(hipDeviceSynchronize());
+        p.wpk = pk;
+    }
+#endif
     if (check) {
         LAUNCH(0, p);
         CK(hipDeviceSynchronize());
