@@ -74,10 +74,11 @@ def step_flops(cat, rows, passes, ntok=257):
     return passes * (12 * full if cat == "qkv_gemm" else 11 * full + full // ntok)
 
 
-# rocprofv3 kernel names of the categories (profiles/<tag>_traffic.json keys)
-TRAFFIC_KEYS = {"mlp_fused": "void mlp_pipe_kernel<0>", "qkv_gemm": "void seqgemm_pipe_kernel<true, 0>",
-                "proj_gemm": "void seqgemm_pipe_kernel<false, 0>", "attention": "attn64_kernel",
-                "abmil_fused": "void abmil_stream_kernel<6>"}
+# rocprofv3 kernel names of the categories (prefixes of the profiles/<tag>_traffic.json keys; with the pre-packed weight
+# images the names end in ", true>")
+TRAFFIC_KEYS = {"mlp_fused": "void mlp_pipe_kernel<0", "qkv_gemm": "void seqgemm_pipe_kernel<true, 0",
+                "proj_gemm": "void seqgemm_pipe_kernel<false, 0", "attention": "attn64_kernel",
+                "abmil_fused": "abmil_pipe_kernel"}
 
 
 def pmc_traffic(cat):
@@ -87,8 +88,9 @@ def pmc_traffic(cat):
             if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         t = json.load(open(os.path.join(ROOT, "profiles", f)))
         k = TRAFFIC_KEYS.get(cat)
-        if k in t:
-            return t[k]["hbm_bytes"]
+        hits = [v["hbm_bytes"] for name, v in t.items() if k and name.startswith(k)]
+        if hits:
+            return max(hits)  # (the ViT-256 launches; a variant without the packed image only runs on tiny shapes)
     return None
 
 

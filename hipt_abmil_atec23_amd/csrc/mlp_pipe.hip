@@ -42,6 +42,9 @@
 #define NT_LD(p) __builtin_nontemporal_load(p)
 #define NT_ST(v, p) __builtin_nontemporal_store(v, p)
 #endif
+#ifndef PSTAMP_SEQ
+#define PSTAMP_SEQ 0  // which tile of a workgroup the debug stamps describe (0 = the first: every CU in step)
+#endif
 #ifndef MLP_DMA_SCHED
 #define MLP_DMA_SCHED 0
 #endif
@@ -52,7 +55,7 @@ constexpr int SLAB = 16384, UNIT = 3 * SLAB;
 
 #define PSTAMP(k)                                                                                                    \
     do {                                                                                                             \
-        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if (p.stamps && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
 enum { KA = 0, KB = 1 };            // phase kind: fc1 half / fc2 half
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
             asm volatile("" : "+v"(a2));
         }
         PSTAMP(2);
-        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
+        if (p.stamps && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
 
         f32x4 acc2[2][NF2];
 #pragma unroll
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
         __builtin_amdgcn_sched_barrier(0);
         phase(TB{}, I1{}, IM1{}, I0{}, IM1{}, 0);
         PSTAMP(3);
-        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
+        if (p.stamps && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
 
         // ---- epilogue: x <- x + y1 + acc2 + b2 (this workgroup owns its rows: in place, no other reader).
         //      acc2[mf][nf][e] is output column 16(nf & ~1) + 8g + 4(nf & 1) + e of row li (permuted fc2 rows): fragment
