@@ -130,6 +130,13 @@ __device__ __forceinline__ void finish_bag(char* smem, f32x4 (&pool)[8], float m
             // every load of the partials is an sc1 load (buffer loads with the sc1 cache-policy bit)
             const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)partials, 0, G * stride * 4, 0x00020000);
             constexpr int SC1 = 16;
+            // all of this thread's share of the partials is requested at once, before anything is reduced: ONE memory
+            // round trip (in batches of 8 behind the max / factor computation it was five).  32 threads x 16 B cover
+            // one partial row, 8 rows per pass; rows past G are out of the buffer's range and read as zero
+            const int c4 = tid & 31, part = tid >> 5;
+            f32x4 rowv[32];  // (rows are 520 B apart: 8-byte aligned -> two 8-byte loads each)
+#pragma unroll
+            for (int i = 0; i < 32; ++i) rowv[i] = ld4(prs, ((part + 8 * i) * stride + 2 + 4 * c4) * 4);
             f32x2 ml = {-INFINITY, 0.f};  // (max, sum)
             if (tid < G) {
                 ml[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, tid * stride * 4, 0, SC1));
@@ -146,12 +153,10 @@ __device__ __forceinline__ void finish_bag(char* smem, f32x4 (&pool)[8], float m
             if (lane == 0) wr[wave] = ls;
             __syncthreads();
             const float L = wr[0] + wr[1] + wr[2] + wr[3];
-            {   // column sums: 32 threads x 16 B cover one partial row, 8 rows per pass, 8 passes in flight
-                const int c4 = tid & 31, part = tid >> 5;
+            {   // column sums, in row order (Fs is 0 past G)
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-                for (int gi = part; gi < G; gi += 8)  // (rows are 520 B apart: 8-byte aligned -> two 8-byte loads)
-                    a += f32x4{0.f, 0.f, 0.f, 0.f} + ld4(prs, (gi * stride + 2 + 4 * c4) * 4) * Fs[gi];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) a += f32x4{0.f, 0.f, 0.f, 0.f} + rowv[i] * Fs[part + 8 * i];
                 *(f32x4*)(Cs + part * S1 + 4 * c4) = a;
             }
             __syncthreads();

@@ -281,6 +281,9 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
         }
         nrows = (p.M - row0) < nrows ? (p.M - row0) : nrows;
         PSTAMP(0);
+#ifdef MLP_WAIT_STAMP
+        unsigned long long wait_vm = 0, wait_bar = 0;
+#endif
         if (tid == 0) {  // next tile: fetched now, read after this tile's ring barriers
             const int nt = atomicAdd(p.counter, 1);
             asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt) : "memory");
@@ -370,8 +373,18 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
                 // (1) fragment reads one group ahead
                 if constexpr (gg == 11) {
                     if constexpr ((DBG & 1) == 0) {
+#ifdef MLP_WAIT_STAMP  // (probe builds) cycles wave 0 spends in the two waits of a tile's 48 ring syncs -> stamp slots 12 / 13
+                        const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        const unsigned long long w1_ = __builtin_amdgcn_s_memtime();
+                        __builtin_amdgcn_s_barrier();
+                        const unsigned long long w2_ = __builtin_amdgcn_s_memtime();
+                        wait_vm += w1_ - w0_;
+                        wait_bar += w2_ - w1_;
+#else
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of the next unit have landed
                         __builtin_amdgcn_s_barrier();                     // ... everyone's; unit cons-1 is no longer read
+#endif
                         set_issue(ipos, (cons + 2) % 3);
                         ipos = ipos + 1 == upt ? 0 : ipos + 1;
                     }
@@ -481,6 +494,12 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
         phase(TB{}, I1{}, IM1{}, I0{}, IM1{}, 0);
         PSTAMP(3);
         if (p.stamps && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
+#ifdef MLP_WAIT_STAMP
+        if (p.stamps && threadIdx.x == 0 && seq == PSTAMP_SEQ) {
+            p.stamps[(size_t)blockIdx.x * 16 + 12] = wait_vm;
+            p.stamps[(size_t)blockIdx.x * 16 + 13] = wait_bar;
+        }
+#endif
 
         // ---- epilogue: x <- x + y1 + acc2 + b2 (this workgroup owns its rows: in place, no other reader).
         //      acc2[mf][nf][e] is output column 16(nf & ~1) + 8g + 4(nf & 1) + e of row li (permuted fc2 rows): fragment
@@ -642,14 +661,24 @@ int hipt_mlp_pipe_launch_dbg(const MlpParams& p_in, hipStream_t st) {
             if (h[b * 16 + 10] > t4) t4 = h[b * 16 + 10];
         }
         double pro = 0, chunks = 0, epi = 0, ghz = 0;
+#ifdef MLP_WAIT_STAMP
+        double wvm = 0, wbar = 0;
+#endif
         for (int b = 0; b < grid; ++b) {
             pro += (double)(h[b * 16 + 2] - h[b * 16 + 0]) * 0.01 / grid;
             chunks += (double)(h[b * 16 + 3] - h[b * 16 + 2]) * 0.01 / grid;
             epi += (double)(h[b * 16 + 4] - h[b * 16 + 3]) * 0.01 / grid;
             ghz += (double)(h[b * 16 + 9] - h[b * 16 + 8]) / (double)(h[b * 16 + 3] - h[b * 16 + 2]) * 0.1 / grid;
+#ifdef MLP_WAIT_STAMP
+            wvm += (double)h[b * 16 + 12] / grid;
+            wbar += (double)h[b * 16 + 13] / grid;
+#endif
         }
         fprintf(stderr, "[mlp_pipe dbg=%d hidden=%d grid=%d tiles=%d(+%d)] total %.1f us | first tiles: rows+LN %.1f, chunks %.1f (%.2f GHz), epilogue %.1f\n",
                 DBG, p.hidden, grid, p.full_tiles, p.ntiles - p.full_tiles, (double)(t4 - t0) * 0.01, pro, chunks, ghz, epi);
+#ifdef MLP_WAIT_STAMP
+        fprintf(stderr, "   ring syncs of that tile, wave 0: %.0f cycles waiting for its DMA pieces, %.0f in the barrier\n", wvm, wbar);
+#endif
     }
     return HIPT_OK;
 }
