@@ -125,8 +125,10 @@ int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* 
 
 // emit_last: the MLP of block b1-1 also writes LayerNorm-1 of block b1 on its output rows (bf16, s.att), for a caller
 // that runs block b1 itself (the [CLS]-pruned last block); *have_xn tells it whether that happened
+// img_ok / x_img_out: the caller owns x and accepts it back as an fp32 activation image (kernels.h): blocks after the
+// first then exchange y1 / xn / x as images (coalesced row phases); *x_img_out tells whether x came back as one
 int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, float* probs, const BlockScratch& s,
-               hipStream_t st, bool emit_last = false, bool* have_xn_out = nullptr) {
+               hipStream_t st, bool emit_last = false, bool* have_xn_out = nullptr, bool img_ok = false, bool* x_img_out = nullptr) {
     const int D = w->dim, M = nseq * w->ntok, dt = w->dtype, dh = D / w->heads;
     const float scale = 1.0f / sqrtf((float)dh);  // head_dim ** -0.5 (vision_transformer.py:112)
     int rc;
@@ -140,6 +142,10 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     const bool chain = seq && hipt_mlp_pipe_supported(dt, D, w->hidden) && hipt_seqgemm_pipe_supported(dt, D, 3 * D, false, 0) &&
                        getenv("HIPT_NO_LN_CHAIN") == nullptr;
     bool have_xn = false;
+    // activation images: chained pipelined blocks with packed weights, whole 16-row fragments, no probability output
+    bool img = img_ok && chain && probs == nullptr && M % 16 == 0 && getenv("HIPT_NO_IMG") == nullptr;
+    for (int i = b0; i < b1 && img; ++i) img = w->blocks[i].qkv_pk && w->blocks[i].proj_pk && w->blocks[i].mlp_pk;
+    bool x_img = false;
     for (int i = b0; i < b1; ++i) {
         const hipt_block_weights& b = w->blocks[i];
         const bool last_probs = probs != nullptr && i == b1 - 1;
@@ -156,7 +162,9 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             q.counter = (int*)s.hid + 16;
             if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue
                 q.A = s.att; q.ln_w = q.ln_b = nullptr;
+                q.img = img ? 1 : 0;
                 PROF(cQKV, hipt_seqgemm_launch(q, false, 0, st));
+                q.img = 0;
             } else {
                 PROF(cQKV, hipt_seqgemm_launch(q, true, 0, st));
             }
@@ -164,6 +172,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             if (last_probs) break;
             q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
             q.counter = (int*)s.hid + 32;
+            q.img = img ? 2 : 0;
             PROF(cPROJ, hipt_seqgemm_launch(q, false, 0, st));
             MlpParams m;
             memset(&m, 0, sizeof(m));
@@ -175,6 +184,10 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
                 m.ln_next_w = w->blocks[i + 1].ln1_w;
                 m.ln_next_b = w->blocks[i + 1].ln1_b;
                 m.xn_out = s.att;
+            }
+            if (img) {
+                m.img = x_img ? 3 : 1;
+                x_img = true;
             }
             PROF(cMLP, hipt_mlp_launch(m, st));
             continue;
@@ -191,6 +204,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
                             HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st, w->ntok));
     }
     if (have_xn_out) *have_xn_out = have_xn;
+    if (x_img_out) *x_img_out = x_img;
     return HIPT_OK;
 }
 
@@ -203,7 +217,7 @@ static bool can_prune_last(const hipt_vit_weights* w) {
            hipt_mlp_supported(w->dtype, w->dim, w->hidden) && getenv("HIPT_NO_SEQGEMM") == nullptr && getenv("HIPT_NO_PRUNE") == nullptr;
 }
 
-static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, const BlockScratch& s, float* xc, bool have_xn, hipStream_t st) {
+static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, const BlockScratch& s, float* xc, bool have_xn, bool x_img, hipStream_t st) {
     const int D = w->dim, M = nseq * w->ntok;
     const hipt_block_weights& b = w->blocks[w->depth - 1];
     int rc;
@@ -215,12 +229,14 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
     q.counter = (int*)s.hid + 16;
     if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue (bf16 operands in s.att)
         q.A = s.att; q.ln_w = q.ln_b = nullptr;
+        q.img = x_img ? 1 : 0;  // (x and the operands s.att change layout together)
         PROF(PC_QKV, hipt_seqgemm_launch(q, false, 0, st));
+        q.img = 0;
     } else {
         PROF(PC_QKV, hipt_seqgemm_launch(q, true, 0, st));
     }
     PROF(PC_ATTN, hipt_attn_cls_launch(s.qkv, s.att, nullptr, nseq, w->ntok, w->heads, D / w->heads, 1.0f / sqrtf((float)(D / w->heads)), st));
-    PROF(PC_OTHER, hipt_gather_cls_launch(x, xc, nseq, (int64_t)w->ntok * D, D, st));
+    PROF(PC_OTHER, hipt_gather_cls_launch(x, xc, nseq, (int64_t)w->ntok * D, D, st, x_img ? 1 : 0));
     q.M = nseq; q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
     q.counter = (int*)s.hid + 32;
     PROF(PC_PROJ, hipt_seqgemm_launch(q, false, 0, st));
@@ -541,9 +557,9 @@ static int vit256_forward_impl(const hipt_vit_weights* w, const void* images, in
         if ((rc = embed256(w, img, lay, s0, n, x, st))) return rc;
         if (can_prune_last(w)) {
             float* xc = (float*)((char*)s.hid + 4096);  // (the hidden-tensor slot is free on this path; its head holds tile queues)
-            bool have_xn = false;
-            if ((rc = run_blocks(w, x, n, 0, w->depth - 1, nullptr, s, st, true, &have_xn))) return rc;
-            if ((rc = run_last_block_cls(w, x, n, s, xc, have_xn, st))) return rc;
+            bool have_xn = false, x_img = false;  // (x is this function's own buffer: it may come back as an activation image)
+            if ((rc = run_blocks(w, x, n, 0, w->depth - 1, nullptr, s, st, true, &have_xn, true, &x_img))) return rc;
+            if ((rc = run_last_block_cls(w, x, n, s, xc, have_xn, x_img, st))) return rc;
             PROF(PC_LN, hipt_layernorm_launch(xc, w->dim, w->norm_w, w->norm_b, out + (size_t)s0 * w->dim, HIPT_F32, w->dim, n, w->dim,
                                               w->ln_eps, st));
         } else {

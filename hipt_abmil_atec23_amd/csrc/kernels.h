@@ -30,6 +30,12 @@ struct GemmParams {
 int hipt_gemm_launch(const GemmParams& p, int dtype, int aload, int flags, hipStream_t st);
 
 // A-stationary GEMM (seqgemm.hip): one workgroup per sequence, activations in registers, optional fused LayerNorm
+// "Activation images" (pipelined D = 384 kernels, M % 16 == 0): a [M, 384] activation stored fragment by fragment in
+// the order the MFMA operand / accumulator layout wants it, so that every load / store instruction of a wave covers 1 KiB
+// of consecutive bytes.  Fragment F = rows [16F, 16F+16); lane = 16 g + li holds row li, 16-byte chunk (g + 4c):
+//   bf16: element offset  F * 6144 + c * 512 + lane * 8                  (c = 0..11: columns (g + 4c) * 8 .. + 7)
+//   fp32: float offset    F * 6144 + c * 512 + h * 256 + lane * 4        (h = 0/1: columns (g + 4c) * 8 + 4h .. + 3)
+// A fragment occupies the same bytes as its 16 rows do row-major, so a kernel may convert in place fragment by fragment.
 struct SeqGemmParams {
     const void* A;       // LN: fp32 x rows; else bf16 rows
     int64_t lda;         // elements
@@ -38,6 +44,7 @@ struct SeqGemmParams {
     float ln_eps;
     const void* W;       // bf16 [N, K]
     const void* wpk;     // optional (pipelined kernel only): W pre-packed in ring order (hipt_seqgemm_pack_launch)
+    int img;             // (pipelined kernel only) activation images: bit 0 = A (bf16, no LayerNorm), bit 1 = out (N = 384)
     int M, N, K;
     unsigned long long* stamps;  // debug: per-workgroup phase timestamps (100 MHz), or null
     int debug;           // HIPT_SEQGEMM_DEBUG bits: 1 = skip epilogue stores, 2 = skip A load (zeros)
@@ -70,6 +77,7 @@ struct MlpParams {
     const float* b2;
     int M, D, hidden;
     const void* wpk;     // optional (pipelined kernel only): both weights pre-packed in ring order (hipt_mlp_pack_launch)
+    int img;             // (pipelined kernel only) activation images: bit 0 = y1, xn_out and the updated x, bit 1 = x on entry
     int* counter;        // device int the launcher zeroes on the stream: the kernel's tile queue
     // optional (pipelined kernel only): LayerNorm-1 of the NEXT block applied to the updated rows, written as bf16
     // [M, D] -- the next block's QKV GEMM then loads operands directly instead of fp32 rows + LayerNorm
@@ -101,7 +109,7 @@ int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int hea
 // attention of the [CLS] query only (bf16, head dim 64): out[B, heads*64] bf16 and/or probs[B, heads, ntok] fp32 (either may be null)
 int hipt_attn_cls_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale, hipStream_t st);
 // dst[s, :] = src[s * seq_stride ...] : the first row of every sequence (fp32)
-int hipt_gather_cls_launch(const float* src, float* dst, int nseq, int64_t seq_stride, int D, hipStream_t st);
+int hipt_gather_cls_launch(const float* src, float* dst, int nseq, int64_t seq_stride, int D, hipStream_t st, int img = 0);
 // x[s, 0, :] = cls + pos[0]  for s in [0, nseq)
 int hipt_cls_init_launch(float* x, const float* cls, const float* pos, int nseq, int ntok, int D, hipStream_t st);
 // out[i] = src[i] (+ (float)y[i] if y)  (fp32, bf16 branch, n % 8 == 0): lands the residual stream in the caller's buffer

@@ -239,12 +239,20 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const bf16_t* __restrict_
 }
 
 // dst[s, :] = src[s * ntok, :]  (fp32 rows of D floats: the [CLS] rows of the residual stream)
-__global__ void gather_cls_kernel(const float* __restrict__ src, float* __restrict__ dst, int nseq, int64_t seq_stride, int D) {
+// img: src is an fp32 activation image (kernels.h; D = 384, seq_stride a multiple of D): row r = s * seq_stride / D sits in
+// fragment r / 16 as li = r % 16; its 4 floats at column 4c are chunk c / 2 = g + 4 cc, half c & 1
+__global__ void gather_cls_kernel(const float* __restrict__ src, float* __restrict__ dst, int nseq, int64_t seq_stride, int D, int img) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one float4
     const int per = D / 4;
     if (i >= nseq * per) return;
     const int s = i / per, c = i % per;
-    *(f32x4*)(dst + (int64_t)s * D + 4 * c) = *(const f32x4*)(src + (int64_t)s * seq_stride + 4 * c);
+    if (img) {
+        const int64_t r = (int64_t)s * seq_stride / D;
+        const int ch = c >> 1, h = c & 1, g = ch & 3, cc = ch >> 2, li = (int)(r & 15);
+        *(f32x4*)(dst + (int64_t)s * D + 4 * c) = *(const f32x4*)(src + (r >> 4) * (16 * D) + cc * 512 + h * 256 + (g * 16 + li) * 4);
+    } else {
+        *(f32x4*)(dst + (int64_t)s * D + 4 * c) = *(const f32x4*)(src + (int64_t)s * seq_stride + 4 * c);
+    }
 }
 
 }  // namespace
@@ -258,10 +266,11 @@ int hipt_attn_cls_launch(const void* qkv, void* out, float* probs, int B, int nt
     return HIPT_OK;
 }
 
-int hipt_gather_cls_launch(const float* src, float* dst, int nseq, int64_t seq_stride, int D, hipStream_t st) {
+int hipt_gather_cls_launch(const float* src, float* dst, int nseq, int64_t seq_stride, int D, hipStream_t st, int img) {
     HIPT_CHECK_ARG(D % 4 == 0, "gather_cls: D %% 4");
+    HIPT_CHECK_ARG(!img || (D == 384 && seq_stride % D == 0), "gather_cls: image source needs D = 384 and whole rows");
     const int n = nseq * (D / 4);
-    hipLaunchKernelGGL(gather_cls_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, dst, nseq, seq_stride, D);
+    hipLaunchKernelGGL(gather_cls_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, dst, nseq, seq_stride, D, img);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }

@@ -129,7 +129,10 @@ __global__ void mlp_pack_kernel(const char* __restrict__ w1, const char* __restr
 // DBG (tools/mlp_probe.hip only): 1 = no weight DMA / ring syncs, 2 = GELU replaced by a plain pack,
 // 4 = no LDS fragment reads / MFMAs.
 // PACKED: the weights come from the pre-packed image p.wpk (a DMA piece = 1 KiB of consecutive bytes) instead of W1 / W2.
-template <int DBG = 0, bool PACKED = false>
+// IMG / XIN: fragment-blocked activation images (kernels.h, "activation images") -- IMG: y1 is read and x / xn_out are
+// written as images; XIN: x is read as an image.  Every load / store instruction of a row phase then touches 1 KiB of
+// consecutive bytes (a row-major matrix gives 16 rows x 64 B per instruction: 35 GB/s per CU instead of 50-120).
+template <int DBG = 0, bool PACKED = false, bool IMG = false, bool XIN = false>
 __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gam = (float*)(smem + 3 * UNIT);
@@ -295,18 +298,25 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
         for (int mf = 0; mf < 2; ++mf) {
             int r = (wave * 2 + mf) * 16 + li;
             r = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
-            const float* xr = p.x + (int64_t)(row0 + r) * D;
+            // image forms: whole fragments only (the launcher guarantees M % 16 == 0); a fragment past the tile's end
+            // re-reads fragment 0 of the tile (never stored)
+            const int fr = (wave * 2 + mf) * 16 < nrows ? (wave * 2 + mf) * 16 : 0;
+            // x: row-major: row r, floats (g + 4c) * 8 + 4h;  image: fragment base + c * 512 + h * 256 + lane * 4
+            const float* xr = XIN ? p.x + (int64_t)(row0 + fr) * D + lane * 4 : p.x + (int64_t)(row0 + r) * D + g * 8;
+            constexpr int xc_ = XIN ? 512 : 32, xh_ = XIN ? 256 : 4;
             f32x4 v[NCH][2];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                v[c][0] = NT_LD((const f32x4*)(xr + (g + 4 * c) * 8));
-                v[c][1] = NT_LD((const f32x4*)(xr + (g + 4 * c) * 8 + 4));
+                v[c][0] = NT_LD((const f32x4*)(xr + c * xc_));
+                v[c][1] = NT_LD((const f32x4*)(xr + c * xc_ + xh_));
             }
             if (p.y1) {
-                const bf16_t* yr = (const bf16_t*)p.y1 + (int64_t)(row0 + r) * D;
+                // y1 (bf16): row-major: row r, elements (g + 4c) * 8;  image: fragment base + c * 512 + lane * 8
+                const bf16_t* yr = IMG ? (const bf16_t*)p.y1 + (int64_t)(row0 + fr) * D + lane * 8 : (const bf16_t*)p.y1 + (int64_t)(row0 + r) * D + g * 8;
+                constexpr int yc_ = IMG ? 512 : 32;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const bf16x8 y = __builtin_bit_cast(bf16x8, NT_LD((const u32x4*)(yr + (g + 4 * c) * 8)));
+                    const bf16x8 y = __builtin_bit_cast(bf16x8, NT_LD((const u32x4*)(yr + c * yc_)));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[c][0][e] += (float)y[e];
@@ -510,19 +520,28 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
             constexpr int mf = decltype(MF_)::value;
             const int r = (wave * 2 + mf) * 16 + li;
             const bool live = r < nrows;
-            float* xr = p.x + (int64_t)(row0 + (live ? r : 0)) * D + 8 * g;
-            const bf16_t* yr = (const bf16_t*)p.y1 + (int64_t)(row0 + (live ? r : 0)) * D + 8 * g;
+            // fragment pair pr of this lane = the 8 columns 32 pr + 8g ..: chunk (g + 4 pr) of the row -- the prologue's
+            // addressing with c = pr (x: h = nf & 1).  xl: old values (layout XIN), xs: new ones (layout IMG)
+            const int fr = (wave * 2 + mf) * 16;  // (image forms: stored only when live, i.e. fr < nrows)
+            const float* xl = XIN ? p.x + (int64_t)(row0 + (live ? fr : 0)) * D + lane * 4 : p.x + (int64_t)(row0 + (live ? r : 0)) * D + 8 * g;
+            float* xs = IMG ? p.x + (int64_t)(row0 + (live ? fr : 0)) * D + lane * 4 : p.x + (int64_t)(row0 + (live ? r : 0)) * D + 8 * g;
+            const bf16_t* yr = IMG ? (const bf16_t*)p.y1 + (int64_t)(row0 + (live ? fr : 0)) * D + lane * 8
+                                   : (const bf16_t*)p.y1 + (int64_t)(row0 + (live ? r : 0)) * D + 8 * g;
+            constexpr int xlp_ = XIN ? 512 : 32, xlh_ = XIN ? 256 : 4, xsp_ = IMG ? 512 : 32, xsh_ = IMG ? 256 : 4, yp_ = IMG ? 512 : 32;
             f32x4 xv[NF2];  // the row's old values, then (in place) its new ones
             u32x4 yv[NF2 / 2];
 #pragma unroll
-            for (int nf = 0; nf < NF2; ++nf) xv[nf] = NT_LD((const f32x4*)(xr + 32 * (nf >> 1) + 4 * (nf & 1)));
+            for (int nf = 0; nf < NF2; ++nf) xv[nf] = NT_LD((const f32x4*)(xl + xlp_ * (nf >> 1) + xlh_ * (nf & 1)));
             if (p.y1) {
 #pragma unroll
-                for (int pr = 0; pr < NF2 / 2; ++pr) yv[pr] = NT_LD((const u32x4*)(yr + 32 * pr));
+                for (int pr = 0; pr < NF2 / 2; ++pr) yv[pr] = NT_LD((const u32x4*)(yr + yp_ * pr));
             } else {
 #pragma unroll
                 for (int pr = 0; pr < NF2 / 2; ++pr) yv[pr] = u32x4{0u, 0u, 0u, 0u};
             }
+            // converting in place (row-major in, image out): a lane's stores land where OTHER lanes' loads read -- every
+            // load of the fragment must have returned before the first store leaves
+            if constexpr (XIN != IMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             float rs = 0.f;
             sfor<0, NF2 / 4>([&](auto Q_) __attribute__((always_inline)) {  // 4 output fragments at a time
                 constexpr int q4 = decltype(Q_)::value;
@@ -537,7 +556,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
                     const bf16x8 y = __builtin_bit_cast(bf16x8, yv[nf >> 1]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += (float)y[4 * (nf & 1) + e];
-                    if (live) NT_ST(v, (f32x4*)(xr + 32 * (nf >> 1) + 4 * (nf & 1)));
+                    if (live) NT_ST(v, (f32x4*)(xs + xsp_ * (nf >> 1) + xsh_ * (nf & 1)));
                     xv[nf] = v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rs += v[e];
@@ -559,7 +578,8 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
                 q += __shfl_xor(q, 16, 64);
                 q += __shfl_xor(q, 32, 64);
                 const float rstd = 1.0f / sqrtf(q * (1.0f / D) + p.ln_eps);
-                bf16_t* nr = (bf16_t*)p.xn_out + (int64_t)(row0 + (live ? r : 0)) * D + 8 * g;
+                bf16_t* nr = IMG ? (bf16_t*)p.xn_out + (int64_t)(row0 + (live ? fr : 0)) * D + lane * 8
+                                 : (bf16_t*)p.xn_out + (int64_t)(row0 + (live ? r : 0)) * D + 8 * g;
                 sfor<0, NF2 / 2>([&](auto P_) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
                     constexpr int pr = decltype(P_)::value;
@@ -575,7 +595,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
                     u32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(y[2 * e], y[2 * e + 1]);
-                    if (live) NT_ST(o, (u32x4*)(nr + 32 * pr));
+                    if (live) NT_ST(o, (u32x4*)(nr + yp_ * pr));
                 });
             }
         });
@@ -610,11 +630,21 @@ template <int DBG>
 int hipt_mlp_pipe_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     MlpParams p = p_in;
     const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4;
-    auto k = p.wpk ? mlp_pipe_kernel<DBG, true> : mlp_pipe_kernel<DBG, false>;
+    // p.img: bit 0 = y1 in / x out / xn out are activation images, bit 1 = x in is one (images need the packed weights too:
+    // one instantiation less; and whole 16-row fragments)
+    if (p.img && (!p.wpk || (p.img & 2 && !(p.img & 1)) || p.M % 16 != 0)) {
+        hipt_set_error("mlp_pipe: activation images need packed weights, M %% 16 == 0 and img in {0, 1, 3} (img=%d, M=%d)", p.img, p.M);
+        return HIPT_E_BADARG;
+    }
+    auto k = p.img == 3 ? mlp_pipe_kernel<DBG, true, true, true>
+           : p.img == 1 ? mlp_pipe_kernel<DBG, true, true, false>
+           : p.wpk ? mlp_pipe_kernel<DBG, true> : mlp_pipe_kernel<DBG, false>;
     static bool attr = false;
     static int ncu = 0;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)mlp_pipe_kernel<DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        if (hipFuncSetAttribute((const void*)mlp_pipe_kernel<DBG, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mlp_pipe_kernel<DBG, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mlp_pipe_kernel<DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)mlp_pipe_kernel<DBG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(mlp_pipe) failed");
             return HIPT_E_LAUNCH;

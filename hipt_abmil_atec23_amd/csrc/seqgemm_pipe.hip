@@ -60,7 +60,8 @@ __global__ void seqgemm_pack_kernel(const char* __restrict__ W, int N, char* __r
 }
 
 // PACKED: the weights come from the pre-packed image p.wpk (a DMA piece = 1 KiB of consecutive bytes) instead of p.W
-template <bool LN, int DBG = 0, bool PACKED = false>
+// AIMG: A (bf16, LN = false) is an activation image;  OIMG: the output (N = 384 = ldc) is written as one (kernels.h)
+template <bool LN, int DBG = 0, bool PACKED = false, bool AIMG = false, bool OIMG = false>
 __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gam = (float*)(smem + 3 * UNIT);
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParam
     // store offsets inside a tile's buffer: row (wave*3 + mf)*16 + li, column 8g (+ uniform n0 + 32f)
     int voff[MF];
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) voff[mf] = (int)((((wave * MF + mf) * 16 + li) * p.ldc + 8 * g) * 2);
+    for (int mf = 0; mf < MF; ++mf)  // (image: fragment (wave*3 + mf) of the tile, chunk position lane; + column chunk * 1 KiB)
+        voff[mf] = OIMG ? (wave * MF + mf) * 16 * K * 2 + lane * 16 : (int)((((wave * MF + mf) * 16 + li) * p.ldc + 8 * g) * 2);
 
     // ---- prime the ring: unit 0 whole, the first two pieces of unit 1 ----
     int cons = 0;
@@ -192,9 +194,16 @@ __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParam
                 }
                 __builtin_amdgcn_sched_barrier(0);
             } else {
-                const bf16_t* ar = (const bf16_t*)p.A + (int64_t)(row0 + r) * p.lda;
+                if constexpr (AIMG) {  // whole fragments (M % 16 == 0); one past the tile's end re-reads fragment 0 (never stored)
+                    const int fr = (wave * MF + mf) * 16 < nrows ? (wave * MF + mf) * 16 : 0;
+                    const bf16_t* ar = (const bf16_t*)p.A + (int64_t)(row0 + fr) * K + lane * 8;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) af[mf][c] = *(const u32x4*)(ar + (g + 4 * c) * 8);
+                    for (int c = 0; c < NCH; ++c) af[mf][c] = *(const u32x4*)(ar + c * 512);
+                } else {
+                    const bf16_t* ar = (const bf16_t*)p.A + (int64_t)(row0 + r) * p.lda;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) af[mf][c] = *(const u32x4*)(ar + (g + 4 * c) * 8);
+                }
             }
         }
         if constexpr (LN) {
@@ -222,7 +231,8 @@ __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParam
             o[1] = pack_bf16x2(acc[buf][mf][2 * f][2], acc[buf][mf][2 * f][3]);
             o[2] = pack_bf16x2(acc[buf][mf][2 * f + 1][0], acc[buf][mf][2 * f + 1][1]);
             o[3] = pack_bf16x2(acc[buf][mf][2 * f + 1][2], acc[buf][mf][2 * f + 1][3]);
-            if constexpr ((DBG & 2) == 0) __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, voff[mf], (n0e + 32 * f) * 2, 0);
+            // (image: column chunk (n0e + 32f) / 32 of the fragment, 1 KiB each)
+            if constexpr ((DBG & 2) == 0) __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, voff[mf], (n0e + 32 * f) * (OIMG ? 32 : 2), 0);
         };
 
         // ---- one phase = one ring unit = 3 k slabs of one N tile: 12 groups of 12 MFMAs ----
@@ -379,11 +389,24 @@ int hipt_seqgemm_pack_launch(const void* W, int N, int K_, void* packed, hipStre
 template <bool LN, int DBG>
 int hipt_seqgemm_pipe_launch_dbg(const SeqGemmParams& p_in, hipStream_t st) {
     SeqGemmParams p = p_in;
+    // p.img: bit 0 = A is an activation image (LN = false), bit 1 = the output is written as one (N = ldc = 384); both
+    // need the packed weights (one instantiation less) and whole 16-row fragments
+    if (p.img && (!p.wpk || LN || p.M % 16 != 0 || p.img == 3 || (p.img == 2 && (p.N != K || p.ldc != K)) || (p.img == 1 && p.lda != K))) {
+        hipt_set_error("seqgemm_pipe: activation images: unsupported combination (img=%d LN=%d M=%d N=%d lda=%lld ldc=%lld packed=%d)", p.img,
+                       (int)LN, p.M, p.N, (long long)p.lda, (long long)p.ldc, p.wpk != nullptr);
+        return HIPT_E_BADARG;
+    }
     auto k = p.wpk ? seqgemm_pipe_kernel<LN, DBG, true> : seqgemm_pipe_kernel<LN, DBG, false>;
+    if constexpr (!LN) {
+        if (p.img == 1) k = seqgemm_pipe_kernel<false, DBG, true, true, false>;
+        if (p.img == 2) k = seqgemm_pipe_kernel<false, DBG, true, false, true>;
+    }
     static bool attr = false;
     static int ncu = 0;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<LN, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        if (hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<LN, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<LN, DBG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(seqgemm_pipe) failed");
             return HIPT_E_LAUNCH;

@@ -341,6 +341,25 @@ def test_vit256_prepacked_weight_images_change_nothing(vit256, monkeypatch):
         N.call("hipt_vit_pack_weights", pk32.ref, 0, N.PACK_MLP, N.ptr(x), N.stream_ptr(x.device))
 
 
+def test_vit256_activation_images_change_nothing(vit256, monkeypatch):
+    """forward() keeps the residual stream, the attention-branch output and the pre-normalised QKV operands of blocks
+    2..11 as fragment-blocked "activation images" (csrc/kernels.h) when the batch has whole 16-row fragments: a pure
+    re-ordering of bytes in private buffers -- identical bits to the row-major path (HIPT_NO_IMG=1), also for a batch
+    whose row count is not a multiple of 16 (which never uses them)."""
+    vit256.set_compute_dtype("bf16")
+    try:
+        for nseq in (16, 48, 5):  # 16 * 257 and 48 * 257 rows: whole fragments; 5 * 257: not
+            x = synth.hash_uniform_torch((nseq, 3, 256, 256), 23 + nseq, device=DEV)
+            img = vit256(x)
+            monkeypatch.setenv("HIPT_NO_IMG", "1")
+            plain = vit256(x)
+            monkeypatch.delenv("HIPT_NO_IMG")
+            assert torch.equal(img, plain), nseq
+    finally:
+        monkeypatch.delenv("HIPT_NO_IMG", raising=False)
+        vit256.set_compute_dtype("fp32")
+
+
 def test_hipt4k_region_batch_equals_single_regions(hipt):
     """R regions per call (throughput form) give the same features as R single-region calls."""
     x = synth.hash_uniform_torch((3, 3, 512, 768), 33, device=DEV)
