@@ -51,9 +51,11 @@ __device__ __forceinline__ void scores(const u32x4 (&qf)[2][2], const char* Ks, 
 }
 
 // softmax over the keys, P V, store
+// oimg >= 0: the output is written as a bf16 activation image (kernels.h; D = 384): oimg = first row (b * ntok) of this
+// sequence, obase = out + h * DH.  Row r, columns h*64 + 16 dt + 4g ..+3 = chunk 8h + 2dt + (g >> 1), half (g & 1).
 template <int NQ>
 __device__ __forceinline__ void finish(f32x4 (&s)[NQ][NKT], bf16_t* __restrict__ obase, const char* Vs, int D, int ntok, float sl2e, int qt0,
-                                       int qt1, int li, int g) {
+                                       int qt1, int li, int g, int64_t oimg, int h) {
     // ---- softmax over keys, fp32, exp2 domain ----
     float inv[NQ];
 #pragma unroll
@@ -130,14 +132,23 @@ __device__ __forceinline__ void finish(f32x4 (&s)[NQ][NKT], bf16_t* __restrict__
     for (int a = 0; a < NQ; ++a) {
         const int q = (a == 0 ? qt0 : qt1) * 16 + li;
         if (q < ntok) {
-            bf16_t* orow = obase + (int64_t)q * D + 4 * g;
+            if (oimg >= 0) {
+                const int64_t r = oimg + q;
+                bf16_t* orow = obase + (r >> 4) * (16 * 384) + (2 * h) * 512 + ((int)(r & 15)) * 8 + (g >> 1) * 128 + 4 * (g & 1);
 #pragma unroll
-            for (int dt = 0; dt < DH / 16; ++dt) store4<bf16_t>(orow + dt * 16, o[a][dt] * inv[a]);
+                for (int dt = 0; dt < DH / 16; ++dt)  // chunk 8h + 2dt + (g>>1): c = 2h + (dt >> 1), lane group 2(dt & 1) + (g >> 1)
+                    store4<bf16_t>(orow + (dt >> 1) * 512 + (dt & 1) * 256, o[a][dt] * inv[a]);
+            } else {
+                bf16_t* orow = obase + (int64_t)q * D + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < DH / 16; ++dt) store4<bf16_t>(orow + dt * 16, o[a][dt] * inv[a]);
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(256, 2) void attn64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int ntok, int heads, float sl2e) {
+__global__ __launch_bounds__(256, 2) void attn64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int ntok, int heads, float sl2e,
+                                                         int out_img) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + ROWS * RB;
@@ -178,18 +189,19 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const bf16_t* __restrict
     }
     __syncthreads();
 
-    bf16_t* obase = out + (int64_t)b * ntok * D + h * DH;
+    bf16_t* obase = out_img ? out : out + (int64_t)b * ntok * D + h * DH;
+    const int64_t oimg = out_img ? (int64_t)b * ntok : -1;
     for (; qt + 4 < nqt; qt += 8) {
         f32x4 s[2][NKT];
         scores<2>(qf, Ks, li, g, s);
         if (qt + 8 < nqt) load_q(qbase, tokstride, ntok, qt + 8, li, g, qf[0]);
         if (qt + 12 < nqt) load_q(qbase, tokstride, ntok, qt + 12, li, g, qf[1]);
-        finish<2>(s, obase, Vs, D, ntok, sl2e, qt, qt + 4, li, g);
+        finish<2>(s, obase, Vs, D, ntok, sl2e, qt, qt + 4, li, g, oimg, h);
     }
     if (qt < nqt) {
         f32x4 s[1][NKT];
         scores<1>(qf, Ks, li, g, s);
-        finish<1>(s, obase, Vs, D, ntok, sl2e, qt, qt, li, g);
+        finish<1>(s, obase, Vs, D, ntok, sl2e, qt, qt, li, g, oimg, h);
     }
 }
 
@@ -199,7 +211,8 @@ bool hipt_attention64_supported(int dtype, int dh, int ntok, bool want_probs) {
     return dtype == HIPT_BF16 && dh == 64 && ntok > ROWS - 32 && ntok <= ROWS && !want_probs;
 }
 
-int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st) {
+int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st, int out_img) {
+    HIPT_CHECK_ARG(!out_img || (heads * DH == 384 && ((int64_t)B * ntok) % 16 == 0), "attention64: image output needs D = 384 and whole 16-row fragments");
     constexpr int lds = 2 * ROWS * RB;
     static bool attr = false;
     if (!attr) {
@@ -210,7 +223,7 @@ int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int hea
         attr = true;
     }
     hipLaunchKernelGGL(attn64_kernel, dim3(B * heads), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, ntok, heads,
-                       scale * 1.4426950408889634f);
+                       scale * 1.4426950408889634f, out_img);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }

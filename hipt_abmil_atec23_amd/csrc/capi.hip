@@ -145,6 +145,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     // activation images: chained pipelined blocks with packed weights, whole 16-row fragments, no probability output
     bool img = img_ok && chain && probs == nullptr && M % 16 == 0 && getenv("HIPT_NO_IMG") == nullptr;
     for (int i = b0; i < b1 && img; ++i) img = w->blocks[i].qkv_pk && w->blocks[i].proj_pk && w->blocks[i].mlp_pk;
+    img = img && hipt_attention64_supported(dt, dh, w->ntok, false) && getenv("HIPT_ATTN_V1") == nullptr;
     bool x_img = false;
     for (int i = b0; i < b1; ++i) {
         const hipt_block_weights& b = w->blocks[i];
@@ -168,11 +169,12 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             } else {
                 PROF(cQKV, hipt_seqgemm_launch(q, true, 0, st));
             }
-            PROF(cATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st));
+            // (with activation images the attention output is one too: proj then reads its operands 1 KiB at a time)
+            PROF(cATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st, img ? 1 : 0));
             if (last_probs) break;
             q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
             q.counter = (int*)s.hid + 32;
-            q.img = img ? 2 : 0;
+            q.img = img ? 3 : 0;  // A = the attention output image, out = y1 image
             PROF(cPROJ, hipt_seqgemm_launch(q, false, 0, st));
             MlpParams m;
             memset(&m, 0, sizeof(m));

@@ -102,9 +102,9 @@ int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, cons
                           int64_t out_stride, int rows, int D, float eps, hipStream_t st);
 
 int hipt_attention_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale,
-                          int dtype, hipStream_t st);  // dispatches to the bf16 / head-dim-64 kernel when it applies
-bool hipt_attention64_supported(int dtype, int dh, int ntok, bool want_probs);
-int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st);
+                          int dtype, hipStream_t st, int out_img = 0);  // dispatches to the bf16 / head-dim-64 kernel when it applies
+bool hipt_attention64_supported(int dtype, int dh, int ntok, bool want_probs);  // (false too when HIPT_ATTN_V1 is set)
+int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st, int out_img = 0);
 
 // attention of the [CLS] query only (bf16, head dim 64): out[B, heads*64] bf16 and/or probs[B, heads, ntok] fp32 (either may be null)
 int hipt_attn_cls_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale, hipStream_t st);

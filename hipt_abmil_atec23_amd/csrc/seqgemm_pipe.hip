@@ -391,7 +391,7 @@ int hipt_seqgemm_pipe_launch_dbg(const SeqGemmParams& p_in, hipStream_t st) {
     SeqGemmParams p = p_in;
     // p.img: bit 0 = A is an activation image (LN = false), bit 1 = the output is written as one (N = ldc = 384); both
     // need the packed weights (one instantiation less) and whole 16-row fragments
-    if (p.img && (!p.wpk || LN || p.M % 16 != 0 || p.img == 3 || (p.img == 2 && (p.N != K || p.ldc != K)) || (p.img == 1 && p.lda != K))) {
+    if (p.img && (!p.wpk || LN || p.M % 16 != 0 || p.img > 3 || ((p.img & 2) && (p.N != K || p.ldc != K)) || ((p.img & 1) && p.lda != K))) {
         hipt_set_error("seqgemm_pipe: activation images: unsupported combination (img=%d LN=%d M=%d N=%d lda=%lld ldc=%lld packed=%d)", p.img,
                        (int)LN, p.M, p.N, (long long)p.lda, (long long)p.ldc, p.wpk != nullptr);
         return HIPT_E_BADARG;
@@ -400,12 +400,14 @@ int hipt_seqgemm_pipe_launch_dbg(const SeqGemmParams& p_in, hipStream_t st) {
     if constexpr (!LN) {
         if (p.img == 1) k = seqgemm_pipe_kernel<false, DBG, true, true, false>;
         if (p.img == 2) k = seqgemm_pipe_kernel<false, DBG, true, false, true>;
+        if (p.img == 3) k = seqgemm_pipe_kernel<false, DBG, true, true, true>;
     }
     static bool attr = false;
     static int ncu = 0;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<LN, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<LN, DBG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(seqgemm_pipe) failed");
