@@ -224,7 +224,7 @@ int dispatch(const void* qkv, void* out, float* probs, int B, int ntok, int head
 }  // namespace
 
 int hipt_attention_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale,
-                          int dtype, hipStream_t st, int out_img) {
+                          int dtype, hipStream_t st, int out_img, int qkv_hm) {
     HIPT_CHECK_ARG(B > 0 && heads > 0 && ntok > 0, "attention: empty problem");
     HIPT_CHECK_ARG(dh == 32 || dh == 64, "attention: head dim %d not in {32, 64}", dh);
     if (ntok > 288) {
@@ -233,8 +233,8 @@ int hipt_attention_launch(const void* qkv, void* out, float* probs, int B, int n
     }
     HIPT_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "attention: 16-byte alignment required");
     static const bool v1_only = getenv("HIPT_ATTN_V1") != nullptr;
-    if (!v1_only && hipt_attention64_supported(dtype, dh, ntok, probs != nullptr)) return hipt_attention64_launch(qkv, out, B, ntok, heads, scale, st, out_img);
-    HIPT_CHECK_ARG(!out_img, "attention: only the 64-wide-head bf16 kernel writes an activation image");
+    if (!v1_only && hipt_attention64_supported(dtype, dh, ntok, probs != nullptr)) return hipt_attention64_launch(qkv, out, B, ntok, heads, scale, st, out_img, qkv_hm);
+    HIPT_CHECK_ARG(!out_img && !qkv_hm, "attention: only the 64-wide-head bf16 kernel handles activation images / head-major qkv");
     if (dtype == HIPT_F32) return dispatch<float>(qkv, out, probs, B, ntok, heads, dh, scale, st);
     if (dtype == HIPT_BF16) return dispatch<bf16_t>(qkv, out, probs, B, ntok, heads, dh, scale, st);
     hipt_set_error("attention: bad dtype %d", dtype);

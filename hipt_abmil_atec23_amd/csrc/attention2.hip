@@ -148,7 +148,7 @@ __device__ __forceinline__ void finish(f32x4 (&s)[NQ][NKT], bf16_t* __restrict__
 }
 
 __global__ __launch_bounds__(256, 2) void attn64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int ntok, int heads, float sl2e,
-                                                         int out_img) {
+                                                         int out_img, int qkv_hm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + ROWS * RB;
@@ -157,10 +157,12 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const bf16_t* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
     const int D = heads * DH;
-    const int64_t tokstride = 3 * (int64_t)D;
-    const bf16_t* qbase = qkv + (int64_t)b * ntok * tokstride + h * DH;
-    const bf16_t* kbase = qbase + D;
-    const bf16_t* vbase = qbase + 2 * D;
+    // qkv row-major [b, token, (q|k|v) x head x 64], or head-major [b][q/k/v][head][token][64] (seqgemm_pipe, OHM)
+    const int64_t tokstride = qkv_hm ? DH : 3 * (int64_t)D;
+    const int64_t mstride = qkv_hm ? (int64_t)heads * ntok * DH : D;  // q -> k -> v
+    const bf16_t* qbase = qkv_hm ? qkv + ((int64_t)b * 3 * heads + h) * ntok * DH : qkv + (int64_t)b * ntok * tokstride + h * DH;
+    const bf16_t* kbase = qbase + mstride;
+    const bf16_t* vbase = qbase + 2 * mstride;
 
     const int g = lane >> 4, li = lane & 15;
     const int nqt = (ntok + 15) >> 4;
@@ -211,7 +213,7 @@ bool hipt_attention64_supported(int dtype, int dh, int ntok, bool want_probs) {
     return dtype == HIPT_BF16 && dh == 64 && ntok > ROWS - 32 && ntok <= ROWS && !want_probs;
 }
 
-int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st, int out_img) {
+int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st, int out_img, int qkv_hm) {
     HIPT_CHECK_ARG(!out_img || (heads * DH == 384 && ((int64_t)B * ntok) % 16 == 0), "attention64: image output needs D = 384 and whole 16-row fragments");
     constexpr int lds = 2 * ROWS * RB;
     static bool attr = false;
@@ -223,7 +225,7 @@ int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int hea
         attr = true;
     }
     hipLaunchKernelGGL(attn64_kernel, dim3(B * heads), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, ntok, heads,
-                       scale * 1.4426950408889634f, out_img);
+                       scale * 1.4426950408889634f, out_img, qkv_hm);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }

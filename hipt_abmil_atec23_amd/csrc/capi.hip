@@ -143,9 +143,12 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
                        getenv("HIPT_NO_LN_CHAIN") == nullptr;
     bool have_xn = false;
     // activation images: chained pipelined blocks with packed weights, whole 16-row fragments, no probability output
-    bool img = img_ok && chain && probs == nullptr && M % 16 == 0 && getenv("HIPT_NO_IMG") == nullptr;
+    bool img = img_ok && chain && probs == nullptr && M % 16 == 0 && getenv("HIPT_NO_IMG") == nullptr &&
+               getenv("HIPT_NO_SEQGEMM_PIPE") == nullptr && getenv("HIPT_NO_MLP_PIPE") == nullptr;
     for (int i = b0; i < b1 && img; ++i) img = w->blocks[i].qkv_pk && w->blocks[i].proj_pk && w->blocks[i].mlp_pk;
     img = img && hipt_attention64_supported(dt, dh, w->ntok, false) && getenv("HIPT_ATTN_V1") == nullptr;
+    // with them, q | k | v leave the QKV GEMM head-major (the attention kernel's K / V staging reads consecutive bytes)
+    const bool hm = img && (int64_t)M * 3 * D * 2 < ((int64_t)1 << 32) - 65536 && getenv("HIPT_NO_QKV_HM") == nullptr;
     bool x_img = false;
     for (int i = b0; i < b1; ++i) {
         const hipt_block_weights& b = w->blocks[i];
@@ -161,16 +164,18 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             q.out = s.qkv; q.ldc = 3 * D;
             // (the hidden tensor is never materialised on this path: its slot holds the kernels' tile queues)
             q.counter = (int*)s.hid + 16;
+            q.out_ntok = w->ntok;
             if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue
                 q.A = s.att; q.ln_w = q.ln_b = nullptr;
-                q.img = img ? 1 : 0;
+                q.img = (img ? 1 : 0) | (hm ? 4 : 0);
                 PROF(cQKV, hipt_seqgemm_launch(q, false, 0, st));
-                q.img = 0;
             } else {
+                q.img = hm ? 4 : 0;
                 PROF(cQKV, hipt_seqgemm_launch(q, true, 0, st));
             }
+            q.img = 0;
             // (with activation images the attention output is one too: proj then reads its operands 1 KiB at a time)
-            PROF(cATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st, img ? 1 : 0));
+            PROF(cATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st, img ? 1 : 0, hm ? 1 : 0));
             if (last_probs) break;
             q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
             q.counter = (int*)s.hid + 32;

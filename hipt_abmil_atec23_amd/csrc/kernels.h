@@ -44,7 +44,9 @@ struct SeqGemmParams {
     float ln_eps;
     const void* W;       // bf16 [N, K]
     const void* wpk;     // optional (pipelined kernel only): W pre-packed in ring order (hipt_seqgemm_pack_launch)
-    int img;             // (pipelined kernel only) activation images: bit 0 = A (bf16, no LayerNorm), bit 1 = out (N = 384)
+    int img;             // (pipelined kernel only) activation images: bit 0 = A (bf16, no LayerNorm), bit 1 = out (N = 384);
+                         // bit 2 = out (N = 1152) head-major [sequence][q/k/v][head][token][64], out_ntok tokens per sequence
+    int out_ntok;
     int M, N, K;
     unsigned long long* stamps;  // debug: per-workgroup phase timestamps (100 MHz), or null
     int debug;           // HIPT_SEQGEMM_DEBUG bits: 1 = skip epilogue stores, 2 = skip A load (zeros)
@@ -102,9 +104,9 @@ int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, cons
                           int64_t out_stride, int rows, int D, float eps, hipStream_t st);
 
 int hipt_attention_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale,
-                          int dtype, hipStream_t st, int out_img = 0);  // dispatches to the bf16 / head-dim-64 kernel when it applies
+                          int dtype, hipStream_t st, int out_img = 0, int qkv_hm = 0);  // dispatches to the bf16 / head-dim-64 kernel when it applies
 bool hipt_attention64_supported(int dtype, int dh, int ntok, bool want_probs);  // (false too when HIPT_ATTN_V1 is set)
-int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st, int out_img = 0);
+int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st, int out_img = 0, int qkv_hm = 0);
 
 // attention of the [CLS] query only (bf16, head dim 64): out[B, heads*64] bf16 and/or probs[B, heads, ntok] fp32 (either may be null)
 int hipt_attn_cls_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale, hipStream_t st);

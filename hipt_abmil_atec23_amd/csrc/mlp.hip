@@ -476,6 +476,7 @@ int hipt_mlp_launch(const MlpParams& p, hipStream_t st) {
                    "mlp: 16-byte alignment required");
     static const bool no_pipe = getenv("HIPT_NO_MLP_PIPE") != nullptr;
     if (!no_pipe && hipt_mlp_pipe_supported(HIPT_BF16, p.D, p.hidden)) return hipt_mlp_pipe_launch(p, st);
+    HIPT_CHECK_ARG(p.img == 0, "mlp: activation images exist only in the pipelined kernel (img=%d)", p.img);
     if (p.D == 384) return launch<6>(p, st);
     if (p.D == 192) return launch<3>(p, st);
     hipt_set_error("mlp: D=%d not in {192, 384}", p.D);

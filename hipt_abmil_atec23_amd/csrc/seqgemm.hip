@@ -348,6 +348,7 @@ int hipt_seqgemm_launch(const SeqGemmParams& p_in, bool ln, int flags, hipStream
                    "seqgemm: 16-byte alignment required");
     static const bool no_pipe = getenv("HIPT_NO_SEQGEMM_PIPE") != nullptr;
     if (!no_pipe && p.counter && hipt_seqgemm_pipe_supported(HIPT_BF16, p.K, p.N, ln, flags)) return hipt_seqgemm_pipe_launch(p, ln, st);
+    HIPT_CHECK_ARG(p.img == 0, "seqgemm: activation images / head-major output exist only in the pipelined kernel (img=%d)", p.img);
     const int tiles_n = (p.N + 127) / 128, tiles_m = (p.M + TM - 1) / TM;
     // whole rounds of 256 CUs run one workgroup per row tile; the tiles of the last partial round are
     // split over their N tiles when that round would otherwise be mostly empty

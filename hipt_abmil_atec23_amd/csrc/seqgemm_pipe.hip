@@ -61,7 +61,9 @@ __global__ void seqgemm_pack_kernel(const char* __restrict__ W, int N, char* __r
 
 // PACKED: the weights come from the pre-packed image p.wpk (a DMA piece = 1 KiB of consecutive bytes) instead of p.W
 // AIMG: A (bf16, LN = false) is an activation image;  OIMG: the output (N = 384 = ldc) is written as one (kernels.h)
-template <bool LN, int DBG = 0, bool PACKED = false, bool AIMG = false, bool OIMG = false>
+// OHM: the output (N = 3 * 384: q | k | v of 6 heads x 64) is written head-major, [sequence][q/k/v][head][token][64]
+//      (p.out_ntok tokens per sequence): the attention kernel then stages a head's K / V with consecutive 1 KiB pieces
+template <bool LN, int DBG = 0, bool PACKED = false, bool AIMG = false, bool OIMG = false, bool OHM = false>
 __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gam = (float*)(smem + 3 * UNIT);
@@ -167,7 +169,20 @@ __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParam
         }
         // this tile's output window: rows beyond nrows are outside the buffer -> their stores are dropped
         const __amdgpu_buffer_rsrc_t orsrc =
-            __builtin_amdgcn_make_buffer_rsrc((char*)p.out + (int64_t)row0 * p.ldc * 2, 0, (int)((int64_t)nrows * p.ldc * 2), 0x00020000);
+            OHM ? __builtin_amdgcn_make_buffer_rsrc((char*)p.out, 0, (int)(uint32_t)((int64_t)p.M * p.N * 2), 0x00020000)
+                : __builtin_amdgcn_make_buffer_rsrc((char*)p.out + (int64_t)row0 * p.ldc * 2, 0, (int)((int64_t)nrows * p.ldc * 2), 0x00020000);
+        if constexpr (OHM) {  // row -> (sequence b, token t): byte offset of element (b, q, head 0, t, 8g); rows past M: out of range
+            const float inv = 1.0f / (float)p.out_ntok;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int row = row0 + (wave * MF + mf) * 16 + li;
+                int b = (int)(((float)row + 0.5f) * inv);
+                b = b * p.out_ntok > row ? b - 1 : b;
+                b = (b + 1) * p.out_ntok <= row ? b + 1 : b;
+                const int t = row - b * p.out_ntok;
+                voff[mf] = row < p.M ? ((b * 18 * p.out_ntok + t) * 64 + 8 * g) * 2 : (int)0xfffffff0u;
+            }
+        }
 
         // ---- activations -> operand fragments ----
         u32x4 af[MF][NCH];
@@ -232,7 +247,13 @@ __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParam
             o[2] = pack_bf16x2(acc[buf][mf][2 * f + 1][0], acc[buf][mf][2 * f + 1][1]);
             o[3] = pack_bf16x2(acc[buf][mf][2 * f + 1][2], acc[buf][mf][2 * f + 1][3]);
             // (image: column chunk (n0e + 32f) / 32 of the fragment, 1 KiB each)
-            if constexpr ((DBG & 2) == 0) __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, voff[mf], (n0e + 32 * f) * (OIMG ? 32 : 2), 0);
+            if constexpr (OHM) {  // columns n0e + 32f + 8g ..+7 lie in one head: (q/k/v, head, d0) -> uniform byte offset
+                const int col0 = n0e + 32 * f, which = col0 >= 2 * K ? 2 : (col0 >= K ? 1 : 0), rem = col0 - which * K;
+                const int soff = (((which * 6 + (rem >> 6)) * p.out_ntok) * 64 + (rem & 63)) * 2;
+                if constexpr ((DBG & 2) == 0) __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, voff[mf], soff, 0);
+            } else {
+                if constexpr ((DBG & 2) == 0) __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, voff[mf], (n0e + 32 * f) * (OIMG ? 32 : 2), 0);
+            }
         };
 
         // ---- one phase = one ring unit = 3 k slabs of one N tile: 12 groups of 12 MFMAs ----
@@ -391,13 +412,21 @@ int hipt_seqgemm_pipe_launch_dbg(const SeqGemmParams& p_in, hipStream_t st) {
     SeqGemmParams p = p_in;
     // p.img: bit 0 = A is an activation image (LN = false), bit 1 = the output is written as one (N = ldc = 384); both
     // need the packed weights (one instantiation less) and whole 16-row fragments
-    if (p.img && (!p.wpk || LN || p.M % 16 != 0 || p.img > 3 || ((p.img & 2) && (p.N != K || p.ldc != K)) || ((p.img & 1) && p.lda != K))) {
+    // bit 2 = head-major q|k|v output (N = 1152 = ldc, p.out_ntok set, the buffer under 4 GiB)
+    if (p.img && (!p.wpk || ((p.img & 3) && (LN || p.M % 16 != 0)) || p.img > 5 || p.img == 3 + 4 || ((p.img & 2) && (p.N != K || p.ldc != K)) ||
+                  ((p.img & 1) && p.lda != K) || ((p.img & 4) && (p.N != 3 * K || p.ldc != 3 * K || p.out_ntok <= 0 || (p.img & 2) ||
+                                                                (int64_t)p.M * p.N * 2 >= ((int64_t)1 << 32) - 65536)))) {
         hipt_set_error("seqgemm_pipe: activation images: unsupported combination (img=%d LN=%d M=%d N=%d lda=%lld ldc=%lld packed=%d)", p.img,
                        (int)LN, p.M, p.N, (long long)p.lda, (long long)p.ldc, p.wpk != nullptr);
         return HIPT_E_BADARG;
     }
     auto k = p.wpk ? seqgemm_pipe_kernel<LN, DBG, true> : seqgemm_pipe_kernel<LN, DBG, false>;
+    if constexpr (LN) {
+        if (p.img == 4) k = seqgemm_pipe_kernel<true, DBG, true, false, false, true>;
+    }
     if constexpr (!LN) {
+        if (p.img == 5) k = seqgemm_pipe_kernel<false, DBG, true, true, false, true>;
+        if (p.img == 4) k = seqgemm_pipe_kernel<false, DBG, true, false, false, true>;
         if (p.img == 1) k = seqgemm_pipe_kernel<false, DBG, true, true, false>;
         if (p.img == 2) k = seqgemm_pipe_kernel<false, DBG, true, false, true>;
         if (p.img == 3) k = seqgemm_pipe_kernel<false, DBG, true, true, true>;
@@ -405,7 +434,9 @@ int hipt_seqgemm_pipe_launch_dbg(const SeqGemmParams& p_in, hipStream_t st) {
     static bool attr = false;
     static int ncu = 0;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        if (hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<LN, DBG, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<LN, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||

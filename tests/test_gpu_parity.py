@@ -351,12 +351,16 @@ def test_vit256_activation_images_change_nothing(vit256, monkeypatch):
         for nseq in (16, 48, 5):  # 16 * 257 and 48 * 257 rows: whole fragments; 5 * 257: not
             x = synth.hash_uniform_torch((nseq, 3, 256, 256), 23 + nseq, device=DEV)
             img = vit256(x)
+            monkeypatch.setenv("HIPT_NO_QKV_HM", "1")  # images, but q | k | v row-major between the QKV GEMM and the attention
+            rowqkv = vit256(x)
+            monkeypatch.delenv("HIPT_NO_QKV_HM")
             monkeypatch.setenv("HIPT_NO_IMG", "1")
             plain = vit256(x)
             monkeypatch.delenv("HIPT_NO_IMG")
-            assert torch.equal(img, plain), nseq
+            assert torch.equal(img, plain) and torch.equal(rowqkv, plain), nseq
     finally:
         monkeypatch.delenv("HIPT_NO_IMG", raising=False)
+        monkeypatch.delenv("HIPT_NO_QKV_HM", raising=False)
         vit256.set_compute_dtype("fp32")
 
 
