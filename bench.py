@@ -74,11 +74,15 @@ def step_flops(cat, rows, passes, ntok=257):
     return passes * (12 * full if cat == "qkv_gemm" else 11 * full + full // ntok)
 
 
-# rocprofv3 kernel names of the categories (prefixes of the profiles/<tag>_traffic.json keys; with the pre-packed weight
-# images the names end in ", true>")
-TRAFFIC_KEYS = {"mlp_fused": "void mlp_pipe_kernel<0", "qkv_gemm": "void seqgemm_pipe_kernel<true, 0",
-                "proj_gemm": "void seqgemm_pipe_kernel<false, 0", "attention": "attn64_kernel",
-                "abmil_fused": "abmil_pipe_kernel"}
+# rocprofv3 kernel names of the categories, most specific first (keys of profiles/<tag>_traffic.json; template
+# arguments of the pipelined kernels: <LN, dbg, packed weights, A image, out image, head-major out> / <dbg, packed, images, x-in image>)
+TRAFFIC_KEYS = {"mlp_fused": ["void mlp_pipe_kernel<0, true, true, true>", "void mlp_pipe_kernel<0, true, false, false>", "void mlp_pipe_kernel<0>"],
+                "qkv_gemm": ["void seqgemm_pipe_kernel<false, 0, true, true, false, true>", "void seqgemm_pipe_kernel<true, 0, true, false, false, false>",
+                             "void seqgemm_pipe_kernel<true, 0>"],
+                "proj_gemm": ["void seqgemm_pipe_kernel<false, 0, true, true, true, false>", "void seqgemm_pipe_kernel<false, 0, true, false, false, false>",
+                              "void seqgemm_pipe_kernel<false, 0>"],
+                "attention": ["attn64_kernel"],
+                "abmil_fused": ["abmil_pipe_kernel", "void abmil_stream_kernel<6>"]}
 
 
 def pmc_traffic(cat):
@@ -87,10 +91,9 @@ def pmc_traffic(cat):
     for f in sorted([p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_traffic.json")], reverse=True) \
             if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         t = json.load(open(os.path.join(ROOT, "profiles", f)))
-        k = TRAFFIC_KEYS.get(cat)
-        hits = [v["hbm_bytes"] for name, v in t.items() if k and name.startswith(k)]
-        if hits:
-            return max(hits)  # (the ViT-256 launches; a variant without the packed image only runs on tiny shapes)
+        for k in TRAFFIC_KEYS.get(cat, []):
+            if k in t:
+                return t[k]["hbm_bytes"]
     return None
 
 
@@ -155,9 +158,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--chunk", type=int, default=0, help="patches per ViT-256 pass (0 = library default)")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the regions of a step are spread over (tail filling)")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the regions of a step are spread over (tail filling)")
     ap.add_argument("--u8", action="store_true", help="regions resident as uint8 RGB [R,W,H,3], normalised on the device (SURVEY 8f-1)")
-    ap.add_argument("--regions", type=int, default=16, help="4096x4096 regions per HIPT_4K call (1 = the reference's batch_size)")
+    ap.add_argument("--regions", type=int, default=24, help="4096x4096 regions per HIPT_4K call (1 = the reference's batch_size)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
