@@ -473,7 +473,10 @@ template <int I, int N, class F> __device__ __forceinline__ void sfor(F&& f) {
 }
 
 // one gate unit: 2 gate pairs of one row; v = (a_j, a_j+1, b_j, b_j+1) with the biases already in, cw = wc[j], wc[j+1]
+// (contraction off, here and where the results are summed: hipcc fuses `num * r` into the caller's sum in one inlined
+//  instance and not in another, and a row's logit must not depend on the fragment / step it lands in)
 __device__ __forceinline__ f32x2 gate_pair(const f32x4& v, const f32x2& cw) {
+#pragma clang fp contract(off)
     f32x2 x = {__builtin_amdgcn_fmed3f(v[0], -15.0f, 15.0f), __builtin_amdgcn_fmed3f(v[1], -15.0f, 15.0f)};
     f32x2 y = {v[2], v[3]};
     x *= 2.0f * LOG2E;
@@ -572,6 +575,7 @@ __global__ __launch_bounds__(256, 1) void abmil_pipe_kernel(const bf16_t* __rest
     const float* gbf = cst + S1 + 4 * g;                                       // gate bias of (n2, g): + 16 n2 floats
 
     float m_run = -INFINITY, l_lane = 0.f;
+    bool m1 = true;
     f32x4 pool[8];
 #pragma unroll
     for (int nf = 0; nf < 8; ++nf) pool[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -646,6 +650,7 @@ __global__ __launch_bounds__(256, 1) void abmil_pipe_kernel(const bf16_t* __rest
                 LGKMN(0);
             }
             if constexpr (PIPE) {
+#pragma clang fp contract(off)
                 if constexpr (G < 16) {
                     gs2[G >> 3] += gate_pair(acc2[G >> 3][G & 7], cw[G & 1]);
                 } else {
@@ -655,9 +660,10 @@ __global__ __launch_bounds__(256, 1) void abmil_pipe_kernel(const bf16_t* __rest
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                Tr<bf16_t>::mma16(cur[0][4 * q + j], w[G & 1][j], xf[0][c]);
-                Tr<bf16_t>::mma16(cur[1][4 * q + j], w[G & 1][j], xf[1][c]);
+            for (int j = 0; j < 4; ++j) Tr<bf16_t>::mma16(cur[0][4 * q + j], w[G & 1][j], xf[0][c]);
+            if (m1) {  // (the second fragment of a wave's last step may be empty: half the MFMAs of that step)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Tr<bf16_t>::mma16(cur[1][4 * q + j], w[G & 1][j], xf[1][c]);
             }
             if constexpr (q == 1) {  // k-step c is done with its rows: request the next step's
                 xf[0][c] = __builtin_amdgcn_raw_buffer_load_b128(rs, vnext[0] + c * 64, 0, 0);
@@ -731,7 +737,7 @@ __global__ __launch_bounds__(256, 1) void abmil_pipe_kernel(const bf16_t* __rest
                 u32x4 wf;
                 wf[0] = wl[G & 1][j][0]; wf[1] = wl[G & 1][j][1]; wf[2] = wh[G & 1][j][0]; wf[3] = wh[G & 1][j][1];
                 Tr<bf16_t>::mma16(acc2[0][4 * q + j], wf, hf[0][f]);
-                Tr<bf16_t>::mma16(acc2[1][4 * q + j], wf, hf[1][f]);
+                if (m1) Tr<bf16_t>::mma16(acc2[1][4 * q + j], wf, hf[1][f]);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -740,13 +746,14 @@ __global__ __launch_bounds__(256, 1) void abmil_pipe_kernel(const bf16_t* __rest
 
     // gate + pooling of the last step: nothing left to hide it under
     auto drain = [&](f32x4 (&prev)[2][8], int sp) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
         // (all 16 units first, then the sums: summed as it goes, the chain of transcendentals runs at its latency)
         f32x2 u[2][8];
 #pragma unroll
         for (int n2 = 0; n2 < 8; ++n2) {
             const f32x2 cwv = *(const f32x2*)(cst + 2 * S1 + 8 * n2 + 2 * g);
             u[0][n2] = gate_pair(acc2[0][n2], cwv);
-            u[1][n2] = gate_pair(acc2[1][n2], cwv);
+            u[1][n2] = m1 ? gate_pair(acc2[1][n2], cwv) : f32x2{0.f, 0.f};  // (an empty fragment: its rows are masked below)
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {  // same order of additions as the overlapped form: bit-identical logits
@@ -761,8 +768,11 @@ __global__ __launch_bounds__(256, 1) void abmil_pipe_kernel(const bf16_t* __rest
 
     constexpr std::false_type PLAIN{};
     constexpr std::true_type OVERLAP{};
+    // m1: the step about to run has rows in its second fragment (false only for a last step of <= 16 rows)
+    auto set_m1 = [&](int s) { m1 = s * 32 + 16 < nrows; };
     if (nstep > 0) {
         ASTAMP(2);
+        set_m1(0);
         phase1(PLAIN, accA, accB, 0);
         ASTAMP(3);
         relu_pack(accA);
@@ -770,14 +780,16 @@ __global__ __launch_bounds__(256, 1) void abmil_pipe_kernel(const bf16_t* __rest
         ASTAMP(4);
         int s = 1;
         for (; s + 1 < nstep; s += 2) {
-            phase1(OVERLAP, accB, accA, s);
+            phase1(OVERLAP, accB, accA, s);  // (m1 stays true: this is not the wave's last step)
             relu_pack(accB);
             phase2();
+            set_m1(s + 1);
             phase1(OVERLAP, accA, accB, s + 1);
             relu_pack(accA);
             phase2();
         }
         if (s < nstep) {
+            set_m1(s);
             phase1(OVERLAP, accB, accA, s);
             relu_pack(accB);
             phase2();
