@@ -45,9 +45,6 @@
 #ifndef PSTAMP_SEQ
 #define PSTAMP_SEQ 0  // which tile of a workgroup the debug stamps describe (0 = the first: every CU in step)
 #endif
-#ifndef MLP_DMA_SCHED
-#define MLP_DMA_SCHED 0
-#endif
 namespace {
 
 constexpr int D = 384, NCH = 12, NF2 = 24, TMR = 128;
@@ -233,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
         set_issue(0, 0);
         sfor<0, 12>(dma_piece);
         set_issue(1, 1);  // its other ten pieces go out in groups 0..4 of the first phase, as in steady state
-        sfor<0, (MLP_DMA_SCHED == 1 ? 4 : MLP_DMA_SCHED == 2 ? 3 : 2)>(dma_piece);
+        sfor<0, 2>(dma_piece);
         ipos = 2;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -443,19 +440,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
                             for (int mf = 0; mf < 2; ++mf) Tr<bf16_t>::mma16(acc2[mf][8 * j + q0 + jj], wA[set][jj], hf[mf][2 * h + fl]);
                     }
                 }
-#if MLP_DMA_SCHED == 1
-                if constexpr (gg == 11) {
-                    sfor<0, 4>(dma_piece);
-                } else if constexpr (gg <= 1) {
-                    sfor<4 + 4 * gg, 8 + 4 * gg>(dma_piece);
-                }
-#elif MLP_DMA_SCHED == 2
-                if constexpr (gg == 11) {
-                    sfor<0, 3>(dma_piece);
-                } else if constexpr (gg <= 2) {
-                    sfor<3 + 3 * gg, 6 + 3 * gg>(dma_piece);
-                }
-#else
+                // (4 + 4 + 4 or 3 x 4 pieces per group instead of 2 x 6: measured, no difference)
                 if constexpr (gg == 11) {
                     dma_piece(std::integral_constant<int, 0>{});
                     dma_piece(std::integral_constant<int, 1>{});
@@ -463,7 +448,6 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
                     dma_piece(std::integral_constant<int, 2 + 2 * gg>{});
                     dma_piece(std::integral_constant<int, 3 + 2 * gg>{});
                 }
-#endif
                 if constexpr (gh >= 0 && gg >= 4) {
                     gelu_unit(std::integral_constant<int, (gh >= 0 ? gh : 0)>{}, std::integral_constant<int, 8 * gsec + gg - 4>{});
                 }
