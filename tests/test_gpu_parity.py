@@ -389,6 +389,17 @@ def test_hipt4k_region_batch_equals_single_regions(hipt):
         hipt.streams = 1
         hipt.set_compute_dtype("fp32")
     assert torch.equal(one, two)
+    # the same with whole 16-row fragments per stream (16 patches x 257 rows each: activation images, packed weights)
+    x2 = synth.hash_uniform_torch((2, 3, 1024, 1024), 34, device=DEV)
+    hipt.set_compute_dtype("bf16")
+    try:
+        one = hipt(x2)
+        hipt.streams = 2
+        two = hipt(x2)
+    finally:
+        hipt.streams = 1
+        hipt.set_compute_dtype("fp32")
+    assert torch.equal(one, two) and torch.equal(one[1:], two[1:])
     with pytest.raises(ValueError):
         hipt.forward_asset_dict(x)
 
