@@ -34,10 +34,11 @@ __device__ __forceinline__ void load_q(const bf16_t* __restrict__ qbase, int64_t
 }
 
 // S^T tiles: s[a][t][i] = <k[16t + 4g + i], q_a[li]>;  NQ = query tiles processed together (2, or 1 for an odd one)
-template <int NQ>
+// NKS: key tiles that hold tokens (17 for 257 tokens: the 18th tile's scores are neither computed nor exponentiated)
+template <int NQ, int NKS>
 __device__ __forceinline__ void scores(const u32x4 (&qf)[2][2], const char* Ks, int li, int g, f32x4 (&s)[NQ][NKT]) {
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) {
+    for (int t = 0; t < NKS; ++t) {
         const u32x4 k0 = *(const u32x4*)(Ks + k_off(t * 16 + li, g));
         const u32x4 k1 = *(const u32x4*)(Ks + k_off(t * 16 + li, g + 4));
 #pragma unroll
@@ -53,22 +54,22 @@ __device__ __forceinline__ void scores(const u32x4 (&qf)[2][2], const char* Ks, 
 // softmax over the keys, P V, store
 // oimg >= 0: the output is written as a bf16 activation image (kernels.h; D = 384): oimg = first row (b * ntok) of this
 // sequence, obase = out + h * DH.  Row r, columns h*64 + 16 dt + 4g ..+3 = chunk 8h + 2dt + (g >> 1), half (g & 1).
-template <int NQ>
+template <int NQ, int NKS>
 __device__ __forceinline__ void finish(f32x4 (&s)[NQ][NKT], bf16_t* __restrict__ obase, const char* Vs, int D, int ntok, float sl2e, int qt0,
                                        int qt1, int li, int g, int64_t oimg, int h) {
     // ---- softmax over keys, fp32, exp2 domain ----
     float inv[NQ];
 #pragma unroll
     for (int a = 0; a < NQ; ++a) {
-        // keys past the end can only sit in the last two key tiles (256 < ntok <= 288)
+        // keys past the end can only sit in the last two key tiles that hold tokens (16 (NKS - 2) < ntok <= 16 NKS)
 #pragma unroll
-        for (int t = NKT - 2; t < NKT; ++t)
+        for (int t = NKS - 2; t < NKS; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (t * 16 + 4 * g + i >= ntok) s[a][t][i] = -INFINITY;
         float m = fmaxf(fmaxf(s[a][0][0], s[a][0][1]), fmaxf(s[a][0][2], s[a][0][3]));
 #pragma unroll
-        for (int t = 1; t < NKT; ++t) {
+        for (int t = 1; t < NKS; ++t) {
             m = __builtin_fmaxf(__builtin_fmaxf(m, s[a][t][0]), s[a][t][1]);  // -> v_max3_f32
             m = __builtin_fmaxf(__builtin_fmaxf(m, s[a][t][2]), s[a][t][3]);
         }
@@ -78,7 +79,9 @@ __device__ __forceinline__ void finish(f32x4 (&s)[NQ][NKT], bf16_t* __restrict__
         const f32x2 sc2 = {sl2e, sl2e}, ms2 = {ms, ms};
         f32x2 l2 = {0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < NKT; ++t) {
+        for (int t = NKS; t < NKT; ++t) s[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};  // (token-free tiles: probability 0 in the P V pairs)
+#pragma unroll
+        for (int t = 0; t < NKS; ++t) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f32x2 x = __builtin_elementwise_fma(f32x2{s[a][t][2 * h], s[a][t][2 * h + 1]}, sc2, ms2);  // v_pk_fma_f32
@@ -147,6 +150,7 @@ __device__ __forceinline__ void finish(f32x4 (&s)[NQ][NKT], bf16_t* __restrict__
     }
 }
 
+template <int NKS>
 __global__ __launch_bounds__(256, 2) void attn64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int ntok, int heads, float sl2e,
                                                          int out_img, int qkv_hm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -195,15 +199,15 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const bf16_t* __restrict
     const int64_t oimg = out_img ? (int64_t)b * ntok : -1;
     for (; qt + 4 < nqt; qt += 8) {
         f32x4 s[2][NKT];
-        scores<2>(qf, Ks, li, g, s);
+        scores<2, NKS>(qf, Ks, li, g, s);
         if (qt + 8 < nqt) load_q(qbase, tokstride, ntok, qt + 8, li, g, qf[0]);
         if (qt + 12 < nqt) load_q(qbase, tokstride, ntok, qt + 12, li, g, qf[1]);
-        finish<2>(s, obase, Vs, D, ntok, sl2e, qt, qt + 4, li, g, oimg, h);
+        finish<2, NKS>(s, obase, Vs, D, ntok, sl2e, qt, qt + 4, li, g, oimg, h);
     }
     if (qt < nqt) {
         f32x4 s[1][NKT];
-        scores<1>(qf, Ks, li, g, s);
-        finish<1>(s, obase, Vs, D, ntok, sl2e, qt, qt, li, g, oimg, h);
+        scores<1, NKS>(qf, Ks, li, g, s);
+        finish<1, NKS>(s, obase, Vs, D, ntok, sl2e, qt, qt, li, g, oimg, h);
     }
 }
 
@@ -218,13 +222,14 @@ int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int hea
     constexpr int lds = 2 * ROWS * RB;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)attn64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)attn64_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attn64_kernel<NKT - 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(attention64) failed");
             return HIPT_E_LAUNCH;
         }
         attr = true;
     }
-    hipLaunchKernelGGL(attn64_kernel, dim3(B * heads), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, ntok, heads,
+    hipLaunchKernelGGL(ntok <= ROWS - 16 ? attn64_kernel<NKT - 1> : attn64_kernel<NKT>, dim3(B * heads), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, ntok, heads,
                        scale * 1.4426950408889634f, out_img, qkv_hm);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
