@@ -5,33 +5,36 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One STEP (per GPU) = one pass of the hot path over one batch of synthetic input, inputs resident in
-HBM before the timed region:
-  * HIPT_4K.forward on one [1,3,4096,4096] fp32 region -> 256 patches through ViT-256 -> ViT-4K over
-    the 16x16 [CLS] grid -> [1,192]  (BASELINE.json configs[2], bf16 operands / fp32 accumulate);
-  * CLAM_SB.forward (gated-attention pooling + bag classifier) on one 100 000 x 384 bf16 bag
-    (configs[3]); bags rotate through a set larger than the 256 MiB Infinity Cache so every pass
-    streams from HBM.
-value = regions/s over ALL ranks (K steps per rank, max-over-ranks wall time between barriers);
-``abmil_fwd_ms`` is the HIP-event time of the CLAM_SB call inside the same timed steps.  With N > 1
-the steps are sharded "slide"-wise with no data-path collective and end with the one all-gather of
-per-slide logits / attention logits (weak scaling: per-GPU work is fixed).
+``python bench.py --gpus N`` with N > 1 and no torchrun environment starts the N ranks ITSELF (a child
+``python -m torch.distributed.run ...`` started before this process has touched the GPU; its output is relayed and its
+exit code returned): a run never silently measures fewer GPUs than it was asked for (``n_gpus != --gpus`` is an error).
 
-After the timed region rank 0 re-runs a few steps with the library's per-kernel HIP-event hooks to
-price the dominant kernel against its roofline, and (N = 1 only) times the numpy oracle on the host
-cores as the CPU baseline (a bounded sample, extrapolated; baseline only).
+One STEP (per GPU) = one pass of the hot path over one batch of synthetic input, inputs resident in HBM before the timed
+region:
+  * HIPT_4K.forward on R resident [3,4096,4096] fp32 regions -> R x 256 patches through ViT-256 -> ViT-4K over each
+    16x16 [CLS] grid -> [R,192]  (BASELINE.json configs[2], bf16 operands / fp32 accumulate);
+  * CLAM_SB.forward (gated-attention pooling + bag classifier) on one 100 000 x 384 bf16 bag (configs[3]); bags rotate
+    through a set larger than the 256 MiB Infinity Cache so every pass streams from HBM.
+value = regions/s over ALL ranks (K steps per rank, max-over-ranks wall time between barriers); ``abmil_fwd_ms`` is the
+HIP-event time of the CLAM_SB call inside the same timed steps (weak scaling: per-GPU work is fixed).
+
+After the timed region:
+  * ``config5`` (every N): BASELINE configs[4] -- 64 synthetic slides sharded slide i -> rank i mod N, per slide a stated
+    SAMPLE of its ~8 192 regions through HIPT_4K (resident pixels), the slide's bag through CLAM_SB, ONE all-gather of all
+    logits and ragged attention logits (``hipt_abmil_atec23_amd/pipeline.py``); slides/s extrapolated from the sample;
+  * rank 0 re-runs a few steps with the library's per-kernel HIP-event hooks to price the kernels against their
+    rooflines, measures the reference's own call patterns (one region per call; fp32 mode; one 256x256 patch in fp32 =
+    configs[1]) and (N = 1 only) times the CPU oracle on the host cores (baseline only).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 METRIC = "4K-regions/sec HIPT extract + ABMIL fwd ms @100k×384; 1/2/4/8 MI355X"
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
@@ -43,6 +46,47 @@ REGION = 4096
 # pruned figure then: per patch, block 12 keeps QKV (K and V of all tokens) and does QK^T / PV / proj / MLP for 1 of 257 rows.
 _BLOCK_TAIL = 50_725_632 + 50_725_632 + 75_792_384 + 606_339_072          # QK^T + PV + proj + MLP of one patch, one block
 FLOP_PER_REGION = 3_146_029_797_888 - 256 * (_BLOCK_TAIL - _BLOCK_TAIL // 257)
+FLOP_PER_REGION_FULL = 3_146_029_797_888
+LIB_CHUNK = 2048  # patches per ViT-256 pass when --chunk is 0 (capi.hip default_chunk)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--chunk", type=int, default=0, help="patches per ViT-256 pass (0 = library default, 2048)")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the regions of a step are spread over (tail filling)")
+    ap.add_argument("--u8", action="store_true", help="regions resident as uint8 RGB [R,W,H,3], normalised on the device (SURVEY 8f-1)")
+    ap.add_argument("--regions", type=int, default=24, help="4096x4096 regions per HIPT_4K call (1 = the reference's batch_size)")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the batch-1 / fp32 / single-patch figures")
+    ap.add_argument("--slides", type=int, default=64, help="config 5: synthetic slides over all ranks (0 = skip the leg)")
+    ap.add_argument("--slide-regions", type=int, default=8192, help="config 5: nominal regions per slide")
+    ap.add_argument("--slide-sample", type=int, default=8, help="config 5: regions per slide actually extracted (stated sub-sample)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args) -> int:
+    """--gpus N > 1 without a torchrun environment: start the N ranks as a CHILD job (this process has not initialised
+    the GPU and never will: torch.cuda.device_count() does not) and relay it."""
+    import socket
+
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def build_models(dev, dtype):
@@ -54,7 +98,10 @@ def build_models(dev, dtype):
     c = CLAM_SB(size_arg="hipt_384")
     c.load_state_dict(synth.make_state_dict(synth.clam_param_specs((384, 128, 64)), 384))
     c = c.eval().to(dev).set_compute_dtype(dtype)
-    return m, c
+    c192 = CLAM_SB(size_arg="hipt_big")  # the slide aggregator over HIPT_4K's 192-d region features (docs/README.md:69)
+    c192.load_state_dict(synth.make_state_dict(synth.clam_param_specs((192, 128, 64)), 192))
+    c192 = c192.eval().to(dev).set_compute_dtype(dtype)
+    return m, c, c192
 
 
 def kernel_flops(cat, rows, D=384, H=1536, heads=6, ntok=257):
@@ -65,17 +112,7 @@ def kernel_flops(cat, rows, D=384, H=1536, heads=6, ntok=257):
             "attention": 4 * (rows // ntok) * heads * ntok * ntok * dh}.get(cat)
 
 
-def step_flops(cat, rows, passes, ntok=257):
-    """Algorithmic FLOPs of a category over one step: `passes` chunks of `rows` token rows through 12 blocks, the last
-    block pruned to the [CLS] row for everything after QKV (1 of ntok rows; attention: 1 of ntok queries)."""
-    full = kernel_flops(cat, rows)
-    if full is None:
-        return None
-    return passes * (12 * full if cat == "qkv_gemm" else 11 * full + full // ntok)
-
-
-# rocprofv3 kernel names of the categories, most specific first (keys of profiles/<tag>_traffic.json; template
-# arguments of the pipelined kernels: <LN, dbg, packed weights, A image, out image, head-major out> / <dbg, packed, images, x-in image>)
+# rocprofv3 kernel names of the categories, most specific first (keys of profiles/<tag>_traffic.json)
 TRAFFIC_KEYS = {"mlp_fused": ["void mlp_pipe_kernel<0, true, true, true>", "void mlp_pipe_kernel<0, true, false, false>", "void mlp_pipe_kernel<0>"],
                 "qkv_gemm": ["void seqgemm_pipe_kernel<false, 0, true, true, false, true>", "void seqgemm_pipe_kernel<true, 0, true, false, false, false>",
                              "void seqgemm_pipe_kernel<true, 0>"],
@@ -86,14 +123,15 @@ TRAFFIC_KEYS = {"mlp_fused": ["void mlp_pipe_kernel<0, true, true, true>", "void
 
 
 def pmc_traffic(cat):
-    """Per-launch HBM bytes from the committed PMC summary (separate rocprofv3 --pmc passes, corrected
-    as MI355X_MICROARCH.md prescribes; tools/summarize_profile.py), or None."""
-    for f in sorted([p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_traffic.json")], reverse=True) \
-            if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-        t = json.load(open(os.path.join(ROOT, "profiles", f)))
+    """Per-launch HBM bytes from the newest committed PMC summary (separate rocprofv3 --pmc passes, corrected as
+    MI355X_MICROARCH.md prescribes; tools/summarize_profile.py), or None."""
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted([p for p in os.listdir(pdir) if p.endswith("_traffic.json")], reverse=True) if os.path.isdir(pdir) else []:
+        t = json.load(open(os.path.join(pdir, f)))
         for k in TRAFFIC_KEYS.get(cat, []):
-            if k in t:
-                return t[k]["hbm_bytes"]
+            for name, v in t.items():
+                if name.startswith(k) or k in name:
+                    return v["hbm_bytes"]
     return None
 
 
@@ -109,76 +147,103 @@ def host_cores():
     return min(n, int(os.environ.get("HIPT_BENCH_CPU_THREADS", "16")))
 
 
-def cpu_baseline(budget_s=12.0):
-    """numpy-oracle ("port") timing on the host cores: ViT-256 on a bounded sample of patches of one
-    region (+ the full ViT-4K), extrapolated to regions/s; CLAM_SB on the full 100k x 384 bag."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline():
+    """SURVEY.md §8(d) / BASELINE.md §4: the PyTorch-CPU restatement of the path (oracle/torch_cpu.py, pinned against the
+    reference's outputs by tests/test_oracle_vs_golden.py) on the box's host cores, fp32, torch.set_num_threads(cores),
+    warm-up 2 + min-of-5: ViT-256 on 16 patches (extrapolated to the 256 of a region) + one full ViT-4K; CLAM_SB on the
+    2 000 x 384 and the 100 000 x 384 bag.  The numpy oracle's figure is kept as ``numpy_port``."""
+    import numpy as np
+    import torch
+
     from hipt_abmil_atec23_amd import synth
     from oracle import hipt_oracle as O
+    from oracle import torch_cpu as TO
     cores = host_cores()
-    try:  # keep the BLAS pool inside the box's CPU share (oversubscription makes numpy crawl)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
         from threadpoolctl import threadpool_limits
         threadpool_limits(limits=cores)
     except Exception:
         pass
-    p256 = synth.make_params_np(synth.vit_param_specs("vit256"), 256)
-    p4k = synth.make_params_np(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096)
-    pc = synth.make_params_np(synth.clam_param_specs((384, 128, 64)), 384)
-    x = synth.hash_uniform_np((8, 3, 256, 256), 3)
-    O.vit256_forward(x[:2], p256)  # warm-up (BLAS thread pool, page-in)
+
+    def best(fn, warm=2, reps=5):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts)
+
+    p256n = synth.make_params_np(synth.vit_param_specs("vit256"), 256)
+    p4kn = synth.make_params_np(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096)
+    pcn = synth.make_params_np(synth.clam_param_specs((384, 128, 64)), 384)
+    p256, p4k, pc = TO.to_torch(p256n), TO.to_torch(p4kn), TO.to_torch(pcn)
+    pos256 = torch.from_numpy(O.interpolate_pos_encoding(p256n["pos_embed"], 256, 256, 256, 16))
+    pos4k = torch.from_numpy(O.interpolate_pos_encoding(p4kn["pos_embed"], 256, 16, 16, 1))
+    n_p = 16
+    with torch.no_grad():
+        x = torch.from_numpy(synth.hash_uniform_np((n_p, 3, 256, 256), 3))
+        t_p = best(lambda: TO.vit256_forward(x, p256, pos256))
+        t_1 = best(lambda: TO.vit256_forward(x[:1], p256, pos256))
+        g = torch.from_numpy(synth.hash_uniform_np((1, 384, 16, 16), 4))
+        t_4k = best(lambda: TO.vit4k_forward(g, p4k, pos4k))
+        bag = torch.from_numpy(synth.hash_uniform_np((BAG_N, BAG_S0), 4))
+        t_2k = best(lambda: TO.clam_sb_forward(bag[:2000], pc))
+        t_100k = best(lambda: TO.clam_sb_forward(bag, pc))
+    region_s = t_p / n_p * 256 + t_4k
+    # the numpy oracle, one un-repeated bounded sample (round 1's figure, kept for continuity)
+    xs = synth.hash_uniform_np((8, 3, 256, 256), 3)
+    O.vit256_forward(xs[:2], p256n)
     t0 = time.perf_counter()
-    O.vit256_forward(x, p256)
-    t8 = time.perf_counter() - t0
-    n = int(max(8, min(256, 8 * (budget_s * 0.8 / max(t8, 1e-3)) // 8 * 8)))
-    xs = synth.hash_uniform_np((n, 3, 256, 256), 3)
-    t0 = time.perf_counter()
-    for i in range(0, n, 16):
-        O.vit256_forward(xs[i:i + 16], p256)
-    t_patches = time.perf_counter() - t0
-    g = synth.hash_uniform_np((1, 384, 16, 16), 4)
-    t0 = time.perf_counter()
-    O.vit4k_forward(g, p4k)
-    t4k = time.perf_counter() - t0
-    region_s = t_patches / n * 256 + t4k
-    bag = synth.hash_uniform_np((BAG_N, BAG_S0), 4)
-    O.clam_sb_forward(bag[:1000], pc)
-    t0 = time.perf_counter()
-    O.clam_sb_forward(bag, pc)
-    tb = time.perf_counter() - t0
-    return {"value": 1.0 / region_s, "unit": "regions/s", "cores": cores, "kind": "port",
-            "sample": f"numpy fp32 oracle: ViT-256 on {n} of the 256 patches of one 4096x4096 region "
-                      f"({t_patches:.2f} s) + full ViT-4K ({t4k * 1e3:.0f} ms), extrapolated to one region; "
-                      f"CLAM_SB on the full 100000x384 fp32 bag",
-            "abmil_fwd_ms": tb * 1e3, "seconds_per_region": region_s}
+    O.vit256_forward(xs, p256n)
+    t_np = (time.perf_counter() - t0) / 8 * 256
+    torch.set_num_threads(prev)
+    return {"value": 1.0 / region_s, "unit": "regions/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": f"PyTorch-CPU fp32 restatement (oracle/torch_cpu.py), {cores} threads, warm-up 2 + min of 5: ViT-256 on {n_p} of the "
+                      f"256 patches of one 4096x4096 region ({t_p:.2f} s) extrapolated + one full ViT-4K ({t_4k * 1e3:.1f} ms); "
+                      f"CLAM_SB on the full 2000x384 and 100000x384 fp32 bags",
+            "patches_per_s": n_p / t_p, "seconds_per_region": region_s, "vit256_one_patch_ms": t_1 * 1e3,
+            "abmil_fwd_ms": t_100k * 1e3, "abmil_2000_fwd_ms": t_2k * 1e3,
+            "numpy_port": {"regions_per_s": 1.0 / (t_np + t_4k), "sample": "numpy oracle, ViT-256 on 8 patches, one pass, extrapolated"}}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--chunk", type=int, default=0, help="patches per ViT-256 pass (0 = library default)")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams the regions of a step are spread over (tail filling)")
-    ap.add_argument("--u8", action="store_true", help="regions resident as uint8 RGB [R,W,H,3], normalised on the device (SURVEY 8f-1)")
-    ap.add_argument("--regions", type=int, default=24, help="4096x4096 regions per HIPT_4K call (1 = the reference's batch_size)")
-    ap.add_argument("--profile-steps", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import numpy as np
+    import torch
 
     from hipt_abmil_atec23_amd import _native as N
     from hipt_abmil_atec23_amd import distributed as D
+    from hipt_abmil_atec23_amd import pipeline as PL
     from hipt_abmil_atec23_amd import synth
 
     rank, world, local = D.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the job has WORLD_SIZE={world} rank(s): refusing to report a number for a "
+                         f"different GPU count than asked for")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     N.lib()  # fail loudly before doing anything if the native library is missing
 
-    model, clam = build_models(dev, args.dtype)
+    model, clam, clam192 = build_models(dev, args.dtype)
     model.streams = args.streams
     model.chunk = args.chunk
     R = args.regions
@@ -190,10 +255,7 @@ def main():
     bags = [synth.hash_uniform_torch((BAG_N, BAG_S0), 40 + 10 * rank + i, device=dev).to(bag_dt) for i in range(n_bags)]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    feats, slide_logits, last_a = [], [], None
-
     def step(i, timed):
-        nonlocal last_a
         f = model(region)
         if timed:
             ev[i][0].record()
@@ -201,9 +263,7 @@ def main():
             logits, _, _, a_raw, _ = clam(bags[i % n_bags])
         if timed:
             ev[i][1].record()
-            feats.append(f)
-            slide_logits.append(logits)
-        last_a = a_raw
+        return f, logits, a_raw
 
     def barrier():
         if world > 1:
@@ -215,33 +275,77 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i, True)
-    if world > 1:  # the one collective of the job: per-slide logits + attention logits of every rank
-        D.gather_slide_outputs([rank], [slide_logits[-1]], [last_a], world, device=dev)
+        last = step(i, True)
+    if world > 1:  # the one collective of a job: per-slide logits + attention logits of every rank
+        D.gather_slide_outputs([rank], [last[1]], [last[2]], world, device=dev)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
-    abmil_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    abmil_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else None
+
+    # ---- config 5 (BASELINE configs[4]): slides sharded over the ranks, one all-gather ----
+    cfg5 = None
+    if args.slides > 0:
+        slides = PL.synthetic_slides(args.slides, args.slide_regions)
+        ns = min(args.slide_sample, R)
+        calls = [0]
+
+        def resident(spec, idx):  # resident pixels: nothing is generated inside the timed region
+            s = (calls[0] * ns) % max(1, R - ns + 1)
+            calls[0] += 1
+            return region[s:s + len(idx)]
+
+        run5 = lambda: PL.process_slides(model, clam192, slides, rank, world, device=dev, regions_per_call=ns, sample_regions=ns,
+                                         region_source=resident, expand_bag=True)
+        run5()  # warm-up (first CLAM_SB [192,128,64] call, gather buffers)
+        barrier()
+        t5 = time.perf_counter()
+        r5 = run5()
+        barrier()
+        d5 = torch.tensor([time.perf_counter() - t5], dtype=torch.float64, device=dev)
+        nreg = torch.tensor([r5.local_regions], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(d5, op=torch.distributed.ReduceOp.MAX)
+            torch.distributed.all_reduce(nreg, op=torch.distributed.ReduceOp.SUM)
+        d5, nreg = float(d5.item()), float(nreg.item())
+        total_regions = sum(s.n_regions for s in slides)
+        cfg5 = {"slides": args.slides, "regions_per_slide_nominal": args.slide_regions, "regions_sampled_per_slide": ns,
+                "seconds": d5, "regions_per_s": nreg / d5, "sampled_slides_per_s": args.slides / d5,
+                "slides_per_s_extrapolated": args.slides / (d5 * total_regions / nreg),
+                "note": "slide i -> rank i mod G; per slide the sampled regions through HIPT_4K (bf16), the features tiled to the slide's "
+                        "n regions, CLAM_SB [192,128,64], ONE all-gather of logits + ragged A_raw; extrapolation = measured time x "
+                        "(all regions / sampled regions), i.e. it charges the per-slide CLAM_SB + gather at the sampled rate",
+                "gathered_logits_shape": list(r5.logits.shape), "gathered_a_raw_total": int(sum(a.numel() for a in r5.a_raw))}
 
     if rank != 0:
+        if world > 1:
+            torch.distributed.barrier()  # rank 0's single-GPU legs below: keep the group alive until it is done
+            torch.distributed.destroy_process_group()
         return
+
+    chunk = args.chunk or LIB_CHUNK
+    per_stream = -(-R // max(1, min(args.streams, R))) * 256
     out = {
         "metric": METRIC, "value": world * args.steps * R / dt, "unit": "regions/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "per step: HIPT_4K.forward on R resident [3,4096,4096] fp32 regions (R x 256 patches ViT-256 -> "
                                "ViT-4K over each 16x16 [CLS] grid, BASELINE configs[2]) + CLAM_SB gated-attention pooling over one "
-                               "100000x384 bag (configs[3]); random-init weights of the reference architectures",
-                   "regions_per_step": R, "streams": args.streams, "input": "uint8 RGB interleaved" if args.u8 else "fp32 normalised", "bag": [BAG_N, BAG_S0], "chunk_patches": args.chunk or 256 * R,
-                   "parallelism": f"slide-sharded x{world}, one all-gather"},
+                               "100000x384 bag (configs[3], the bag resident in the compute dtype); random-init weights of the "
+                               "reference architectures",
+                   "regions_per_step": R, "streams": args.streams, "input": "uint8 RGB interleaved" if args.u8 else "fp32 normalised",
+                   "bag": [BAG_N, BAG_S0], "bag_dtype": "bf16-resident" if args.dtype == "bf16" else "fp32-resident",
+                   "chunk_patches": min(chunk, per_stream), "parallelism": f"slide-sharded x{world}, one all-gather"},
         "abmil_fwd_ms": abmil_ms,
         "model_tflops": world * args.steps * R * FLOP_PER_REGION / dt / 1e12,
     }
+    if cfg5:
+        out["config5"] = cfg5
 
-    # ---- per-kernel roofline leg: same workload, HIP events around every launch ----
+    # ---- per-kernel roofline leg: same workload, HIP events around every launch, ONE stream ----
     prof = {}
     if args.profile_steps > 0:
         model.streams = 1  # per-launch HIP events: one stream, so that a kernel's time is its own (no other kernel on the CUs)
@@ -251,37 +355,82 @@ def main():
         torch.cuda.synchronize()
         prof = N.profile_read()
         N.profile_enable(False)
-    chunk_rows = (args.chunk or 256 * R) * 257
-    passes = (256 * R) // (args.chunk or 256 * R)  # ViT-256 passes (chunks of patches) per step
+        model.streams = args.streams
     kernels = {}
     for cat, (ms, cnt) in prof.items():
         kernels[cat] = {"launches_per_step": cnt / args.profile_steps, "total_ms": ms, "avg_us": ms / cnt * 1e3,
                         "ms_per_step": ms / args.profile_steps}
     out["kernels"] = kernels
-    mf = {c: v for c, v in kernels.items() if kernel_flops(c, chunk_rows)}
-    if mf:
-        # dominant kernel = largest share of the step.  Each category holds the 12 ViT-256 launches of a step (11 over
-        # R x 65 792 rows, the last block's over the R x 256 [CLS] rows): achieved = their algorithmic FLOPs / their
-        # HIP-event time; avg_launch_us is the average over the 12.
-        dom = max(mf, key=lambda c: mf[c]["ms_per_step"])
-        fl_step = step_flops(dom, chunk_rows, passes)  # (the ViT-4K launches are booked under 'vit4k_blocks')
-        ach = fl_step / (mf[dom]["ms_per_step"] * 1e-3) / 1e12
-        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                           "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": pmc_traffic(dom),
-                           "flops_per_step": fl_step, "launches_per_step": mf[dom]["launches_per_step"],
-                           "avg_launch_us": mf[dom]["avg_us"]}
-        out["roofline_all"] = {c: round(step_flops(c, chunk_rows, passes) /
-                                        (v["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4) for c, v in mf.items()}
+    # every launch of these categories is a full-size one (the [CLS]-row launches of the pruned last block are booked
+    # under 'last_block_cls'): rows per launch = one chunk of patches x 257, or all of the step's patches when fewer
+    rows_launch = min(chunk, 256 * R) * 257
+    mf = {c: v for c, v in kernels.items() if kernel_flops(c, rows_launch)}
+    if mf and (256 * R) % min(chunk, 256 * R) == 0:
+        frac = {}
+        for c, v in mf.items():
+            ach = kernel_flops(c, rows_launch) / (v["avg_us"] * 1e-6) / 1e12
+            frac[c] = {"achieved": ach, "frac": ach / PEAK_TFLOPS[args.dtype], "avg_launch_us": v["avg_us"], "launches_per_step": v["launches_per_step"]}
+        dom = max(mf, key=lambda c: mf[c]["ms_per_step"])  # dominant kernel = largest share of the step
+        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": frac[dom]["achieved"], "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                           "frac": frac[dom]["frac"], "traffic": pmc_traffic(dom), "flops_per_launch": kernel_flops(dom, rows_launch),
+                           "rows_per_launch": rows_launch, "launches_per_step": mf[dom]["launches_per_step"], "avg_launch_us": mf[dom]["avg_us"]}
+        out["roofline_all"] = {c: round(f["frac"], 4) for c, f in frac.items()}
+        if all(c in frac for c in ("qkv_gemm", "attention", "proj_gemm")):
+            # north_star's "ViT-256 attention" unit: LN1 + QKV + QK^T + softmax + PV + proj = 404 620 800 FLOP per patch and block
+            us = sum(frac[c]["avg_launch_us"] for c in ("qkv_gemm", "attention", "proj_gemm"))
+            fl = sum(kernel_flops(c, rows_launch) for c in ("qkv_gemm", "attention", "proj_gemm"))
+            out["roofline_attention_unit"] = {"kernels": ["qkv_gemm", "attention", "proj_gemm"], "bound": "mfma", "us_per_launch_set": us,
+                                              "achieved": fl / (us * 1e-6) / 1e12, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                                              "frac": fl / (us * 1e-6) / 1e12 / PEAK_TFLOPS[args.dtype], "target": 0.60}
     if "abmil_fused" in kernels:
         esz = 2 if args.dtype == "bf16" else 4
         alg = BAG_N * BAG_S0 * esz + 4 * BAG_N
         gbs = alg / (kernels["abmil_fused"]["avg_us"] * 1e-6) / 1e9
         out["roofline_abmil"] = {"kernel": "abmil_fused", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": gbs / PEAK_HBM_GBS, "traffic": pmc_traffic("abmil_fused"), "algorithmic_bytes": alg,
-                                 "avg_launch_us": kernels["abmil_fused"]["avg_us"]}
+                                 "avg_launch_us": kernels["abmil_fused"]["avg_us"], "target": 0.50}
+
+    # ---- the reference's own call patterns (SURVEY.md §8d configs 2-3 as the unmodified scripts issue them) ----
+    if not args.no_extras:
+        def timed(fn, n, warm=2):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+
+        ex = {}
+        one = region[:1]
+        model.streams = 1
+        ex["batch1_regions_per_s"] = 1.0 / timed(lambda: model(one), 10)  # extract_features_fp.py:159-171: batch_size 1
+        if not args.u8:
+            model.set_compute_dtype("fp32")  # the reference's own precision (exact-fp32 MFMA kernels, 1e-4 parity mode)
+            t32 = timed(lambda: model(one), 2, warm=1)
+            ex["fp32_regions_per_s"] = 1.0 / t32
+            ex["fp32_model_tflops"] = FLOP_PER_REGION_FULL / t32 / 1e12
+            ex["fp32_frac_of_fp32_mfma_peak"] = ex["fp32_model_tflops"] / PEAK_TFLOPS["fp32"]
+            patch = synth.hash_uniform_torch((1, 3, 256, 256), 2, device=dev)
+            ex["config2_vit256_one_patch_fp32_ms"] = timed(lambda: model.model256(patch), 20) * 1e3  # BASELINE configs[1]
+            model.set_compute_dtype(args.dtype)
+            ex["config2_vit256_one_patch_bf16_ms"] = timed(lambda: model.model256(patch), 20) * 1e3
+        bag2k = synth.hash_uniform_torch((2000, BAG_S0), 1, device=dev)
+        clam.set_compute_dtype("fp32")
+        with torch.no_grad():
+            ex["clam_sb_2000x384_fp32_ms"] = timed(lambda: clam(bag2k), 20) * 1e3  # BASELINE configs[0] on the GPU
+        clam.set_compute_dtype(args.dtype)
+        model.streams = args.streams
+        out["extras"] = ex
+
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
+    sys.stdout.flush()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

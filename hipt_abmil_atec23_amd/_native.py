@@ -12,12 +12,13 @@ import subprocess
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhipt_abmil.so")
+# HIPT_AMD_LIB selects another build of the same ABI (the diagnostic twin libhipt_abmil_dbg.so of `make DEBUG_STAMPS=1`)
+LIB_PATH = os.environ.get("HIPT_AMD_LIB") or os.path.join(HERE, "libhipt_abmil.so")
 CSRC = os.path.join(HERE, "csrc")
 
 HIPT_F32, HIPT_BF16 = 0, 1
 EPI_GELU, EPI_RESID, EPI_OUT_F32, EPI_RELU = 1, 2, 4, 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 PACK_QKV, PACK_PROJ, PACK_MLP = 0, 1, 2
 
 c_f32p = C.c_void_p  # device pointers travel as integers
@@ -32,6 +33,7 @@ class BlockWeights(C.Structure):
 class VitWeights(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("dim", C.c_int32), ("depth", C.c_int32), ("heads", C.c_int32),
                 ("hidden", C.c_int32), ("ntok", C.c_int32), ("embed_k", C.c_int32), ("ln_eps", C.c_float),
+                ("attn_scale", C.c_float), ("reserved", C.c_int32),
                 ("embed_w", C.c_void_p), ("embed_b", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("blocks", C.POINTER(BlockWeights))]
 
@@ -80,6 +82,7 @@ SIGNATURES = {
     "hipt_hipt4k_forward_u8": (_i, [_VW, _VW, _p, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "hipt_u8_normalize": (_i, [_p, _i, C.c_int64, C.c_int64, _p, _i, _p]),
     "hipt_clam_workspace_bytes": (_sz, [_CW, _i]),
+    "hipt_clam_ticket_offset": (_sz, [_CW, _i]),
     "hipt_clam_sb_forward": (_i, [_CW, _p, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "hipt_attn_net_gated": (_i, [_CW, _p, _i, _p, _p, _sz, _p]),
     "hipt_clam_gather_h1": (_i, [_CW, _p, _p, _i, _p, _p]),
@@ -137,16 +140,51 @@ def check(rc: int, what: str = "") -> None:
         raise RuntimeError(f"libhipt_abmil: {what} failed with code {rc}: {msg}")
 
 
+class StreamArg(C.c_void_p):
+    """A hipStream_t argument that remembers which device it belongs to (see ``call``)."""
+    device = None
+
+
 def call(name: str, *args):
-    """Invoke an int-returning entry point and raise on a non-zero status."""
+    """Invoke an int-returning entry point and raise on a non-zero status.
+
+    The library launches on the calling thread's CURRENT device (kernel launches, hipMemsetAsync and the per-device
+    hipFuncSetAttribute opt-ins all follow it), so the call is made with the device of its stream argument current:
+    a module on cuda:1 while cuda:0 is current, or HIPT_4K's device256 != device4k placement (hipt_4k.py:39-46), would
+    otherwise enqueue on the wrong GPU's stream against foreign memory."""
     global calls
     calls += 1
+    dev = next((a.device for a in args if isinstance(a, StreamArg)), None)
+    if dev is not None:
+        import torch
+        if dev.index != torch.cuda.current_device():
+            with torch.cuda.device(dev):
+                check(getattr(lib(), name)(*args), name)
+            return
     check(getattr(lib(), name)(*args), name)
 
 
-def stream_ptr(device=None):
+def stream_ptr(device=None) -> StreamArg:
+    """The current HIP stream of ``device`` (default: the current device) as a call argument."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError(f"stream_ptr: {dev} is not a HIP device")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    s = StreamArg(torch.cuda.current_stream(dev).cuda_stream)
+    s.device = dev
+    return s
+
+
+def same_device(what: str, ref_device, *tensors) -> None:
+    """Every tensor whose address is handed to a kernel must live on the device the kernel runs on: a parameter left on
+    the CPU (relocate() never called) or on another GPU would be a wild pointer on the GPU -- the reference raises a
+    device-mismatch RuntimeError there, and so does this."""
+    for t in tensors:
+        if t is not None and t.device != ref_device:
+            raise RuntimeError(f"{what}: expected all tensors on {ref_device}, found one on {t.device} "
+                               f"(move the module and its input to the same HIP device)")
 
 
 def ptr(t):

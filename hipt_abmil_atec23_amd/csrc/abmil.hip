@@ -488,13 +488,14 @@ int launch_fused(const hipt_clam_weights* w, const void* bag, int N, int attenti
     const int ntiles = (N + TM - 1) / TM;
     int grid = ntiles < 512 ? ntiles : 512;
     auto k = abmil_fused_kernel<T, S1, S2>;
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce once;
+    HIPT_CUR_DEVICE(dev);
+    if (!once.done[dev]) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(abmil) failed");
             return HIPT_E_LAUNCH;
         }
-        attr = true;
+        once.done[dev] = true;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), G::LDS, st, (const T*)bag, N, w->s0, (const T*)w->w1, w->b1,
                        (const T*)w->wab, w->bab, w->wc, w->bc, A_raw, partials, attention_only);

@@ -118,7 +118,14 @@ __device__ __forceinline__ void finish_bag(char* smem, f32x4 (&pool)[8], float m
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int* flag = (int*)(red + 600);
-        if (tid == 0) *flag = atomicAdd(ticket, 1u) == gridDim.x - 1;
+        if (tid == 0) {
+            const bool last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+            *flag = last;
+            // the ticket is an arrival COUNTER that starts at zero (hipt_clam_sb_forward's contract: the caller zeroes the
+            // ticket block once, when it allocates the workspace) and that the last arriver puts back to zero: correct for
+            // any dispatch order and any mix of streams, replayable from a graph, no memset node per call
+            if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
         if (*flag) {
             const int G = gridDim.x, stride = 2 + S1;
@@ -208,12 +215,11 @@ __global__ __launch_bounds__(256, 1) void abmil_stream_kernel(const bf16_t* __re
                                                               int64_t* __restrict__ Y_hat) {
 #define ASTAMP(k)                                                                                          \
     do {                                                                                                   \
-        if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if (HIPT_STAMPS_ON(stamps) && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
     ASTAMP(0);
-    // finish ticket of the fused combine: workgroup 0 (dispatched first) clears it with its first instruction; every
-    // workgroup adds to it only when its rows are done, tens of microseconds later (a stream memset costs ~10 us)
-    if (ticket && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (finish ticket of the fused combine: zero on entry -- the caller zeroes it once, the last arriver of every launch
+    //  puts it back to zero, see finish_bag -- so nothing depends on which workgroup is dispatched first)
     constexpr int S0 = KS * 64;
     constexpr int NC = KS * 2;  // 16-byte chunks per lane per row
     extern __shared__ __attribute__((aligned(16))) char smem[];  // W1 image (KS slabs) | [Wa;Wb] image (2 slabs)
@@ -498,7 +504,6 @@ __global__ __launch_bounds__(256, 1) void abmil_pipe_kernel(const bf16_t* __rest
                                                             float* __restrict__ M, float* __restrict__ logits,
                                                             float* __restrict__ Y_prob, int64_t* __restrict__ Y_hat) {
     ASTAMP(0);
-    if (ticket && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr int KS = 6, S0 = 384, NC = 12;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // W1 image (6 slabs) | [Wa;Wb] image (2 slabs) | constants
 
@@ -809,34 +814,40 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
            int* n_partials, unsigned* ticket, float* M, float* logits, float* Y_prob, int64_t* Y_hat, hipStream_t st) {
     constexpr int lds = (KS + 2) * SLAB + (S1 + 3 * S2) * 4;
     auto k = abmil_stream_kernel<KS>;
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce once;
+    HIPT_CUR_DEVICE(dev);
+    if (!once.done[dev]) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(abmil stream) failed");
             return HIPT_E_LAUNCH;
         }
-        attr = true;
+        once.done[dev] = true;
     }
     // contiguous row ranges per wave, multiples of 16 rows; at most 256 workgroups x 4 waves
     int rows = (N + 1023) / 1024;
     rows = (rows + 15) / 16 * 16;
     const int waves = (N + rows - 1) / rows;
     const int grid = (waves + 3) / 4;
+#ifdef HIPT_DEBUG_STAMPS  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
     static const bool want_stamps = getenv("HIPT_ABMIL_STAMPS") != nullptr;
     static unsigned long long* dbuf = nullptr;
     if (want_stamps && !dbuf) (void)hipMalloc(&dbuf, 512 * 8 * sizeof(unsigned long long));
+#else
+    constexpr bool want_stamps = false;
+    constexpr unsigned long long* dbuf = nullptr;
+#endif
     const bool fuse = !attention_only && ticket && M && w->n_classes <= 64 && grid <= 256;
     static const bool no_pipe = getenv("HIPT_NO_ABMIL_PIPE") != nullptr;
     const bool piped = KS == 6 && !no_pipe;
     if (piped) {
         auto kp = abmil_pipe_kernel;
-        static bool attr_p = false;
-        if (!attr_p) {
+        static DevOnce once_p;
+        if (!once_p.done[dev]) {
             if (hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
                 hipt_set_error("hipFuncSetAttribute(abmil pipe) failed");
                 return HIPT_E_LAUNCH;
             }
-            attr_p = true;
+            once_p.done[dev] = true;
         }
         hipLaunchKernelGGL(kp, dim3(grid), dim3(256), lds, st, (const bf16_t*)bag, N, rows, (const bf16_t*)w->w1, w->b1,
                            (const bf16_t*)w->wab, w->bab, w->wc, w->bc, A_raw, partials, attention_only,
@@ -846,6 +857,7 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
                        (const bf16_t*)w->wab, w->bab, w->wc, w->bc, A_raw, partials, attention_only, want_stamps ? dbuf : nullptr,
                        fuse ? ticket : nullptr, w->wcls, w->bcls, w->n_classes, M, logits, Y_prob, Y_hat);
     HIPT_CHECK_LAUNCH();
+#ifdef HIPT_DEBUG_STAMPS
     if (want_stamps && grid <= 512) {
         static unsigned long long h[512 * 8];
         (void)hipStreamSynchronize(st);
@@ -866,6 +878,7 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
                 piped ? "- / step 0 phase 1 / its gate GEMM / steps 1.. + drain:" : "issue loads / step 0 / step 1 / steps 2..:", ph[1], ph[2], ph[3],
                 ph[4], ph[5]);
     }
+#endif
     *n_partials = fuse ? 0 : grid;  // 0: the kernel has already produced M / logits / Y_prob / Y_hat
     return HIPT_OK;
 }

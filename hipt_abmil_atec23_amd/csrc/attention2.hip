@@ -220,14 +220,15 @@ bool hipt_attention64_supported(int dtype, int dh, int ntok, bool want_probs) {
 int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st, int out_img, int qkv_hm) {
     HIPT_CHECK_ARG(!out_img || (heads * DH == 384 && ((int64_t)B * ntok) % 16 == 0), "attention64: image output needs D = 384 and whole 16-row fragments");
     constexpr int lds = 2 * ROWS * RB;
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce once;
+    HIPT_CUR_DEVICE(dev);
+    if (!once.done[dev]) {
         if (hipFuncSetAttribute((const void*)attn64_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
             hipFuncSetAttribute((const void*)attn64_kernel<NKT - 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(attention64) failed");
             return HIPT_E_LAUNCH;
         }
-        attr = true;
+        once.done[dev] = true;
     }
     hipLaunchKernelGGL(ntok <= ROWS - 16 ? attn64_kernel<NKT - 1> : attn64_kernel<NKT>, dim3(B * heads), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, ntok, heads,
                        scale * 1.4426950408889634f, out_img, qkv_hm);

@@ -37,10 +37,10 @@ struct Carver {
 };
 
 // ---- optional per-kernel timing (bench.py's roofline leg): HIP events around every launch -----
-enum { PC_EMBED, PC_LN, PC_QKV, PC_ATTN, PC_PROJ, PC_FC1, PC_FC2, PC_MLP, PC_ABMIL, PC_COMBINE, PC_OTHER, PC_VIT4K, PC_N };
+enum { PC_EMBED, PC_LN, PC_QKV, PC_ATTN, PC_PROJ, PC_FC1, PC_FC2, PC_MLP, PC_ABMIL, PC_COMBINE, PC_OTHER, PC_VIT4K, PC_LASTCLS, PC_N };
 const char* const kProfNames[PC_N] = {"embed_gemm", "layernorm", "qkv_gemm", "attention", "proj_gemm",
                                       "fc1_gemm",   "fc2_gemm",  "mlp_fused",   "abmil_fused", "abmil_combine", "other",
-                                      "vit4k_blocks"};
+                                      "vit4k_blocks", "last_block_cls"};
 constexpr int kProfMax = 8192;
 struct Prof {
     bool on = false, created = false;
@@ -84,6 +84,9 @@ int check_vit(const hipt_vit_weights* w) {
     }
     return HIPT_OK;
 }
+
+// Attention.scale (vision_transformer.py:112): qk_scale when the module was built with one, else head_dim ** -0.5
+inline float attn_scale(const hipt_vit_weights* w) { return w->attn_scale > 0.f ? w->attn_scale : 1.0f / sqrtf((float)(w->dim / w->heads)); }
 
 struct BlockScratch {
     void *xn, *qkv, *att, *hid;
@@ -130,7 +133,7 @@ int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* 
 int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, float* probs, const BlockScratch& s,
                hipStream_t st, bool emit_last = false, bool* have_xn_out = nullptr, bool img_ok = false, bool* x_img_out = nullptr) {
     const int D = w->dim, M = nseq * w->ntok, dt = w->dtype, dh = D / w->heads;
-    const float scale = 1.0f / sqrtf((float)dh);  // head_dim ** -0.5 (vision_transformer.py:112)
+    const float scale = attn_scale(w);
     int rc;
     const bool seq = hipt_seqgemm_supported(dt, D) && hipt_mlp_supported(dt, D, w->hidden) && getenv("HIPT_NO_SEQGEMM") == nullptr;
     // timing categories: the kernels of the small second-level ViT (D = 192, a few hundred rows) are booked together,
@@ -242,17 +245,18 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
     } else {
         PROF(PC_QKV, hipt_seqgemm_launch(q, true, 0, st));
     }
-    PROF(PC_ATTN, hipt_attn_cls_launch(s.qkv, s.att, nullptr, nseq, w->ntok, w->heads, D / w->heads, 1.0f / sqrtf((float)(D / w->heads)), st));
+    // (the [CLS]-row launches of the pruned block are booked apart: the per-kernel categories then hold full-size launches only)
+    PROF(PC_LASTCLS, hipt_attn_cls_launch(s.qkv, s.att, nullptr, nseq, w->ntok, w->heads, D / w->heads, attn_scale(w), st));
     PROF(PC_OTHER, hipt_gather_cls_launch(x, xc, nseq, (int64_t)w->ntok * D, D, st, x_img ? 1 : 0));
     q.M = nseq; q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
     q.counter = (int*)s.hid + 32;
-    PROF(PC_PROJ, hipt_seqgemm_launch(q, false, 0, st));
+    PROF(PC_LASTCLS, hipt_seqgemm_launch(q, false, 0, st));
     MlpParams m;
     memset(&m, 0, sizeof(m));
     m.x = xc; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
     m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.M = nseq; m.D = D; m.hidden = w->hidden;
     m.counter = (int*)s.hid;
-    PROF(PC_MLP, hipt_mlp_launch(m, st));
+    PROF(PC_LASTCLS, hipt_mlp_launch(m, st));
     return HIPT_OK;
 }
 
@@ -448,16 +452,12 @@ int hipt_vit_blocks(const hipt_vit_weights* w, float* x, int nseq, int blk_begin
 
 // the [CLS] row of the last block's attention map, probs_cls[nseq, heads, ntok], without the
 // [nseq, heads, ntok, ntok] tensor (heat-maps read attention[:, :, 0, 1:], hipt_4k.py:143-158).  x = prepared tokens
-// (modified: it ends as the input of the last block).  bf16 / head dim 64 only: HIPT_E_UNSUPPORTED otherwise.
+// (modified: it ends as the input of the last block).  Every dtype / head dim check_vit admits.
 int hipt_vit_cls_attention(const hipt_vit_weights* w, float* x, int nseq, float* probs_cls, void* workspace, size_t ws_bytes, void* stream) {
     int rc = check_vit(w);
     if (rc) return rc;
     HIPT_CHECK_ARG(x && probs_cls && nseq > 0, "vit_cls_attention: null/empty argument");
-    const int D = w->dim, dh = D / w->heads;
-    if (!(w->dtype == HIPT_BF16 && dh == 64 && w->ntok <= 320 && hipt_seqgemm_supported(w->dtype, D))) {
-        hipt_set_error("vit_cls_attention: bf16 weights with head dim 64 only");
-        return HIPT_E_UNSUPPORTED;
-    }
+    const int D = w->dim, dh = D / w->heads, M = nseq * w->ntok;
     Carver c(workspace, ws_bytes);
     BlockScratch s = carve_blocks(c, w, nseq);
     if (!c.ok()) {
@@ -465,20 +465,28 @@ int hipt_vit_cls_attention(const hipt_vit_weights* w, float* x, int nseq, float*
         return HIPT_E_WORKSPACE;
     }
     hipStream_t st = S(stream);
-    bool have_xn = false;
-    if ((rc = run_blocks(w, x, nseq, 0, w->depth - 1, nullptr, s, st, true, &have_xn))) return rc;
     const hipt_block_weights& b = w->blocks[w->depth - 1];
-    SeqGemmParams q;
-    memset(&q, 0, sizeof(q));
-    q.M = nseq * w->ntok; q.K = D; q.ln_eps = w->ln_eps;
-    q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.wpk = b.qkv_pk; q.N = 3 * D; q.bias = b.qkv_b;
-    q.out = s.qkv; q.ldc = 3 * D;
-    q.counter = (int*)s.hid + 16;
-    if (have_xn) {
-        q.A = s.att; q.ln_w = q.ln_b = nullptr;
+    if (w->dtype == HIPT_BF16 && dh == 64 && hipt_seqgemm_supported(w->dtype, D)) {  // ViT-256 hot case: chained kernels
+        bool have_xn = false;
+        if ((rc = run_blocks(w, x, nseq, 0, w->depth - 1, nullptr, s, st, true, &have_xn))) return rc;
+        SeqGemmParams q;
+        memset(&q, 0, sizeof(q));
+        q.M = M; q.K = D; q.ln_eps = w->ln_eps;
+        q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.wpk = b.qkv_pk; q.N = 3 * D; q.bias = b.qkv_b;
+        q.out = s.qkv; q.ldc = 3 * D;
+        q.counter = (int*)s.hid + 16;
+        if (have_xn) {
+            q.A = s.att; q.ln_w = q.ln_b = nullptr;
+        }
+        if ((rc = hipt_seqgemm_launch(q, !have_xn, 0, st))) return rc;
+        return hipt_attn_cls_launch(s.qkv, nullptr, probs_cls, nseq, w->ntok, w->heads, dh, attn_scale(w), st);
     }
-    if ((rc = hipt_seqgemm_launch(q, !have_xn, 0, st))) return rc;
-    return hipt_attn_cls_launch(s.qkv, nullptr, probs_cls, nseq, w->ntok, w->heads, dh, 1.0f / sqrtf((float)dh), st);
+    // every other configuration (fp32; head dim 32 = ViT-4K): the blocks before the last, then LayerNorm-1 + the QKV
+    // projection of the last one and the probabilities of the [CLS] query from the one-query kernel
+    if ((rc = run_blocks(w, x, nseq, 0, w->depth - 1, nullptr, s, st))) return rc;
+    if ((rc = hipt_layernorm_launch(x, D, b.ln1_w, b.ln1_b, s.xn, w->dtype, D, M, D, w->ln_eps, st))) return rc;
+    if ((rc = linear(s.xn, D, b.qkv_w, D, b.qkv_b, nullptr, s.qkv, 3 * D, M, 3 * D, D, w->dtype, 0, st, w->ntok))) return rc;
+    return hipt_attn_cls_probs_launch(s.qkv, probs_cls, nseq, w->ntok, w->heads, dh, attn_scale(w), w->dtype, st);
 }
 
 size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {
@@ -686,6 +694,8 @@ static size_t clam_partials_bytes(const hipt_clam_weights* w, int N) {
     const size_t g = 1024;  // fused: <= 512 workgroups; generic pool: <= 1024 row blocks
     return al256(g * (2 + w->s1) * 4);
 }
+
+size_t hipt_clam_ticket_offset(const hipt_clam_weights* w, int N) { return clam_partials_bytes(w, N); }
 
 size_t hipt_clam_workspace_bytes(const hipt_clam_weights* w, int N) {
     // partials | gmax | h1 fp32 | ab fp32 | h1 in dtype (generic path)

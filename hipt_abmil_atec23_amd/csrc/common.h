@@ -126,6 +126,32 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // host side -------------------------------------------------------------------------------
 void hipt_set_error(const char* fmt, ...);
+
+// hipFuncSetAttribute (the > 64 KiB dynamic-LDS opt-in) is a PER-DEVICE setting and a process may drive several GPUs
+// (HIPT_4K's device256 != device4k placement, a module on cuda:1 while cuda:0 is current): launchers cache it per
+// (kernel family, device).  hipt_cur_device(): ordinal of the calling thread's current device, -1 on failure.
+constexpr int HIPT_MAX_DEV = 64;
+struct DevOnce {
+    bool done[HIPT_MAX_DEV] = {};
+    int ncu[HIPT_MAX_DEV] = {};
+};
+inline int hipt_cur_device() {
+    int d = 0;
+    return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < HIPT_MAX_DEV) ? d : -1;
+}
+// In-kernel time stamps and the host code that reads them back (hipMalloc, hipStreamSynchronize, hipMemcpy) exist only in
+// diagnostic builds (make DEBUG_STAMPS=1 -> libhipt_abmil_dbg.so).
+#ifdef HIPT_DEBUG_STAMPS
+#define HIPT_STAMPS_ON(ptr) ((ptr) != nullptr)
+#else
+#define HIPT_STAMPS_ON(ptr) false
+#endif
+#define HIPT_CUR_DEVICE(dev)                                              \
+    const int dev = hipt_cur_device();                                    \
+    if (dev < 0) {                                                        \
+        hipt_set_error("%s:%d: hipGetDevice failed", __FILE__, __LINE__); \
+        return HIPT_E_LAUNCH;                                             \
+    }
 #define HIPT_CHECK_ARG(cond, ...)                \
     do {                                         \
         if (!(cond)) {                           \

@@ -196,14 +196,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
 template <typename T, int ALOAD, int FLAGS>
 int launch(const GemmParams& p, hipStream_t st) {
     const int tiles = ((p.M + p.rpt - 1) / p.rpt) * ((p.N + BN - 1) / BN);
-    static bool attr_set = false;  // > 64 KiB dynamic LDS needs the opt-in once per kernel
-    if (!attr_set) {
+    static DevOnce once;  // > 64 KiB dynamic LDS needs the opt-in once per kernel and device
+    HIPT_CUR_DEVICE(dev);
+    if (!once.done[dev]) {
         if (hipFuncSetAttribute((const void*)gemm_kernel<T, ALOAD, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GEMM_LDS) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(gemm) failed");
             return HIPT_E_LAUNCH;
         }
-        attr_set = true;
+        once.done[dev] = true;
     }
     hipLaunchKernelGGL((gemm_kernel<T, ALOAD, FLAGS>), dim3(tiles), dim3(512), GEMM_LDS, st, p);
     HIPT_CHECK_LAUNCH();

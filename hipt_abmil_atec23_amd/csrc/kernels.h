@@ -110,6 +110,8 @@ int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int hea
 
 // attention of the [CLS] query only (bf16, head dim 64): out[B, heads*64] bf16 and/or probs[B, heads, ntok] fp32 (either may be null)
 int hipt_attn_cls_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale, hipStream_t st);
+// probabilities of the [CLS] query only, any compute dtype, head dim 32 / 64: probs[B, heads, ntok] fp32
+int hipt_attn_cls_probs_launch(const void* qkv, float* probs, int B, int ntok, int heads, int dh, float scale, int dtype, hipStream_t st);
 // dst[s, :] = src[s * seq_stride ...] : the first row of every sequence (fp32)
 int hipt_gather_cls_launch(const float* src, float* dst, int nseq, int64_t seq_stride, int D, hipStream_t st, int img = 0);
 // x[s, 0, :] = cls + pos[0]  for s in [0, nseq)

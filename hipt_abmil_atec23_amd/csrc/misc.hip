@@ -238,6 +238,74 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const bf16_t* __restrict_
     }
 }
 
+// Attention PROBABILITIES of the [CLS] query only, any compute dtype, head dim 32 or 64 (what
+// get_last_selfattention(x)[:, :, 0, :] holds, HIPT_4K/hipt_4k.py:143-158, without the [B, heads, N, N] tensor): one
+// wave per (sequence, head), lane l scores keys l, l + 64, ... in fp32 (k-ordered fma chain), wave softmax.
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_cls_probs_kernel(const T* __restrict__ qkv, float* __restrict__ probs, int nbh, int ntok, int heads,
+                                                             float scale) {
+    constexpr int MAXK = 5, EPC = Tr<T>::EPC;  // up to 320 keys; elements per 16-byte chunk
+    const int lane = threadIdx.x & 63;
+    const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bh >= nbh) return;
+    const int b = bh / heads, h = bh % heads, D = heads * DH;
+    const int64_t tokstride = 3 * (int64_t)D;
+    const T* qrow = qkv + (int64_t)b * ntok * tokstride + h * DH;  // token 0
+    const T* kbase = qrow + D;
+    float q[DH];
+#pragma unroll
+    for (int c = 0; c < DH / EPC; ++c) {
+        const u32x4 raw = *(const u32x4*)(qrow + c * EPC);
+        if constexpr (sizeof(T) == 2) {
+            const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[c * 8 + e] = (float)v[e];
+        } else {
+            const f32x4 v = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[c * 4 + e] = v[e];
+        }
+    }
+    float sc[MAXK];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        const int key = j * 64 + lane;
+        sc[j] = -INFINITY;
+        if (key < ntok) {
+            const T* kr = kbase + key * tokstride;
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH / EPC; ++c) {
+                const u32x4 raw = *(const u32x4*)(kr + c * EPC);
+                if constexpr (sizeof(T) == 2) {
+                    const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a = __builtin_fmaf(q[c * 8 + e], (float)v[e], a);
+                } else {
+                    const f32x4 v = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = __builtin_fmaf(q[c * 4 + e], v[e], a);
+                }
+            }
+            sc[j] = a * scale;
+        }
+        m = fmaxf(m, sc[j]);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        sc[j] = expf(sc[j] - m);  // exp(-inf) = 0 for the keys past the end
+        l += sc[j];
+    }
+    l = wave_sum(l);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j)
+        if (j * 64 + lane < ntok) probs[(int64_t)bh * ntok + j * 64 + lane] = sc[j] * inv;
+}
+
 // dst[s, :] = src[s * ntok, :]  (fp32 rows of D floats: the [CLS] rows of the residual stream)
 // img: src is an fp32 activation image (kernels.h; D = 384, seq_stride a multiple of D): row r = s * seq_stride / D sits in
 // fragment r / 16 as li = r % 16; its 4 floats at column 4c are chunk c / 2 = g + 4 cc, half c & 1
@@ -262,6 +330,21 @@ int hipt_attn_cls_launch(const void* qkv, void* out, float* probs, int B, int nt
     const int nbh = B * heads;
     hipLaunchKernelGGL(attn_cls_kernel, dim3((nbh + 3) / 4), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, probs, nbh, ntok, heads,
                        scale);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}
+
+int hipt_attn_cls_probs_launch(const void* qkv, float* probs, int B, int ntok, int heads, int dh, float scale, int dtype, hipStream_t st) {
+    HIPT_CHECK_ARG((dh == 64 || dh == 32) && ntok > 0 && ntok <= 320, "attn_cls_probs: head dim 32 / 64 and <= 320 tokens (dh=%d ntok=%d)", dh, ntok);
+    const int nbh = B * heads;
+    const dim3 grid((nbh + 3) / 4), blk(256);
+#define CLSP(TT, DHH) hipLaunchKernelGGL((attn_cls_probs_kernel<TT, DHH>), grid, blk, 0, st, (const TT*)qkv, probs, nbh, ntok, heads, scale)
+    if (dtype == HIPT_BF16) {
+        if (dh == 64) CLSP(bf16_t, 64); else CLSP(bf16_t, 32);
+    } else {
+        if (dh == 64) CLSP(float, 64); else CLSP(float, 32);
+    }
+#undef CLSP
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }

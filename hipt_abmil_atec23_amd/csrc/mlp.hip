@@ -52,7 +52,7 @@ template <int U> __device__ __forceinline__ void wait_units(int units) {  // 4*U
 
 #define MSTAMP(k)                                                                                   \
     do {                                                                                            \
-        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
 // KS = D / 64 (6: ViT-256, 3: ViT-4K).  DBG (tools/mlp_probe.hip only; the library instantiates 0) removes
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     if (tid == 0) tile_s[0] = atomicAdd(p.counter, 1);
     __syncthreads();
     int tile = __builtin_amdgcn_readfirstlane(tile_s[0]);
-    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+    if (HIPT_STAMPS_ON(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
     if (p.stagger > 0) {  // start groups apart: (block / 8) & 3 mixes the groups inside every XCD
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         const unsigned long long wait = (unsigned long long)(((blockIdx.x >> 3) & 3) * p.stagger);
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             ln_rows<NCH>(v, gam, bet, D, p.ln_eps, g, af[mf]);
         }
         MSTAMP(2);
-        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
 
         f32x4 acc2[2][NF2];
 #pragma unroll
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 }
         }
         MSTAMP(3);
-        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
 #undef DSR128
 #undef LGKM
 #undef SLAB_SYNC
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         tile = __builtin_amdgcn_readfirstlane(tile_s[(seq + 1) & 1]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (continuous stream: units of a pass that never runs)
-    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+    if (HIPT_STAMPS_ON(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <int KS, int DBG = 0>
@@ -395,22 +395,22 @@ int launch(const MlpParams& p_in, hipStream_t st) {
     constexpr int D = KS * 64;
     const int lds = NSLOT * SLAB_BYTES + (3 * D + p.hidden) * 4 + 16;
     auto k = mlp_kernel<KS, DBG>;
-    static bool attr = false;
-    static int ncu = 0;
-    if (!attr) {
+    static DevOnce once;
+    HIPT_CUR_DEVICE(dev);
+    if (!once.done[dev]) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(mlp) failed");
             return HIPT_E_LAUNCH;
         }
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
             hipt_set_error("mlp: cannot query the device");
             return HIPT_E_LAUNCH;
         }
-        ncu = prop.multiProcessorCount;
-        attr = true;
+        once.ncu[dev] = prop.multiProcessorCount;
+        once.done[dev] = true;
     }
+    const int ncu = once.ncu[dev];
     // whole rounds of #CU workgroups take 128 rows each; a last partial round that would be less than an
     // eighth full is cut into 16-row tiles (one active wave each: such a tile costs about half a full one)
     const int tiles = (p.M + TMR - 1) / TMR;
@@ -429,6 +429,7 @@ int launch(const MlpParams& p_in, hipStream_t st) {
         return HIPT_E_LAUNCH;
     }
 
+#ifdef HIPT_DEBUG_STAMPS  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
     static const bool want_stamps = getenv("HIPT_SEQGEMM_STAMPS") != nullptr;
     static unsigned long long* dbuf = nullptr;
     if (want_stamps) {
@@ -436,8 +437,10 @@ int launch(const MlpParams& p_in, hipStream_t st) {
         (void)hipMemsetAsync(dbuf, 0, 4096 * 16 * sizeof(unsigned long long), st);
         p.stamps = dbuf;
     }
+#endif
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
     HIPT_CHECK_LAUNCH();
+#ifdef HIPT_DEBUG_STAMPS
     if (want_stamps && grid <= 4096) {
         static unsigned long long h[4096 * 16];
         (void)hipStreamSynchronize(st);
@@ -460,6 +463,7 @@ int launch(const MlpParams& p_in, hipStream_t st) {
         fprintf(stderr, "[mlp KS=%d dbg=%d hidden=%d grid=%d full=%d stagger=%d] total %.1f us | first tiles: stage %.1f, Aload+LN %.1f, chunks %.1f (chunk1: fc1 %.2f, gelu %.2f; %.2f GHz), epilogue %.1f\n", KS,
                 DBG, p.hidden, grid, p.full_tiles, p.stagger, (double)(t4 - t0) * 0.01, ph[0], ph[1], ph[2], c1, c2, ghz, ph[3]);
     }
+#endif
     return HIPT_OK;
 }
 

@@ -52,7 +52,7 @@ constexpr int SLAB = 16384, UNIT = 3 * SLAB;
 
 #define PSTAMP(k)                                                                                                    \
     do {                                                                                                             \
-        if (p.stamps && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
 enum { KA = 0, KB = 1 };            // phase kind: fc1 half / fc2 half
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
     if (tid == 0) tile_s[0] = atomicAdd(p.counter, 1);
     __syncthreads();
     int tile = __builtin_amdgcn_readfirstlane(tile_s[0]);
-    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+    if (HIPT_STAMPS_ON(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
 
     // fragment read offsets inside a slab (128-byte LDS rows, chunk XOR ((row>>1)&7))
     uint32_t foff[2];
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
             asm volatile("" : "+v"(a2));
         }
         PSTAMP(2);
-        if (p.stamps && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
 
         f32x4 acc2[2][NF2];
 #pragma unroll
@@ -487,9 +487,9 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
         __builtin_amdgcn_sched_barrier(0);
         phase(TB{}, I1{}, IM1{}, I0{}, IM1{}, 0);
         PSTAMP(3);
-        if (p.stamps && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
 #ifdef MLP_WAIT_STAMP
-        if (p.stamps && threadIdx.x == 0 && seq == PSTAMP_SEQ) {
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) {
             p.stamps[(size_t)blockIdx.x * 16 + 12] = wait_vm;
             p.stamps[(size_t)blockIdx.x * 16 + 13] = wait_bar;
         }
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pipe_kernel(const MlpParams p) {
         tile = __builtin_amdgcn_readfirstlane(nt);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (continuous stream: pieces of a pass that never runs)
-    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+    if (HIPT_STAMPS_ON(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace
@@ -623,9 +623,9 @@ int hipt_mlp_pipe_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     auto k = p.img == 3 ? mlp_pipe_kernel<DBG, true, true, true>
            : p.img == 1 ? mlp_pipe_kernel<DBG, true, true, false>
            : p.wpk ? mlp_pipe_kernel<DBG, true> : mlp_pipe_kernel<DBG, false>;
-    static bool attr = false;
-    static int ncu = 0;
-    if (!attr) {
+    static DevOnce once;
+    HIPT_CUR_DEVICE(dev);
+    if (!once.done[dev]) {
         if (hipFuncSetAttribute((const void*)mlp_pipe_kernel<DBG, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)mlp_pipe_kernel<DBG, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)mlp_pipe_kernel<DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -633,15 +633,15 @@ int hipt_mlp_pipe_launch_dbg(const MlpParams& p_in, hipStream_t st) {
             hipt_set_error("hipFuncSetAttribute(mlp_pipe) failed");
             return HIPT_E_LAUNCH;
         }
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
             hipt_set_error("mlp_pipe: cannot query the device");
             return HIPT_E_LAUNCH;
         }
-        ncu = prop.multiProcessorCount;
-        attr = true;
+        once.ncu[dev] = prop.multiProcessorCount;
+        once.done[dev] = true;
     }
+    const int ncu = once.ncu[dev];
     // whole rounds of #CU workgroups take 128 rows each; a last partial round that would be less than an
     // eighth full is cut into 16-row tiles (one active wave each: such a tile costs about half a full one)
     const int tiles = (p.M + TMR - 1) / TMR;
@@ -656,6 +656,7 @@ int hipt_mlp_pipe_launch_dbg(const MlpParams& p_in, hipStream_t st) {
         hipt_set_error("mlp_pipe: hipMemsetAsync(counter) failed");
         return HIPT_E_LAUNCH;
     }
+#ifdef HIPT_DEBUG_STAMPS  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
     static const bool want_stamps = getenv("HIPT_SEQGEMM_STAMPS") != nullptr;
     static unsigned long long* dbuf = nullptr;
     if (want_stamps) {
@@ -663,8 +664,10 @@ int hipt_mlp_pipe_launch_dbg(const MlpParams& p_in, hipStream_t st) {
         (void)hipMemsetAsync(dbuf, 0, 4096 * 16 * sizeof(unsigned long long), st);
         p.stamps = dbuf;
     }
+#endif
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
     HIPT_CHECK_LAUNCH();
+#ifdef HIPT_DEBUG_STAMPS
     if (want_stamps && grid <= 4096) {
         static unsigned long long h[4096 * 16];
         (void)hipStreamSynchronize(st);
@@ -694,6 +697,7 @@ int hipt_mlp_pipe_launch_dbg(const MlpParams& p_in, hipStream_t st) {
         fprintf(stderr, "   ring syncs of that tile, wave 0: %.0f cycles waiting for its DMA pieces, %.0f in the barrier\n", wvm, wbar);
 #endif
     }
+#endif
     return HIPT_OK;
 }
 

@@ -110,7 +110,7 @@ __device__ __forceinline__ void ln_rows(f32x4 (&v)[NCH][2], const float* gam, co
 
 #define STAMP(k)                                                                                   \
     do {                                                                                           \
-        if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
 template <int KS, bool LN, int FLAGS>
@@ -283,24 +283,28 @@ __global__ __launch_bounds__(256, 1) void seqgemm_kernel(const SeqGemmParams p) 
 template <int KS, bool LN, int FLAGS>
 int launch(const SeqGemmParams& p, int grid, hipStream_t st) {
     auto k = seqgemm_kernel<KS, LN, FLAGS>;
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce once;
+    HIPT_CUR_DEVICE(dev);
+    if (!once.done[dev]) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(seqgemm) failed");
             return HIPT_E_LAUNCH;
         }
-        attr = true;
+        once.done[dev] = true;
     }
-    static const bool want_stamps = getenv("HIPT_SEQGEMM_STAMPS") != nullptr;
     SeqGemmParams q = p;
+#ifdef HIPT_DEBUG_STAMPS  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
+    static const bool want_stamps = getenv("HIPT_SEQGEMM_STAMPS") != nullptr;
     static unsigned long long* dbuf = nullptr;
     if (want_stamps) {
         if (!dbuf) (void)hipMalloc(&dbuf, 4096 * 8 * sizeof(unsigned long long));
         (void)hipMemsetAsync(dbuf, 0, 4096 * 8 * sizeof(unsigned long long), st);
         q.stamps = dbuf;
     }
+#endif
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), SEQ_LDS, st, q);
     HIPT_CHECK_LAUNCH();
+#ifdef HIPT_DEBUG_STAMPS
     if (want_stamps && grid <= 4096) {  // debug only: synchronises and prints phase medians (us)
         static unsigned long long h[4096 * 8];
         (void)hipStreamSynchronize(st);
@@ -322,6 +326,7 @@ int launch(const SeqGemmParams& p, int grid, hipStream_t st) {
         fprintf(stderr, "[seqgemm KS=%d LN=%d F=%d N=%d grid=%d] total %.1f us | first-256 WGs: start<=%.1f, stage %.1f, Aload %.1f, tile0-k %.1f, tile0-epi %.1f, rest %.1f, end(avg) %.1f\n",
                 KS, (int)LN, FLAGS, p.N, grid, (double)(t5 - t0) * 0.01, start_max, ph[0], ph[1], ph[2], ph[3], ph[4], end_med);
     }
+#endif
     return HIPT_OK;
 }
 

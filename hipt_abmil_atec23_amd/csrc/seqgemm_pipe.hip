@@ -29,7 +29,7 @@ constexpr int PIPE_LDS = 3 * UNIT + 2 * K * 4 + MAXN * 4 + 16;
 
 #define QSTAMP(k)                                                                                                    \
     do {                                                                                                             \
-        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
 typedef std::integral_constant<int, 0> I0;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParam
     if (tid == 0) tile_s[0] = atomicAdd(p.counter, 1);
     __syncthreads();
     int tile = __builtin_amdgcn_readfirstlane(tile_s[0]);
-    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+    if (HIPT_STAMPS_ON(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
 
     uint32_t foff[2];
 #pragma unroll
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParam
                 }
         }
         QSTAMP(2);
-        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
 
         f32x4 acc[2][MF][8];
 
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParam
         }
         __builtin_amdgcn_sched_barrier(0);
         QSTAMP(3);
-        if (p.stamps && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == 0) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
         QSTAMP(4);
         if (DBG & 1) __syncthreads();  // (no ring barriers in this debug build)
         int nt;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParam
         tile = __builtin_amdgcn_readfirstlane(nt);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (continuous stream: pieces of a pass that never runs)
-    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+    if (HIPT_STAMPS_ON(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace
@@ -431,9 +431,9 @@ int hipt_seqgemm_pipe_launch_dbg(const SeqGemmParams& p_in, hipStream_t st) {
         if (p.img == 2) k = seqgemm_pipe_kernel<false, DBG, true, false, true>;
         if (p.img == 3) k = seqgemm_pipe_kernel<false, DBG, true, true, true>;
     }
-    static bool attr = false;
-    static int ncu = 0;
-    if (!attr) {
+    static DevOnce once;
+    HIPT_CUR_DEVICE(dev);
+    if (!once.done[dev]) {
         if (hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<LN, DBG, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -444,21 +444,22 @@ int hipt_seqgemm_pipe_launch_dbg(const SeqGemmParams& p_in, hipStream_t st) {
             hipt_set_error("hipFuncSetAttribute(seqgemm_pipe) failed");
             return HIPT_E_LAUNCH;
         }
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
             hipt_set_error("seqgemm_pipe: cannot query the device");
             return HIPT_E_LAUNCH;
         }
-        ncu = prop.multiProcessorCount;
-        attr = true;
+        once.ncu[dev] = prop.multiProcessorCount;
+        once.done[dev] = true;
     }
+    const int ncu = once.ncu[dev];
     p.ntiles = (p.M + TMR - 1) / TMR;
     const int grid = p.ntiles < ncu ? p.ntiles : ncu;
     if (hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
         hipt_set_error("seqgemm_pipe: hipMemsetAsync(counter) failed");
         return HIPT_E_LAUNCH;
     }
+#ifdef HIPT_DEBUG_STAMPS  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
     static const bool want_stamps = getenv("HIPT_SEQGEMM_STAMPS") != nullptr;
     static unsigned long long* dbuf = nullptr;
     if (want_stamps) {
@@ -466,8 +467,10 @@ int hipt_seqgemm_pipe_launch_dbg(const SeqGemmParams& p_in, hipStream_t st) {
         (void)hipMemsetAsync(dbuf, 0, 4096 * 16 * sizeof(unsigned long long), st);
         p.stamps = dbuf;
     }
+#endif
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), PIPE_LDS, st, p);
     HIPT_CHECK_LAUNCH();
+#ifdef HIPT_DEBUG_STAMPS
     if (want_stamps && grid <= 4096) {
         static unsigned long long h[4096 * 16];
         (void)hipStreamSynchronize(st);
@@ -487,6 +490,7 @@ int hipt_seqgemm_pipe_launch_dbg(const SeqGemmParams& p_in, hipStream_t st) {
         fprintf(stderr, "[seqgemm_pipe LN=%d dbg=%d N=%d grid=%d tiles=%d] total %.1f us | first tiles: rows%s %.1f, N tile 0 %.1f, N tiles 1.. + last stores %.1f (%.2f GHz)\n",
                 (int)LN, DBG, p.N, grid, p.ntiles, (double)(t4 - t0) * 0.01, LN ? "+LN" : "", pro, first, rest, ghz);
     }
+#endif
     return HIPT_OK;
 }
 

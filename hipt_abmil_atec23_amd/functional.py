@@ -18,12 +18,15 @@ def torch_dtype(code: int):
     return _TORCH_DT[code]
 
 
-def workspace(device, nbytes: int, slot: int = 0) -> torch.Tensor:
-    """Grow-only per-device scratch (the library itself never allocates).  ``slot``: one scratch per concurrent stream."""
+def workspace(device, nbytes: int, slot=0, zero: bool = False) -> torch.Tensor:
+    """Grow-only per-device scratch (the library itself never allocates).  ``slot``: one scratch per concurrent use (a
+    stream handle, a part index).  ``zero``: allocate zero-filled -- for scratch that carries the CLAM ticket block
+    (include/hipt_abmil.h: zero before the first call, left zero by every call)."""
     key = (device.type, device.index, slot)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        n = max(int(nbytes), 1 << 20)
+        ws = torch.zeros(n, dtype=torch.uint8, device=device) if zero else torch.empty(n, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
 

@@ -62,17 +62,17 @@ class HIPT_4K(torch.nn.Module):
         return img.dtype == torch.uint8 and img.dim() == 4 and img.shape[-1] == 3 and img.shape[1] != 3
 
     def _same_device(self) -> bool:
-        d256 = next(self.model256.parameters()).device
-        d4k = next(self.model4k.parameters()).device
-        return d256 == d4k
+        return self.model256.weight_device == self.model4k.weight_device
 
     def _run(self, x: torch.Tensor, want_cls256: bool):
         batch, w_256, h_256 = self.prepare_img_tensor(x)
         if w_256 == 0 or h_256 == 0:
             raise ValueError(f"region {tuple(x.shape)} is smaller than one 256x256 patch")
         nreg = batch.shape[0]  # the reference takes 1 (hipt_4k.py:73); R > 1 regions are independent -> stacked
-        d256 = next(self.model256.parameters()).device
-        d4k = next(self.model4k.parameters()).device
+        # (weight_device, not next(parameters()): a nn.DataParallel replica has no parameters -- the reference wraps the
+        #  model whenever it sees more than one GPU, extract_features_fp.py:217-218 -- and .to() may have moved the ViTs
+        #  since the constructor recorded device256 / device4k)
+        d256, d4k = self.model256.weight_device, self.model4k.weight_device
         u8 = batch.dtype == torch.uint8  # raw RGB bytes: ToTensor + Normalize(0.5, 0.5) happen on the device
         hwc = self._interleaved(batch)
         region = batch.to(d256, non_blocking=True).detach()

@@ -96,8 +96,14 @@ class Attn_Net_Gated(nn.Module):
     def _torch_forward(self, x):
         return self.attention_c(self.attention_a(x).mul(self.attention_b(x))), x
 
+    def __getstate__(self):  # the packed weight image (ctypes struct + tensors) is a cache: never pickled / deep-copied
+        d = self.__dict__.copy()
+        d["_packed"] = None
+        return d
+
     def _pack(self, device):
         code = N.dtype_code(self._compute_dtype)
+        N.same_device("Attn_Net_Gated", device, *self.parameters())
         key = (code, tuple((p.data_ptr(), p._version) for p in self.parameters()))
         if self._packed is None or self._packed[0] != key:
             wa, wb = self.attention_a[0], self.attention_b[0]
@@ -117,13 +123,17 @@ class Attn_Net_Gated(nn.Module):
             return self._torch_forward(x)  # training / multi-branch (CLAM_MB): PyTorch ops on the same device
         N.require_cuda(x, "Attn_Net_Gated")
         w = self._pack(x.device)
-        xin = Fn.as_compute(x, w.dtype)
+        if x.dim() < 1 or x.shape[-1] != w.s1:
+            raise RuntimeError(f"Attn_Net_Gated: input {tuple(x.shape)} does not end in the L = {w.s1} features the module was built for")
+        xin = Fn.as_compute(x, w.dtype).reshape(-1, w.s1)  # nn.Linear semantics: any leading dims
         n = xin.shape[0]
         A = torch.empty((n, 1), dtype=torch.float32, device=x.device)
-        need = n * 2 * w.s2 * 4 + 4096
-        ws = Fn.workspace(x.device, need)
-        N.call("hipt_attn_net_gated", C.byref(w), N.ptr(xin), n, N.ptr(A), N.ptr(ws), ws.numel(), N.stream_ptr(x.device))
-        return A, x
+        if n:
+            need = n * 2 * w.s2 * 4 + 4096
+            st = N.stream_ptr(x.device)
+            ws = Fn.workspace(x.device, need, ("gated", st.value))
+            N.call("hipt_attn_net_gated", C.byref(w), N.ptr(xin), n, N.ptr(A), N.ptr(ws), ws.numel(), st)
+        return A.reshape(*x.shape[:-1], 1), x
 
 
 class CLAM_SB(nn.Module):
@@ -244,8 +254,14 @@ class CLAM_SB(nn.Module):
         return logits, Y_prob, Y_hat, A_raw, results
 
     # ---- HIP path ---------------------------------------------------------------------------------
-    def _pack(self):
+    def __getstate__(self):  # the packed weight image (ctypes struct + tensors) is a cache: never pickled / deep-copied
+        d = self.__dict__.copy()
+        d["_packed"] = None
+        return d
+
+    def _pack(self, device):
         code = N.dtype_code(self._compute_dtype)
+        N.same_device("CLAM_SB", device, *self.parameters())  # e.g. relocate() never called: a clean error, not a GPU fault
         key = (code, tuple((p.data_ptr(), p._version) for p in self.parameters()))
         if self._packed is None or self._packed[0] != key:
             fc1, gated = self.attention_net[0], self.attention_net[-1]
@@ -271,24 +287,26 @@ class CLAM_SB(nn.Module):
         N.require_cuda(h, "CLAM_SB")
         if h.dim() != 2 or h.shape[0] == 0:
             raise ValueError(f"expected a non-empty [N, {self.attention_net[0].in_features}] bag, got {tuple(h.shape)}")
-        w = self._pack()
+        w = self._pack(h.device)
         if h.shape[1] != w.s0:
             raise ValueError(f"bag width {h.shape[1]} != model input width {w.s0}")
         dev = h.device
         bag = Fn.as_compute(h, w.dtype)
         n = bag.shape[0]
         A_raw = torch.empty((1, n), dtype=torch.float32, device=dev)
-        ws = Fn.workspace(dev, N.lib().hipt_clam_workspace_bytes(C.byref(w), n))
+        st = N.stream_ptr(dev)
+        # one scratch (partials + finish ticket) per stream: two CLAM calls on two streams must not share them
+        ws = Fn.workspace(dev, N.lib().hipt_clam_workspace_bytes(C.byref(w), n), ("clam", st.value), zero=True)
         if attention_only:
             N.call("hipt_clam_sb_forward", C.byref(w), N.ptr(bag), n, 1, N.ptr(A_raw), None, None, None, None,
-                   N.ptr(ws), ws.numel(), N.stream_ptr(dev))
+                   N.ptr(ws), ws.numel(), st)
             return A_raw
         M = torch.empty((1, w.s1), dtype=torch.float32, device=dev)
         logits = torch.empty((1, w.n_classes), dtype=torch.float32, device=dev)
         Y_prob = torch.empty_like(logits)
         Y_hat = torch.empty((1, 1), dtype=torch.int64, device=dev)
         N.call("hipt_clam_sb_forward", C.byref(w), N.ptr(bag), n, 0, N.ptr(A_raw), N.ptr(M), N.ptr(logits), N.ptr(Y_prob),
-               N.ptr(Y_hat), N.ptr(ws), ws.numel(), N.stream_ptr(dev))
+               N.ptr(Y_hat), N.ptr(ws), ws.numel(), st)
         results = {}
         if instance_eval:
             # top-k stays on PyTorch-ROCm ops; only the 2k selected rows of h1 are

@@ -71,6 +71,7 @@ class _PackedVit:
         w.hidden = model.blocks[0].mlp.fc1.out_features if depth else 4 * model.embed_dim
         w.ntok, w.embed_k = pos.shape[1], embed_k
         w.ln_eps = float(model.norm.eps)
+        w.attn_scale = float(model.blocks[0].attn.scale) if depth else 0.0  # qk_scale or head_dim ** -0.5 (vision_transformer.py:112)
         w.embed_w, w.embed_b = cw(embed_w.reshape(embed_w.shape[0], -1)), cf(embed_b)
         w.cls, w.pos = cf(model.cls_token.reshape(-1)), cf(pos.reshape(pos.shape[1], -1))
         w.norm_w, w.norm_b = cf(model.norm.weight), cf(model.norm.bias)
@@ -105,8 +106,15 @@ class _HipVitMixin:
 
     def _init_native(self):
         self._compute_dtype = _default_dtype()
-        self._packed = {}
-        self._pos_cache = {}
+        self._packed = {}      # device -> (key, _PackedVit): one weight image per device (nn.DataParallel replicas share this dict)
+        self._pos_cache = {}   # device -> (key, interpolated positional table)
+        self._warned_grad = False
+
+    def __getstate__(self):
+        """The device-side images (ctypes structs + packed tensors) are caches: never pickled, never deep-copied."""
+        d = self.__dict__.copy()
+        d["_packed"], d["_pos_cache"] = {}, {}
+        return d
 
     def set_compute_dtype(self, name: str):
         N.dtype_code(name)
@@ -117,26 +125,59 @@ class _HipVitMixin:
     def compute_dtype(self) -> str:
         return self._compute_dtype
 
+    def _tensors(self):
+        """The weight tensors of this module tree.  A ``nn.DataParallel`` replica has no ``parameters()`` (they are plain
+        attributes there, torch/nn/parallel/replicate.py; the reference wraps the model so whenever it sees more than one
+        GPU, extract_features_fp.py:217-218): take them from ``_former_parameters``."""
+        ps = list(self.parameters())
+        if ps:
+            return ps
+        return [t for m in self.modules() for t in getattr(m, "_former_parameters", {}).values() if t is not None]
+
+    @property
+    def weight_device(self):
+        """Device the weights live on; survives DataParallel replication (``next(self.parameters())`` does not)."""
+        return self.pos_embed.device
+
     def _version_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in self._tensors())
+
+    def _check_inference_only(self):
+        """The HIP forwards are inference kernels (the ViTs are frozen feature extractors, hipt_model_utils.py:55-57):
+        what they would silently get wrong is refused, what they merely do not provide is said once."""
+        if self.training:
+            for m in self.modules():
+                if isinstance(m, nn.Dropout) and m.p > 0:
+                    raise RuntimeError("HIP ViT forward: dropout p > 0 in train() mode is not implemented (inference kernels); call .eval()")
+                if isinstance(m, DropPath) and (m.drop_prob or 0.) > 0:
+                    raise RuntimeError("HIP ViT forward: drop_path > 0 in train() mode is not implemented (inference kernels); call .eval()")
+        if torch.is_grad_enabled() and not self._warned_grad and any(p.requires_grad for p in self.parameters()):
+            import warnings
+            warnings.warn("HIP ViT forward returns tensors without grad_fn: no gradient flows into the ViT weights "
+                          "(the reference freezes them, hipt_model_utils.py:55-57)", stacklevel=3)
+            self._warned_grad = True
 
     def _pos_for(self, ntok_patches: int, w: int, h: int) -> torch.Tensor:
+        dev = self.pos_embed.device
         key = (ntok_patches, w, h, self.pos_embed.data_ptr(), self.pos_embed._version)
-        pos = self._pos_cache.get(key)
-        if pos is None:
+        hit = self._pos_cache.get(dev)
+        if hit is None or hit[0] != key:
             with torch.no_grad():
-                pos = self._interpolate(ntok_patches, w, h).detach().float().contiguous()
-            self._pos_cache = {key: pos}
-        return pos
+                hit = (key, self._interpolate(ntok_patches, w, h).detach().float().contiguous())
+            self._pos_cache[dev] = hit
+        return hit[1]
 
     def _packed_for(self, pos: torch.Tensor) -> _PackedVit:
+        self._check_inference_only()
         code = N.dtype_code(self._compute_dtype)
         key = (code, pos.data_ptr(), pos.shape[1], self._version_key())
-        pk = self._packed.get("cur")
+        pk = self._packed.get(pos.device)
         if pk is None or pk[0] != key:
+            ts = self._tensors()
+            N.same_device(type(self).__name__, pos.device, *ts)
             ew, eb, ek = self._embed_params()
             pk = (key, _PackedVit(self, code, pos, ew, eb, ek))
-            self._packed["cur"] = pk
+            self._packed[pos.device] = pk
         return pk[1]
 
     # ---- shared tails -------------------------------------------------------------------
@@ -162,19 +203,15 @@ class _HipVitMixin:
 
     def get_last_selfattention_cls(self, x):
         """[B, heads, N]: the [CLS] query's row of the last block's attention map, i.e. ``get_last_selfattention(x)[:, :, 0, :]``,
-        which is all the heat-maps use (hipt_4k.py:143-158) -- without the [B, heads, N, N] tensor where the fused
-        one-query kernel applies (bf16, head dim 64); elsewhere the slice of the full map."""
+        which is all the heat-maps use (hipt_4k.py:143-158), from the one-query kernel: the [B, heads, N, N] tensor is never
+        built (both ViTs, both compute dtypes)."""
         pk, tok = self._tokens(x)
         B, ntok, _ = tok.shape
-        if pk.w.dtype == N.HIPT_BF16 and pk.w.dim // pk.w.heads == 64 and ntok <= 320:
-            out = torch.empty((B, pk.w.heads, ntok), dtype=torch.float32, device=tok.device)
-            need = N.lib().hipt_vit_workspace_bytes(pk.ref, B)
-            ws = Fn.workspace(tok.device, need)
-            N.call("hipt_vit_cls_attention", pk.ref, N.ptr(tok), B, N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(tok.device))
-            return out
-        probs = torch.empty((B, pk.w.heads, ntok, ntok), dtype=torch.float32, device=tok.device)
-        self._blocks(pk, tok, 0, pk.w.depth, probs)
-        return probs[:, :, 0, :].contiguous()
+        out = torch.empty((B, pk.w.heads, ntok), dtype=torch.float32, device=tok.device)
+        need = N.lib().hipt_vit_workspace_bytes(pk.ref, B)
+        ws = Fn.workspace(tok.device, need)
+        N.call("hipt_vit_cls_attention", pk.ref, N.ptr(tok), B, N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(tok.device))
+        return out
 
     def get_intermediate_layers(self, x, n=1):
         """Normed outputs of the ``n`` last blocks (vision_transformer.py:264-272)."""
@@ -359,6 +396,7 @@ class VisionTransformer(_HipVitMixin, nn.Module):
         N.require_cuda(x, type(self).__name__)
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f"expected [B,3,W,H] images, got {tuple(x.shape)}")
+        N.same_device(type(self).__name__, self.pos_embed.device, x)
         ps = self.patch_embed.patch_size
         if ps != 16:
             raise NotImplementedError("the HIP patch embedding is built for 16x16-pixel tokens")
@@ -388,6 +426,8 @@ class VisionTransformer(_HipVitMixin, nn.Module):
         if layout is None:
             layout, nseq = self._layout(x), x.shape[0]
         else:
+            N.require_cuda(x, type(self).__name__)
+            N.same_device(type(self).__name__, self.pos_embed.device, x)
             pk = self._packed_for(self._pos_for((layout.patch_h // 16) * (layout.patch_w // 16), layout.patch_h,
                                                 layout.patch_w))
         out = torch.empty((nseq, pk.w.dim), dtype=torch.float32, device=x.device)

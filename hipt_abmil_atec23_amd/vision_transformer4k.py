@@ -74,6 +74,7 @@ class VisionTransformer4K(_HipVitMixin, nn.Module):
         N.require_cuda(x, type(self).__name__)
         if x.dim() != 4 or x.shape[1] != self.phi[0].in_features:
             raise ValueError(f"expected [B,{self.phi[0].in_features},w,h] feature grids, got {tuple(x.shape)}")
+        N.same_device(type(self).__name__, self.pos_embed.device, x)
         self.mpp_feature = x  # the reference keeps the raw grid on the module (:225)
         B, E, w, h = x.shape
         tokens_in = x.detach().float().flatten(2, 3).transpose(1, 2).contiguous()  # [B, w*h, 384] (:227)
@@ -90,6 +91,8 @@ class VisionTransformer4K(_HipVitMixin, nn.Module):
 
     def forward_tokens(self, tokens_in: torch.Tensor, w: int, h: int):
         """[B, w*h, 384] token-major features (what ViT-256 emits) -> [B, 192]; HIPT_4K's fast path."""
+        N.require_cuda(tokens_in, type(self).__name__)
+        N.same_device(type(self).__name__, self.pos_embed.device, tokens_in)
         pk = self._packed_for(self._pos_for(w * h, w, h))
         B = tokens_in.shape[0]
         out = torch.empty((B, pk.w.dim), dtype=torch.float32, device=tokens_in.device)

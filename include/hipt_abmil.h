@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HIPT_ABI_VERSION 2
+#define HIPT_ABI_VERSION 3
 
 enum { HIPT_F32 = 0, HIPT_BF16 = 1 };
 
@@ -92,6 +92,9 @@ typedef struct hipt_vit_weights {
     int32_t ntok;         /* tokens per sequence incl. [CLS] (257); <= 288                        */
     int32_t embed_k;      /* K of the embedding GEMM: 3*16*16 = 768 (ViT-256) / 384 (ViT-4K phi)   */
     float   ln_eps;       /* eps of every LayerNorm (1e-6 for vit_small / vit4k_xs)                 */
+    float   attn_scale;   /* Attention.scale = qk_scale or head_dim ** -0.5 (vision_transformer.py:112);
+                             <= 0 selects head_dim ** -0.5                                          */
+    int32_t reserved;
     const void*  embed_w; /* patch_embed.proj.weight viewed [D, 768]  /  phi.0.weight [D, 384]     */
     const float* embed_b; /* patch_embed.proj.bias / phi.0.bias                                   */
     const float* cls;     /* cls_token [D]                                                        */
@@ -179,8 +182,7 @@ int hipt_vit_blocks(const hipt_vit_weights* w, float* x, int nseq, int blk_begin
 /* [CLS] row of the last block's attention map: probs_cls[nseq, heads, ntok] fp32 =
  * get_last_selfattention(x)[:, :, 0, :] (vision_transformer.py:255-262 as consumed by the heat-maps,
  * HIPT_4K/hipt_4k.py:143-158) without materialising [nseq, heads, ntok, ntok].  x = prepared tokens, modified.
- * bf16 weights with head dim 64 only (HIPT_E_UNSUPPORTED otherwise: slice hipt_vit_blocks' probabilities).
- * workspace >= hipt_vit_workspace_bytes(). */
+ * Both compute dtypes, head dim 32 (ViT-4K) and 64 (ViT-256).  workspace >= hipt_vit_workspace_bytes(). */
 int hipt_vit_cls_attention(const hipt_vit_weights* w, float* x, int nseq, float* probs_cls,
                            void* workspace, size_t ws_bytes, void* stream);
 
@@ -241,7 +243,13 @@ typedef struct hipt_clam_weights {
     const float* wcls; const float* bcls;  /* classifiers Linear(S1,C): [C,S1], [C]             */
 } hipt_clam_weights;
 
+/* Scratch of the calls below.  ONE piece of state lives in it: the 256-byte "ticket block" at byte offset
+ * hipt_clam_ticket_offset() (the arrival counter of the in-kernel combine).  It must be ZERO before the first call that
+ * uses a given workspace (zero it once when allocating) and every completed call leaves it zero again -- no memset per
+ * call, any dispatch order, graph-replayable.  Calls that may run concurrently (different streams) need different
+ * workspaces. */
 size_t hipt_clam_workspace_bytes(const hipt_clam_weights* w, int N);
+size_t hipt_clam_ticket_offset(const hipt_clam_weights* w, int N);
 
 /* CLAM_SB.forward (model_clam.py:147-191, eval path without instance_eval), one bag:
  *   h1 = ReLU(bag W1^T + b1); A_raw = (tanh(h1 Wa^T+ba) * sigmoid(h1 Wb^T+bb)) wc + bc;

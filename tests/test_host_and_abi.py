@@ -27,11 +27,11 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     import ctypes as C
     # hipt_vit_weights: 8 x 4-byte scalars, 6 pointers, 1 pointer
-    assert C.sizeof(N.VitWeights) == 8 * 4 + 7 * 8
+    assert C.sizeof(N.VitWeights) == 10 * 4 + 7 * 8
     assert C.sizeof(N.BlockWeights) == 15 * 8  # 12 matrices / vectors + 3 optional packed images
     assert C.sizeof(N.ImageLayout) == 4 * 4 + 3 * 8
     assert C.sizeof(N.ClamWeights) == 6 * 4 + 8 * 8
-    assert N.VitWeights.ln_eps.offset == 28 and N.VitWeights.embed_w.offset == 32
+    assert N.VitWeights.ln_eps.offset == 28 and N.VitWeights.attn_scale.offset == 32 and N.VitWeights.embed_w.offset == 40
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -205,3 +205,76 @@ def test_library_load_brings_torch_in_first():
             "assert 'torch' not in sys.modules; N.lib(); assert 'torch' in sys.modules; print('ok')" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def _replicate_like_data_parallel(module):
+    """What torch.nn.parallel.replicate does to a module tree, on the CPU (the real one needs GPUs to broadcast to): replicas
+    built by _replicate_for_data_parallel() have NO parameters(); the copies are plain tensor attributes, also listed in
+    _former_parameters (torch/nn/parallel/replicate.py)."""
+    from collections import OrderedDict
+    mods = list(module.modules())
+    idx = {m: i for i, m in enumerate(mods)}
+    reps = []
+    for m in mods:
+        r = m._replicate_for_data_parallel()
+        r._former_parameters = OrderedDict()
+        reps.append(r)
+    for i, m in enumerate(mods):
+        for key, child in m._modules.items():
+            setattr(reps[i], key, None if child is None else reps[idx[child]])
+        for key, p in m._parameters.items():
+            if p is not None:
+                c = p.detach().clone()
+                setattr(reps[i], key, c)
+                reps[i]._former_parameters[key] = c
+    return reps[0]
+
+
+def test_hipt4k_survives_data_parallel_replication_and_deepcopy():
+    """extract_features_fp.py:217-218 wraps the model in nn.DataParallel whenever it sees more than one GPU: a replica has
+    no parameters(), so nothing on the forward path may rely on next(self.parameters())."""
+    import copy
+    import pickle
+
+    from hipt_abmil_atec23_amd import HIPT_4K
+    m = HIPT_4K(None, None, "cpu", "cpu").eval()
+    r = _replicate_like_data_parallel(m)
+    assert list(r.parameters()) == [] and list(r.model256.parameters()) == []
+    assert r.model256.weight_device == torch.device("cpu") and r._same_device()
+    assert len(r.model256._tensors()) == len(list(m.model256.parameters())) and len(r.model256._version_key()) > 100
+    with pytest.raises(RuntimeError, match="HIP device"):  # the loud no-CPU-path error, not StopIteration
+        r(torch.zeros(1, 3, 256, 256))
+    # the device-side weight images are caches: deep copy / pickle of a module that has run must work and drop them
+    class Unpicklable:
+        def __reduce__(self):
+            raise TypeError("ctypes objects containing pointers cannot be pickled")
+    m.model256._packed[torch.device("cpu")] = ("key", Unpicklable())
+    m2 = copy.deepcopy(m)
+    assert m2.model256._packed == {} and m.model256._packed != {}
+    assert torch.equal(m2.model256.pos_embed, m.model256.pos_embed)
+    m3 = pickle.loads(pickle.dumps(m.model256))
+    assert m3._packed == {} and torch.equal(m3.cls_token, m.model256.cls_token)
+
+
+def test_vit_refuses_what_the_inference_kernels_would_get_wrong():
+    from hipt_abmil_atec23_amd.vision_transformer import VisionTransformer
+    m = VisionTransformer(embed_dim=64, depth=1, num_heads=2, drop_rate=0.1)
+    m.train()
+    with pytest.raises(RuntimeError, match="dropout"):
+        m._check_inference_only()
+    m.eval()
+    with pytest.warns(UserWarning, match="no gradient flows"):
+        m._check_inference_only()
+    m._check_inference_only()  # said once
+    qs = VisionTransformer(embed_dim=64, depth=1, num_heads=2, qk_scale=0.3)
+    assert qs.blocks[0].attn.scale == 0.3  # travels to the kernels as hipt_vit_weights.attn_scale
+
+
+def test_stream_argument_carries_its_device():
+    import ctypes as C
+    s = N.StreamArg(0)
+    assert isinstance(s, C.c_void_p) and s.device is None
+    t_cpu = torch.zeros(1)
+    with pytest.raises(RuntimeError, match="expected all tensors on"):
+        N.same_device("x", torch.device("cuda", 0), t_cpu)
+    N.same_device("x", torch.device("cpu"), t_cpu, None)

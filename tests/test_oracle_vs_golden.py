@@ -153,3 +153,48 @@ def test_fp64_oracle_agrees_with_fp32_reference():
     p = {k: v.astype(np.float64) for k, v in P(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096).items()}
     out = O.vit4k_forward(synth.hash_uniform_np((1, 384, 16, 16), 4).astype(np.float64), p)
     assert maxdiff(out, g["out16"]) < TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# the PyTorch-CPU form of the oracle (oracle/torch_cpu.py: what bench.py times as the CPU baseline)
+# ---------------------------------------------------------------------------------------------
+def _tp(specs, base):
+    from oracle import torch_cpu as TO
+    return TO.to_torch(P(specs, base))
+
+
+def test_torch_cpu_oracle_vit256_vit4k_hipt4k():
+    import torch
+    from oracle import torch_cpu as TO
+    s256, s4k = synth.vit_param_specs("vit256"), synth.vit_param_specs("vit4k", embed_dim=192, depth=6)
+    p256n, p4kn = P(s256, 256), P(s4k, 4096)
+    p256, p4k = TO.to_torch(p256n), TO.to_torch(p4kn)
+    pos256 = torch.from_numpy(O.interpolate_pos_encoding(p256n["pos_embed"], 256, 256, 256, 16))
+    with torch.no_grad():
+        g = golden("vit256_full")
+        x = torch.from_numpy(synth.hash_uniform_np((2, 3, 256, 256), 2))
+        assert maxdiff(TO.vit256_forward(x, p256, pos256).numpy(), g["out"]) < TOL
+        g = golden("vit4k")
+        pos16 = torch.from_numpy(O.interpolate_pos_encoding(p4kn["pos_embed"], 256, 16, 16, 1))
+        pos34 = torch.from_numpy(O.interpolate_pos_encoding(p4kn["pos_embed"], 12, 3, 4, 1))
+        assert maxdiff(TO.vit4k_forward(torch.from_numpy(synth.hash_uniform_np((1, 384, 16, 16), 4)), p4k, pos16).numpy(), g["out16"]) < TOL
+        assert maxdiff(TO.vit4k_forward(torch.from_numpy(synth.hash_uniform_np((2, 384, 3, 4), 44)), p4k, pos34).numpy(), g["out34"]) < TOL
+        g = golden("hipt4k_1024x768")  # non-square: pins the patch order and the grid permute of the torch form too
+        x = torch.from_numpy(synth.hash_uniform_np((1, 3, 1024, 768), 3))
+        pos43 = torch.from_numpy(O.interpolate_pos_encoding(p4kn["pos_embed"], 12, 4, 3, 1))  # 1024 x 768 -> a 4 x 3 [CLS] grid
+        assert maxdiff(TO.hipt4k_forward(x, p256, p4k, pos256, pos43).numpy(), g["out"]) < TOL
+
+
+@pytest.mark.parametrize("name,size,base,shape,seed", [("clam_384_n2000", (384, 128, 64), 384, (2000, 384), 1),
+                                                        ("clam_hipt_big_n500", (192, 128, 64), 192, (500, 192), 5),
+                                                        ("clam_384_n1", (384, 128, 64), 384, (1, 384), 12)])
+def test_torch_cpu_oracle_clam_sb(name, size, base, shape, seed):
+    import torch
+    from oracle import torch_cpu as TO
+    g = golden(name)
+    p = _tp(synth.clam_param_specs(size), base)
+    with torch.no_grad():
+        logits, y_prob, y_hat, a_raw, M = TO.clam_sb_forward(torch.from_numpy(synth.hash_uniform_np(shape, seed)), p)
+    assert maxdiff(a_raw.numpy(), g["A_raw"]) < TOL and maxdiff(logits.numpy(), g["logits"]) < TOL
+    assert maxdiff(y_prob.numpy(), g["Y_prob"]) < TOL and maxdiff(M.numpy(), g["M"]) < TOL
+    assert np.array_equal(y_hat.numpy(), g["Y_hat"])
