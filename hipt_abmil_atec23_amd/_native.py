@@ -50,7 +50,17 @@ class ClamWeights(C.Structure):
                 ("wc", C.c_void_p), ("bc", C.c_void_p), ("wcls", C.c_void_p), ("bcls", C.c_void_p)]
 
 
+class ClamTrainWeights(C.Structure):
+    _fields_ = [("s0", C.c_int32), ("s1", C.c_int32), ("s2", C.c_int32), ("n_att", C.c_int32), ("n_classes", C.c_int32),
+                ("multi_branch", C.c_int32)] + [(n, C.c_void_p) for n in ("w1", "b1", "wa", "ba", "wb", "bb", "wc", "bc", "wcls", "bcls")]
+
+
+class ClamTrainGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dw1", "db1", "dwa", "dba", "dwb", "dbb", "dwc", "dbc", "dwcls", "dbcls", "dbag")]
+
+
 _VW, _IL, _CW = C.POINTER(VitWeights), C.POINTER(ImageLayout), C.POINTER(ClamWeights)
+_TW, _TG = C.POINTER(ClamTrainWeights), C.POINTER(ClamTrainGrads)
 _i, _i64, _p, _sz, _f = C.c_int, C.c_int64, C.c_void_p, C.c_size_t, C.c_float
 
 # name -> (restype, argtypes); mirrors include/hipt_abmil.h one to one
@@ -86,6 +96,10 @@ SIGNATURES = {
     "hipt_clam_sb_forward": (_i, [_CW, _p, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "hipt_attn_net_gated": (_i, [_CW, _p, _i, _p, _p, _sz, _p]),
     "hipt_clam_gather_h1": (_i, [_CW, _p, _p, _i, _p, _p]),
+    "hipt_clam_train_workspace_bytes": (_sz, [_TW, _i]),
+    "hipt_clam_train_forward": (_i, [_TW, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "hipt_clam_train_backward": (_i, [_TW, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _TG, _p, _sz, _p]),
+    "hipt_topk_rows": (_i, [_p, _i, _i, _i, _p, _p]),
 }
 
 _lib = None

@@ -7,16 +7,19 @@ state-dict keys (``attention_net.0.*``, ``attention_net.{2|3}.attention_{a,b}.0.
 ``utils/eval_utils.py:51-57``.  Inference forwards (no autograd) run as ONE fused HIP pass over
 the bag (csrc/abmil.hip).
 
-Outside the accelerated path, by design ("next" row):
-  * a forward that must be differentiated (``main.py`` trains this module) or that has active
-    dropout runs as plain PyTorch ops ON THE SAME HIP DEVICE — this is the training path, not a
-    fallback for inference; inference never takes it;
-  * ``Attn_Net`` (ungated) and ``CLAM_MB`` are import-compatible PyTorch modules.
-There is no CPU path for the HIP forwards: a CPU bag raises.
+Training: a forward that must be differentiated (``main.py`` trains this module,
+``utils/core_utils.py:300-348, 373-426``) or that has active dropout runs the TRAINING kernels
+(csrc/clam_train.hip) behind a ``torch.autograd.Function``: two launches forward (rows; softmax pooling + classifier +
+on-device top-k of the instance branch), two backward (rows; weight gradients), fp32, for ``CLAM_SB`` and the K-branch
+``CLAM_MB`` alike.  Only the pieces the caller supplies as Python callables stay PyTorch ops: the instance classifiers'
+``Linear(S1, 2)`` on the 2k gathered rows and ``instance_loss_fn`` (``SmoothTop1SVM`` in the reference's scripts).
+Outside the HIP path, by design: the ungated ``Attn_Net`` variant (``gate=False``; SURVEY.md allows the fallback) and
+tensors on the CPU in training mode (PyTorch ops, so that ``main.py`` still runs where there is no GPU).
+There is no CPU path for the HIP inference forwards: a CPU bag raises.
 """
 from __future__ import annotations
 
-import ctypes as C
+import ctypes as C_
 import os
 
 import numpy as np
@@ -132,8 +135,95 @@ class Attn_Net_Gated(nn.Module):
             need = n * 2 * w.s2 * 4 + 4096
             st = N.stream_ptr(x.device)
             ws = Fn.workspace(x.device, need, ("gated", st.value))
-            N.call("hipt_attn_net_gated", C.byref(w), N.ptr(xin), n, N.ptr(A), N.ptr(ws), ws.numel(), st)
+            N.call("hipt_attn_net_gated", C_.byref(w), N.ptr(xin), n, N.ptr(A), N.ptr(ws), ws.numel(), st)
         return A.reshape(*x.shape[:-1], 1), x
+
+
+def _train_supported(sizes, k_att, n_classes) -> bool:
+    return all(v > 0 and v % 4 == 0 for v in sizes) and 1 <= k_att <= 8 and 1 <= n_classes <= 8
+
+
+class _ClamTrainFn(torch.autograd.Function):
+    """Differentiable CLAM forward on the training kernels (include/hipt_abmil.h: hipt_clam_train_forward / _backward).
+
+    forward(cfg, bag, m1, ma, mb, w1, b1, wa, ba, wb, bb, wc, bc, *cls) -> (logits [1,C], A_raw [K,N], M [K,S1],
+    h1_sel [K,2,k,S1], topk_ids [K,2,k] int64, Y_hat [1,1] int64); ``cls`` = (weight [C,S1], bias [C]) for CLAM_SB or the
+    2C tensors of CLAM_MB's per-class ``Linear(S1, 1)`` (w_0, b_0, w_1, b_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, cfg, bag, m1, ma, mb, w1, b1, wa, ba, wb, bb, wc, bc, *cls):
+        dev = bag.device
+        K, C, multi, k_sel = cfg["K"], cfg["C"], cfg["multi"], cfg["k_sample"]
+        f = lambda t: None if t is None else t.detach().float().contiguous()
+        x = f(bag)
+        n, S0 = x.shape
+        S1, S2 = w1.shape[0], wa.shape[0]
+        if multi:
+            wcls = torch.cat([f(cls[2 * c]).reshape(1, S1) for c in range(C)], dim=0)
+            bcls = torch.cat([f(cls[2 * c + 1]).reshape(1) for c in range(C)], dim=0)
+        else:
+            wcls, bcls = f(cls[0]), f(cls[1])
+        keep = [x, f(m1), f(ma), f(mb), f(w1), f(b1), f(wa), f(ba), f(wb), f(bb), f(wc).reshape(K, S2), f(bc), wcls, bcls]
+        N.same_device("CLAM training forward", dev, *keep)
+        w = N.ClamTrainWeights()
+        w.s0, w.s1, w.s2, w.n_att, w.n_classes, w.multi_branch = S0, S1, S2, K, C, int(multi)
+        for name, t in zip(("w1", "b1", "wa", "ba", "wb", "bb", "wc", "bc", "wcls", "bcls"), keep[4:]):
+            setattr(w, name, t.data_ptr())
+        e = lambda *shape, dt=torch.float32: torch.empty(shape, dtype=dt, device=dev)
+        h1, t, s, A_raw, stats, M = e(n, S1), e(n, S2), e(n, S2), e(K, n), e(K, 2), e(K, S1)
+        logits, y_prob, y_hat = e(1, C), e(1, C), e(1, 1, dt=torch.int64)
+        ids = e(K, 2, k_sel, dt=torch.int64) if k_sel > 0 else None
+        h1_sel = e(K, 2, k_sel, S1) if k_sel > 0 else None
+        st = N.stream_ptr(dev)
+        N.call("hipt_clam_train_forward", C_.byref(w), N.ptr(x), n, N.ptr(keep[1]), N.ptr(keep[2]), N.ptr(keep[3]), N.ptr(h1), N.ptr(t),
+               N.ptr(s), N.ptr(A_raw), N.ptr(stats), N.ptr(M), N.ptr(logits), N.ptr(y_prob), N.ptr(y_hat), k_sel, N.ptr(ids), N.ptr(h1_sel), st)
+        ctx.cfg = cfg
+        ctx.w = w          # (the pointers stay valid: every tensor they name is in ctx.keep)
+        ctx.keep = keep
+        ctx.saved = (h1, t, s, A_raw, stats, M, ids)
+        ctx.set_materialize_grads(False)
+        if ids is None:
+            ids, h1_sel = torch.empty((K, 2, 0), dtype=torch.int64, device=dev), torch.empty((K, 2, 0, S1), device=dev)
+        ctx.mark_non_differentiable(ids, y_hat)
+        return logits, A_raw, M, h1_sel, ids, y_hat
+
+    @staticmethod
+    def backward(ctx, dlogits, dA_raw, dM, dh1_sel, _ids, _yhat):
+        cfg, w, keep = ctx.cfg, ctx.w, ctx.keep
+        x, m1, ma, mb = keep[:4]
+        h1, t, s, A_raw, stats, M, ids = ctx.saved
+        dev = x.device
+        n, S0 = x.shape
+        S1, S2, K, C = w.s1, w.s2, w.n_att, w.n_classes
+        z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        g = N.ClamTrainGrads()
+        out = dict(dw1=z(S1, S0), db1=z(S1), dwa=z(S2, S1), dba=z(S2), dwb=z(S2, S1), dbb=z(S2), dwc=z(K, S2), dbc=z(K), dwcls=z(C, S1), dbcls=z(C))
+        if ctx.needs_input_grad[1]:
+            out["dbag"] = z(n, S0)
+        for name, tns in out.items():
+            setattr(g, name, tns.data_ptr())
+        c = lambda tns: None if tns is None else tns.detach().float().contiguous()
+        dl = c(dlogits) if dlogits is not None else torch.zeros((1, C), device=dev)
+        dA, dMx, dsel = c(dA_raw), c(dM), c(dh1_sel)
+        n_sel = 0
+        sel_ids = None
+        if dsel is not None and ids is not None and dsel.numel():
+            sel_ids, n_sel = ids.reshape(-1), ids.numel()
+        st = N.stream_ptr(dev)
+        need = N.lib().hipt_clam_train_workspace_bytes(C_.byref(w), n)
+        ws = Fn.workspace(dev, need, ("clam_train", st.value))
+        N.call("hipt_clam_train_backward", C_.byref(w), N.ptr(x), n, N.ptr(m1), N.ptr(ma), N.ptr(mb), N.ptr(h1), N.ptr(t), N.ptr(s), N.ptr(A_raw),
+               N.ptr(stats), N.ptr(M), N.ptr(dl), N.ptr(dA), N.ptr(dMx), N.ptr(sel_ids), N.ptr(dsel if n_sel else None), n_sel, C_.byref(g),
+               N.ptr(ws), ws.numel(), st)
+        if cfg["multi"]:
+            gcls = []
+            for cl in range(C):
+                gcls += [out["dwcls"][cl:cl + 1], out["dbcls"][cl:cl + 1]]
+        else:
+            gcls = [out["dwcls"], out["dbcls"]]
+        wc_shape = cfg["wc_shape"]
+        return (None, out.get("dbag"), None, None, None, out["dw1"], out["db1"], out["dwa"], out["dba"], out["dwb"], out["dbb"],
+                out["dwc"].reshape(wc_shape), out["dbc"], *gcls)
 
 
 class CLAM_SB(nn.Module):
@@ -142,20 +232,25 @@ class CLAM_SB(nn.Module):
     ``size_arg`` is a key of the reference's size table (plus ``'hipt_384'``) or an explicit
     ``[S0, S1, S2]`` list."""
 
+    _multi = False
+
     def __init__(self, gate=True, size_arg="small", dropout=0.0, k_sample=8, n_classes=2,
                  instance_loss_fn=nn.CrossEntropyLoss(), subtyping=False):
         super().__init__()
         self.size_dict = dict(SIZE_DICT)
         size = list(size_arg) if isinstance(size_arg, (list, tuple)) else self.size_dict[size_arg]
+        self._build(gate, size, dropout, k_sample, n_classes, instance_loss_fn, subtyping, att_branches=1,
+                    classifiers=lambda: nn.Linear(size[1], n_classes))
+        initialize_weights(self)
+
+    def _build(self, gate, size, dropout, k_sample, n_classes, instance_loss_fn, subtyping, att_branches, classifiers):
         fc = [nn.Linear(size[0], size[1]), nn.ReLU()]
         if dropout > 0:
             fc.append(nn.Dropout(dropout))
-        if gate:
-            fc.append(Attn_Net_Gated(L=size[1], D=size[2], dropout=dropout, n_classes=1))
-        else:
-            fc.append(Attn_Net(L=size[1], D=size[2], dropout=dropout, n_classes=1))
+        head = Attn_Net_Gated if gate else Attn_Net
+        fc.append(head(L=size[1], D=size[2], dropout=dropout, n_classes=att_branches))
         self.attention_net = nn.Sequential(*fc)
-        self.classifiers = nn.Linear(size[1], n_classes)
+        self.classifiers = classifiers()  # (registration order = the reference's: attention_net, classifiers, instance_classifiers)
         self.instance_classifiers = nn.ModuleList([nn.Linear(size[1], 2) for _ in range(n_classes)])
         self.k_sample = k_sample
         self.instance_loss_fn = instance_loss_fn
@@ -163,9 +258,9 @@ class CLAM_SB(nn.Module):
         self.subtyping = subtyping
         self._gate = gate
         self._dropout = dropout
+        self._sizes = tuple(size)
         self._compute_dtype = _default_dtype()
         self._packed = None
-        initialize_weights(self)
 
     def set_compute_dtype(self, name):
         N.dtype_code(name)
@@ -190,42 +285,46 @@ class CLAM_SB(nn.Module):
     def create_negative_targets(length, device):
         return torch.full((length,), 0, device=device).long()
 
-    # ---- instance-level branches (model_clam.py:116-145); h_rows(ids) yields h1[ids] -------------
-    def _inst_eval(self, A, h_rows, classifier):
-        if A.dim() == 1:
-            A = A.view(1, -1)
-        top_p_ids = torch.topk(A, self.k_sample)[1][-1]
-        top_n_ids = torch.topk(-A, self.k_sample, dim=1)[1][-1]
-        device = A.device
+    # ---- instance-level branches (model_clam.py:116-145) ------------------------------------------
+    # rows_p / rows_n: the h1 rows of the k highest / k lowest attention scores of the branch
+    def _inst_eval_rows(self, rows_p, rows_n, classifier):
+        device = rows_p.device
         targets = torch.cat([self.create_positive_targets(self.k_sample, device),
                              self.create_negative_targets(self.k_sample, device)], dim=0)
-        logits = classifier(h_rows(torch.cat([top_p_ids, top_n_ids], dim=0)))
+        logits = classifier(torch.cat([rows_p, rows_n], dim=0))
         preds = torch.topk(logits, 1, dim=1)[1].squeeze(1)
         return self.instance_loss_fn(logits, targets), preds, targets
 
-    def _inst_eval_out(self, A, h_rows, classifier):
-        if A.dim() == 1:
-            A = A.view(1, -1)
-        top_p_ids = torch.topk(A, self.k_sample)[1][-1]
-        targets = self.create_negative_targets(self.k_sample, A.device)
-        logits = classifier(h_rows(top_p_ids))
+    def _inst_eval_out_rows(self, rows_p, classifier):
+        targets = self.create_negative_targets(self.k_sample, rows_p.device)
+        logits = classifier(rows_p)
         preds = torch.topk(logits, 1, dim=1)[1].squeeze(1)
         return self.instance_loss_fn(logits, targets), preds, targets
 
     def inst_eval(self, A, h, classifier):
-        return self._inst_eval(A, lambda ids: torch.index_select(h, dim=0, index=ids), classifier)
+        """Reference signature (model_clam.py:116-132): top-k of A by PyTorch ops on whatever device A lives on."""
+        if A.dim() == 1:
+            A = A.view(1, -1)
+        top_p_ids = torch.topk(A, self.k_sample)[1][-1]
+        top_n_ids = torch.topk(-A, self.k_sample, dim=1)[1][-1]
+        return self._inst_eval_rows(torch.index_select(h, 0, top_p_ids), torch.index_select(h, 0, top_n_ids), classifier)
 
     def inst_eval_out(self, A, h, classifier):
-        return self._inst_eval_out(A, lambda ids: torch.index_select(h, dim=0, index=ids), classifier)
+        if A.dim() == 1:
+            A = A.view(1, -1)
+        top_p_ids = torch.topk(A, self.k_sample)[1][-1]
+        return self._inst_eval_out_rows(torch.index_select(h, 0, top_p_ids), classifier)
 
-    def _instance_branch(self, A, h_rows, label):
+    def _instance_branch(self, rows_of, label):
+        """The instance loop of forward (:156-178 / :234-245).  rows_of(branch) -> (rows_p [k,S1], rows_n [k,S1])."""
         total, all_preds, all_targets = 0.0, [], []
         inst_labels = F.one_hot(label, num_classes=self.n_classes).squeeze()
         for i, classifier in enumerate(self.instance_classifiers):
+            rows_p, rows_n = rows_of(i if self._multi else 0)
             if inst_labels[i].item() == 1:
-                loss, preds, targets = self._inst_eval(A, h_rows, classifier)
+                loss, preds, targets = self._inst_eval_rows(rows_p, rows_n, classifier)
             elif self.subtyping:
-                loss, preds, targets = self._inst_eval_out(A, h_rows, classifier)
+                loss, preds, targets = self._inst_eval_out_rows(rows_p, classifier)
             else:
                 continue
             all_preds.extend(preds.cpu().numpy())
@@ -235,7 +334,10 @@ class CLAM_SB(nn.Module):
             total /= len(self.instance_classifiers)
         return {'instance_loss': total, 'inst_labels': np.array(all_targets), 'inst_preds': np.array(all_preds)}
 
-    # ---- training path: the reference op sequence as PyTorch ops on the module's device ----------
+    def _bag_logits(self, M):
+        return self.classifiers(M)  # :181
+
+    # ---- the reference op sequence as PyTorch ops (ungated head; CPU tensors in training) ----------
     def _torch_forward(self, h, label, instance_eval, return_features, attention_only):
         A, h = self.attention_net(h)
         A = torch.transpose(A, 1, 0)
@@ -243,17 +345,57 @@ class CLAM_SB(nn.Module):
             return A
         A_raw = A
         A = F.softmax(A, dim=1)
-        results = self._instance_branch(A, lambda ids: torch.index_select(h, dim=0, index=ids), label) \
-            if instance_eval else {}
+        results = {}
+        if instance_eval:
+            def rows_of(b):
+                a = A[b].view(1, -1)
+                return (torch.index_select(h, 0, torch.topk(a, self.k_sample)[1][-1]),
+                        torch.index_select(h, 0, torch.topk(-a, self.k_sample, dim=1)[1][-1]))
+            results = self._instance_branch(rows_of, label)
         M = torch.mm(A, h)
-        logits = self.classifiers(M)
+        logits = self._bag_logits(M)
         Y_hat = torch.topk(logits, 1, dim=1)[1]
         Y_prob = F.softmax(logits, dim=1)
         if return_features:
             results.update({'features': M})
         return logits, Y_prob, Y_hat, A_raw, results
 
-    # ---- HIP path ---------------------------------------------------------------------------------
+    # ---- HIP training path ----------------------------------------------------------------------------
+    def _cls_tensors(self):
+        return [self.classifiers.weight, self.classifiers.bias]
+
+    def _train_forward(self, h, label, instance_eval, return_features, attention_only):
+        if h.dim() != 2 or h.shape[0] == 0 or h.shape[1] != self._sizes[0]:
+            raise ValueError(f"expected a non-empty [N, {self._sizes[0]}] bag, got {tuple(h.shape)}")
+        fc1, gated = self.attention_net[0], self.attention_net[-1]
+        wa, wb, wc = gated.attention_a[0], gated.attention_b[0], gated.attention_c
+        n, (S0, S1, S2), K = h.shape[0], self._sizes, wc.out_features
+        m1 = ma = mb = None
+        if self.training and self._dropout > 0:  # the masks nn.Dropout would draw, in the reference's order (:86, :48-52)
+            ones = lambda c: torch.ones((n, c), dtype=torch.float32, device=h.device)
+            m1, ma, mb = (F.dropout(ones(S1), self._dropout, True), F.dropout(ones(S2), self._dropout, True),
+                          F.dropout(ones(S2), self._dropout, True))
+        k_sel = self.k_sample if (instance_eval and not attention_only) else 0
+        cfg = dict(K=K, C=self.n_classes, multi=self._multi, k_sample=k_sel, wc_shape=tuple(wc.weight.shape))
+        logits, A_raw, M, h1_sel, _ids, Y_hat = _ClamTrainFn.apply(
+            cfg, h, m1, ma, mb, fc1.weight, fc1.bias, wa.weight, wa.bias, wb.weight, wb.bias, wc.weight, wc.bias, *self._cls_tensors())
+        if attention_only:
+            return A_raw
+        results = self._instance_branch(lambda b: (h1_sel[b, 0], h1_sel[b, 1]), label) if instance_eval else {}
+        Y_prob = F.softmax(logits, dim=1)
+        if return_features:
+            results.update({'features': M})
+        return logits, Y_prob, Y_hat, A_raw, results
+
+    def _use_train_kernels(self, h, dropout_on) -> bool:
+        if not self._gate or not h.is_cuda:
+            return False
+        K = self.attention_net[-1].attention_c.out_features
+        if not _train_supported(self._sizes, K, self.n_classes):
+            return False
+        return self._multi or dropout_on or _needs_autograd(self, h)
+
+    # ---- HIP inference path ---------------------------------------------------------------------------
     def __getstate__(self):  # the packed weight image (ctypes struct + tensors) is a cache: never pickled / deep-copied
         d = self.__dict__.copy()
         d["_packed"] = None
@@ -261,7 +403,7 @@ class CLAM_SB(nn.Module):
 
     def _pack(self, device):
         code = N.dtype_code(self._compute_dtype)
-        N.same_device("CLAM_SB", device, *self.parameters())  # e.g. relocate() never called: a clean error, not a GPU fault
+        N.same_device(type(self).__name__, device, *self.parameters())  # e.g. relocate() never called: a clean error, not a GPU fault
         key = (code, tuple((p.data_ptr(), p._version) for p in self.parameters()))
         if self._packed is None or self._packed[0] != key:
             fc1, gated = self.attention_net[0], self.attention_net[-1]
@@ -282,7 +424,10 @@ class CLAM_SB(nn.Module):
 
     def forward(self, h, label=None, instance_eval=False, return_features=False, attention_only=False):
         dropout_on = self.training and self._dropout > 0
-        if not self._gate or dropout_on or _needs_autograd(self, h):
+        if self._use_train_kernels(h, dropout_on):
+            N.same_device(type(self).__name__, h.device, *self.parameters())
+            return self._train_forward(h, label, instance_eval, return_features, attention_only)
+        if not self._gate or ((dropout_on or _needs_autograd(self, h)) and not h.is_cuda) or self._multi:
             return self._torch_forward(h, label, instance_eval, return_features, attention_only)
         N.require_cuda(h, "CLAM_SB")
         if h.dim() != 2 or h.shape[0] == 0:
@@ -296,85 +441,58 @@ class CLAM_SB(nn.Module):
         A_raw = torch.empty((1, n), dtype=torch.float32, device=dev)
         st = N.stream_ptr(dev)
         # one scratch (partials + finish ticket) per stream: two CLAM calls on two streams must not share them
-        ws = Fn.workspace(dev, N.lib().hipt_clam_workspace_bytes(C.byref(w), n), ("clam", st.value), zero=True)
+        ws = Fn.workspace(dev, N.lib().hipt_clam_workspace_bytes(C_.byref(w), n), ("clam", st.value), zero=True)
         if attention_only:
-            N.call("hipt_clam_sb_forward", C.byref(w), N.ptr(bag), n, 1, N.ptr(A_raw), None, None, None, None,
+            N.call("hipt_clam_sb_forward", C_.byref(w), N.ptr(bag), n, 1, N.ptr(A_raw), None, None, None, None,
                    N.ptr(ws), ws.numel(), st)
             return A_raw
         M = torch.empty((1, w.s1), dtype=torch.float32, device=dev)
         logits = torch.empty((1, w.n_classes), dtype=torch.float32, device=dev)
         Y_prob = torch.empty_like(logits)
         Y_hat = torch.empty((1, 1), dtype=torch.int64, device=dev)
-        N.call("hipt_clam_sb_forward", C.byref(w), N.ptr(bag), n, 0, N.ptr(A_raw), N.ptr(M), N.ptr(logits), N.ptr(Y_prob),
+        N.call("hipt_clam_sb_forward", C_.byref(w), N.ptr(bag), n, 0, N.ptr(A_raw), N.ptr(M), N.ptr(logits), N.ptr(Y_prob),
                N.ptr(Y_hat), N.ptr(ws), ws.numel(), st)
         results = {}
         if instance_eval:
-            # top-k stays on PyTorch-ROCm ops; only the 2k selected rows of h1 are
-            # recomputed by the library instead of materialising h1 [N,S1]
-            def h_rows(ids):
-                ids = ids.to(torch.int64).contiguous()
-                out = torch.empty((ids.numel(), w.s1), dtype=torch.float32, device=dev)
-                N.call("hipt_clam_gather_h1", C.byref(w), N.ptr(bag), N.ptr(ids), ids.numel(), N.ptr(out), N.stream_ptr(dev))
-                return out
-            results = self._instance_branch(F.softmax(A_raw, dim=1), h_rows, label)
+            # inst_eval in eval mode (validate_clam, core_utils.py:506-560): top-k ids on the device (softmax is monotone:
+            # the ids of A_raw are those of softmax(A_raw)), then only the 2k selected rows of h1 are recomputed by the
+            # library instead of materialising h1 [N,S1]
+            if self.k_sample > n:
+                raise RuntimeError(f"selected index k out of range: k_sample={self.k_sample} > {n} rows (torch.topk, model_clam.py:120)")
+            ids = torch.empty((1, 2, self.k_sample), dtype=torch.int64, device=dev)
+            N.call("hipt_topk_rows", N.ptr(A_raw), 1, n, self.k_sample, N.ptr(ids), st)
+            rows = torch.empty((2 * self.k_sample, w.s1), dtype=torch.float32, device=dev)
+            N.call("hipt_clam_gather_h1", C_.byref(w), N.ptr(bag), N.ptr(ids), 2 * self.k_sample, N.ptr(rows), st)
+            results = self._instance_branch(lambda b: (rows[:self.k_sample], rows[self.k_sample:]), label)
         if return_features:
             results.update({'features': M})
         return logits, Y_prob, Y_hat, A_raw, results
 
 
 class CLAM_MB(CLAM_SB):
-    """Multi-branch CLAM (model_clam.py:193-264): import-compatible PyTorch module, not on the HIP path."""
+    """Multi-branch CLAM (model_clam.py:193-264): one attention branch and one ``Linear(S1, 1)`` bag classifier per class.
+    Every forward (training or not) runs the K-branch fp32 kernels of csrc/clam_train.hip; ``gate=False`` and CPU tensors
+    take the PyTorch-op sequence."""
+
+    _multi = True
 
     def __init__(self, gate=True, size_arg="small", dropout=0.0, k_sample=8, n_classes=2,
                  instance_loss_fn=nn.CrossEntropyLoss(), subtyping=False):
         nn.Module.__init__(self)
         self.size_dict = dict(SIZE_DICT)
         size = list(size_arg) if isinstance(size_arg, (list, tuple)) else self.size_dict[size_arg]
-        fc = [nn.Linear(size[0], size[1]), nn.ReLU()]
-        if dropout > 0:
-            fc.append(nn.Dropout(dropout))
-        head = Attn_Net_Gated if gate else Attn_Net
-        fc.append(head(L=size[1], D=size[2], dropout=dropout, n_classes=n_classes))
-        self.attention_net = nn.Sequential(*fc)
-        self.classifiers = nn.ModuleList([nn.Linear(size[1], 1) for _ in range(n_classes)])
-        self.instance_classifiers = nn.ModuleList([nn.Linear(size[1], 2) for _ in range(n_classes)])
-        self.k_sample = k_sample
-        self.instance_loss_fn = instance_loss_fn
-        self.n_classes = n_classes
-        self.subtyping = subtyping
+        self._build(gate, size, dropout, k_sample, n_classes, instance_loss_fn, subtyping, att_branches=n_classes,
+                    classifiers=lambda: nn.ModuleList([nn.Linear(size[1], 1) for _ in range(n_classes)]))
         initialize_weights(self)
 
-    def forward(self, h, label=None, instance_eval=False, return_features=False, attention_only=False):
-        device = h.device
-        A, h = self.attention_net(h)
-        A = torch.transpose(A, 1, 0)
-        if attention_only:
-            return A
-        A_raw = A
-        A = F.softmax(A, dim=1)
-        results = {}
-        if instance_eval:
-            total, all_preds, all_targets = 0.0, [], []
-            inst_labels = F.one_hot(label, num_classes=self.n_classes).squeeze()
-            for i, classifier in enumerate(self.instance_classifiers):
-                if inst_labels[i].item() == 1:
-                    loss, preds, targets = self.inst_eval(A[i], h, classifier)
-                elif self.subtyping:
-                    loss, preds, targets = self.inst_eval_out(A[i], h, classifier)
-                else:
-                    continue
-                all_preds.extend(preds.cpu().numpy())
-                all_targets.extend(targets.cpu().numpy())
-                total += loss
-            if self.subtyping:
-                total /= len(self.instance_classifiers)
-            results = {'instance_loss': total, 'inst_labels': np.array(all_targets), 'inst_preds': np.array(all_preds)}
-        M = torch.mm(A, h)
-        logits = torch.empty(1, self.n_classes).float().to(device)
+    def _cls_tensors(self):
+        out = []
+        for c in self.classifiers:
+            out += [c.weight, c.bias]
+        return out
+
+    def _bag_logits(self, M):  # :248-250
+        logits = torch.empty(1, self.n_classes).float().to(M.device)
         for c in range(self.n_classes):
             logits[0, c] = self.classifiers[c](M[c])
-        Y_hat = torch.topk(logits, 1, dim=1)[1]
-        Y_prob = F.softmax(logits, dim=1)
-        if return_features:
-            results.update({'features': M})
-        return logits, Y_prob, Y_hat, A_raw, results
+        return logits

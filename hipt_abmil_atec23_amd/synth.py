@@ -115,9 +115,12 @@ def vit_param_specs(kind: str = "vit256", embed_dim: int = 384, depth: int = 12,
     return sp
 
 
-def clam_param_specs(size=(384, 128, 64), n_classes: int = 2, dropout: bool = False, k_attn: int = 1):
-    """``name -> (shape, scale, offset)`` for CLAM_SB (models/model_clam.py:77-100)."""
+def clam_param_specs(size=(384, 128, 64), n_classes: int = 2, dropout: bool = False, k_attn: int = 1, multi: bool = False):
+    """``name -> (shape, scale, offset)`` for CLAM_SB (models/model_clam.py:77-100); ``multi``: CLAM_MB (:193-224), one
+    attention branch and one ``Linear(S1, 1)`` bag classifier per class."""
     s0, s1, s2 = size
+    if multi:
+        k_attn = n_classes
     g = 3 if dropout else 2  # index of Attn_Net_Gated inside attention_net (Dropout shifts it)
 
     def xav(fo, fi):
@@ -133,8 +136,13 @@ def clam_param_specs(size=(384, 128, 64), n_classes: int = 2, dropout: bool = Fa
     # attention_c is scaled up so that the softmax over N is peaked rather than flat
     sp[f"attention_net.{g}.attention_c.weight"] = ((k_attn, s2), 4.0 * xav(k_attn, s2), 0.0)
     sp[f"attention_net.{g}.attention_c.bias"] = ((k_attn,), 0.02, 0.0)
-    sp["classifiers.weight"] = ((n_classes, s1), xav(n_classes, s1), 0.0)
-    sp["classifiers.bias"] = ((n_classes,), 0.02, 0.0)
+    if multi:
+        for c in range(n_classes):
+            sp[f"classifiers.{c}.weight"] = ((1, s1), xav(n_classes, s1), 0.0)
+            sp[f"classifiers.{c}.bias"] = ((1,), 0.02, 0.0)
+    else:
+        sp["classifiers.weight"] = ((n_classes, s1), xav(n_classes, s1), 0.0)
+        sp["classifiers.bias"] = ((n_classes,), 0.02, 0.0)
     for c in range(n_classes):
         sp[f"instance_classifiers.{c}.weight"] = ((2, s1), xav(2, s1), 0.0)
         sp[f"instance_classifiers.{c}.bias"] = ((2,), 0.02, 0.0)

@@ -271,6 +271,61 @@ int hipt_attn_net_gated(const hipt_clam_weights* w, const void* x, int N, float*
 int hipt_clam_gather_h1(const hipt_clam_weights* w, const void* bag, const int64_t* idx, int n_idx,
                         float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * CLAM training step: differentiable forward + backward of CLAM_SB.forward / CLAM_MB.forward
+ * (models/model_clam.py:147-191, 226-264) with the instance branch's top-k (inst_eval / inst_eval_out, :116-145), as
+ * driven by utils/core_utils.py:300-348 (train_loop_clam) and :373-426 (train_loop; loss.backward() at :423).
+ * fp32 throughout (the reference's training precision).  A forward is two launches, a backward two.
+ * ---------------------------------------------------------------------------------- */
+typedef struct hipt_clam_train_weights {
+    int32_t s0, s1, s2;       /* size_dict entry; each a multiple of 4 (every entry of the reference's table is)  */
+    int32_t n_att;            /* K attention branches: 1 (CLAM_SB) or n_classes (CLAM_MB); <= 8                   */
+    int32_t n_classes;        /* C <= 8                                                                           */
+    int32_t multi_branch;     /* 0: logits = wcls[C,S1] M[0] + bcls (CLAM_SB :181); 1: logits[c] = wcls[c] . M[c] + bcls[c] (CLAM_MB :248-250) */
+    const float* w1;  const float* b1;     /* attention_net.0                     [S1,S0], [S1] */
+    const float* wa;  const float* ba;     /* attention_a.0                       [S2,S1], [S2] */
+    const float* wb;  const float* bb;     /* attention_b.0                       [S2,S1], [S2] */
+    const float* wc;  const float* bc;     /* attention_c                         [K,S2],  [K]  */
+    const float* wcls; const float* bcls;  /* classifiers (CLAM_MB: the C Linear(S1,1) stacked) [C,S1], [C] */
+} hipt_clam_train_weights;
+
+typedef struct hipt_clam_train_grads {     /* outputs of the backward, same shapes as the weights; dbag may be NULL */
+    float* dw1; float* db1; float* dwa; float* dba; float* dwb; float* dbb; float* dwc; float* dbc;
+    float* dwcls; float* dbcls;
+    float* dbag;                           /* [N,S0] or NULL (bags normally do not require a gradient)            */
+} hipt_clam_train_grads;
+
+size_t hipt_clam_train_workspace_bytes(const hipt_clam_train_weights* w, int N);   /* scratch of the backward */
+
+/* Forward.  bag [N,S0] fp32.  m1 [N,S1], ma / mb [N,S2]: dropout masks already scaled (0 or 1/(1-p)), or NULL
+ * (nn.Dropout after the ReLU, :86-87, and inside Attn_Net_Gated, :48-52; the caller draws them).
+ * Saved for the backward (caller-allocated): h1 [N,S1] (after ReLU and dropout = the `h` the reference returns),
+ * t = tanh(.) and s = sigmoid(.) [N,S2] before dropout, A_raw [K,N], stats [K,2] = (max, sum exp) of the softmax over N,
+ * M [K,S1].  Results: logits [C], Y_prob [C], Y_hat int64 [1].
+ * k_sample > 0: topk_ids int64 [K,2,k_sample] = per branch the ids of the k largest and of the k smallest attention
+ * scores (torch.topk(A, k) / torch.topk(-A, k), :120-123; ties: lowest index first), and, when h1_sel != NULL,
+ * h1_sel [K,2,k_sample,S1] = those rows of h1 (index_select).  k_sample > N is an error, as in torch.topk. */
+int hipt_clam_train_forward(const hipt_clam_train_weights* w, const float* bag, int N,
+                            const float* m1, const float* ma, const float* mb,
+                            float* h1, float* t, float* s, float* A_raw, float* stats, float* M,
+                            float* logits, float* Y_prob, int64_t* Y_hat,
+                            int k_sample, int64_t* topk_ids, float* h1_sel, void* stream);
+
+/* Backward.  Incoming gradients: dlogits [C]; optional (NULL = zero) dA_raw [K,N] and dM [K,S1] (the 'features' output);
+ * optional instance-branch rows: n_sel row ids sel_ids [n_sel] with their gradients dh1_sel [n_sel,S1], added to dh1.
+ * Everything else is what the forward saved.  Writes every member of g.  workspace >= hipt_clam_train_workspace_bytes(). */
+int hipt_clam_train_backward(const hipt_clam_train_weights* w, const float* bag, int N,
+                             const float* m1, const float* ma, const float* mb,
+                             const float* h1, const float* t, const float* s, const float* A_raw,
+                             const float* stats, const float* M,
+                             const float* dlogits, const float* dA_raw, const float* dM,
+                             const int64_t* sel_ids, const float* dh1_sel, int n_sel,
+                             const hipt_clam_train_grads* g, void* workspace, size_t ws_bytes, void* stream);
+
+/* torch.topk(A, k) and torch.topk(-A, k) of every row of A [rows, N] on the device (inst_eval, :120-123):
+ * ids int64 [rows, 2, k], descending / ascending by value, ties -> lowest index first. */
+int hipt_topk_rows(const float* A, int rows, int N, int k, int64_t* ids, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,3 +88,70 @@ def clam_sb_forward(h, p):
     M = torch.mm(F.softmax(A_raw, dim=1), h1)
     logits = F.linear(M, p["classifiers.weight"], p["classifiers.bias"])
     return logits, F.softmax(logits, dim=1), torch.topk(logits, 1, dim=1)[1], A_raw, M
+
+
+# --------------------------------------------------------------------------------------
+# CLAM training step: forward with autograd, so that tests can take gradients of any size / seed
+# --------------------------------------------------------------------------------------
+
+def clam_forward_train(h, p, n_classes, multi=False, k_sample=8, label=None, instance_eval=False, subtyping=False,
+                       masks=None, instance_loss_fn=None):
+    """CLAM_SB.forward / CLAM_MB.forward (model_clam.py:147-191, 226-264) as differentiable torch ops on ``p`` (tensors
+    that may require grad).  ``masks`` = (m1 [N,S1], ma [N,S2], mb [N,S2]) scaled dropout masks or None (nn.Dropout after
+    the ReLU :86 and inside Attn_Net_Gated :48-52).  Returns (logits, Y_prob, Y_hat, A_raw, dict)."""
+    g = next(int(k.split(".")[1]) for k in p if ".attention_a." in k)
+    pre = f"attention_net.{g}."
+    h1 = F.relu(F.linear(h, p["attention_net.0.weight"], p["attention_net.0.bias"]))
+    if masks is not None:
+        h1 = h1 * masks[0]
+    a = torch.tanh(F.linear(h1, p[pre + "attention_a.0.weight"], p[pre + "attention_a.0.bias"]))
+    b = torch.sigmoid(F.linear(h1, p[pre + "attention_b.0.weight"], p[pre + "attention_b.0.bias"]))
+    if masks is not None:
+        a, b = a * masks[1], b * masks[2]
+    A_raw = F.linear(a * b, p[pre + "attention_c.weight"], p[pre + "attention_c.bias"]).transpose(1, 0)  # [K, N]
+    A = F.softmax(A_raw, dim=1)
+    res = {}
+    if instance_eval:
+        loss_fn = instance_loss_fn or F.cross_entropy
+        total, preds, targets = 0.0, [], []
+        for c in range(n_classes):
+            w, bb = p[f"instance_classifiers.{c}.weight"], p[f"instance_classifiers.{c}.bias"]
+            Ab = (A[c] if multi else A[-1]).view(1, -1)
+            if int(label) == c:  # inst_eval (:116-132)
+                ids = torch.cat([torch.topk(Ab, k_sample)[1][-1], torch.topk(-Ab, k_sample, dim=1)[1][-1]])
+                tg = torch.cat([torch.ones(k_sample, dtype=torch.long), torch.zeros(k_sample, dtype=torch.long)])
+            elif subtyping:      # inst_eval_out (:135-145)
+                ids, tg = torch.topk(Ab, k_sample)[1][-1], torch.zeros(k_sample, dtype=torch.long)
+            else:
+                continue
+            lg = F.linear(h1[ids], w, bb)
+            total = total + loss_fn(lg, tg)
+            preds.append(lg.argmax(dim=1))
+            targets.append(tg)
+        if subtyping:
+            total = total / n_classes
+        res = dict(instance_loss=total, inst_preds=torch.cat(preds), inst_labels=torch.cat(targets))
+    M = torch.mm(A, h1)
+    if multi:
+        logits = torch.stack([F.linear(M[c], p[f"classifiers.{c}.weight"], p[f"classifiers.{c}.bias"]).reshape(()) for c in range(n_classes)]).view(1, -1)
+    else:
+        logits = F.linear(M, p["classifiers.weight"], p["classifiers.bias"])
+    res["features"] = M
+    return logits, F.softmax(logits, dim=1), torch.topk(logits, 1, dim=1)[1], A_raw, res
+
+
+def clam_train_step(h, params_np, label, n_classes=2, multi=False, k_sample=8, instance_eval=True, subtyping=False, bag_weight=0.7,
+                    masks=None):
+    """One step of train_loop_clam / train_loop (utils/core_utils.py:300-348, 373-426) -> (outputs dict, grads dict)."""
+    p = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params_np.items()}
+    h = h.clone().requires_grad_(True)
+    logits, y_prob, y_hat, a_raw, res = clam_forward_train(h, p, n_classes, multi, k_sample, label, instance_eval, subtyping, masks)
+    loss = F.cross_entropy(logits, torch.tensor([label]))
+    total = bag_weight * loss + (1 - bag_weight) * res["instance_loss"] if instance_eval else loss
+    total.backward()
+    out = dict(logits=logits.detach(), A_raw=a_raw.detach(), M=res["features"].detach(), loss=total.detach())
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()}
+    grads["bag"] = h.grad
+    if instance_eval:
+        out["inst_preds"], out["instance_loss"] = res["inst_preds"], res["instance_loss"].detach()
+    return out, grads

@@ -69,13 +69,55 @@ def save(name, **arrs):
 ROWS = [0, 1, 128, 256]
 
 
+def clam_train_goldens(clam):
+    """Training steps of the reference's CLAM modules with autograd: the loss of train_loop_clam
+    (utils/core_utils.py:300-348: bag_weight * CE(logits, label) + (1 - bag_weight) * instance_loss, bag_weight 0.7) or of
+    train_loop (:373-426: CE alone), backward(), and the gradient of every parameter."""
+    def step(model, h, label, instance_eval, bag_weight=0.7):
+        model.train()
+        model.zero_grad()
+        lab = torch.tensor([label])
+        logits, y_prob, y_hat, a_raw, res = model(h, label=lab, instance_eval=instance_eval, return_features=True)
+        loss = torch.nn.functional.cross_entropy(logits, lab)
+        total = bag_weight * loss + (1 - bag_weight) * res["instance_loss"] if instance_eval else loss
+        total.backward()
+        d = dict(logits=logits, Y_prob=y_prob, Y_hat=y_hat, A_raw=a_raw, M=res["features"], loss=total)
+        if instance_eval:
+            d["instance_loss"] = res["instance_loss"]
+            d["inst_preds"], d["inst_labels"] = res["inst_preds"], res["inst_labels"]
+        for k, p in model.named_parameters():
+            d["grad." + k] = p.grad if p.grad is not None else torch.zeros_like(p)
+        return d
+
+    with torch.enable_grad():
+        for n, seed in ((15, 21), (100, 22), (2000, 23)):
+            m = load(clam.CLAM_SB(size_arg="hipt_big", k_sample=8), synth.clam_param_specs((192, 128, 64)), 192)
+            h = synth.hash_uniform_torch((n, 192), seed=seed)
+            save(f"clam_grad_hipt_big_n{n}", **step(m, h, 1, True))
+        m = load(clam.CLAM_SB(size_arg="hipt_big", k_sample=8), synth.clam_param_specs((192, 128, 64)), 192)
+        save("clam_grad_hipt_big_n100_bagonly", **step(m, synth.hash_uniform_torch((100, 192), seed=22), 0, False))
+        m = load(clam.CLAM_SB(size_arg="hipt_smallest", k_sample=4, subtyping=True), synth.clam_param_specs((192, 8, 4)), 8)
+        save("clam_grad_hipt_smallest_n100", **step(m, synth.hash_uniform_torch((100, 192), seed=6), 0, True))
+        mb = load(clam.CLAM_MB(size_arg="hipt_big", k_sample=8, n_classes=3, subtyping=True),
+                  synth.clam_param_specs((192, 128, 64), n_classes=3, multi=True), 193)
+        save("clam_mb_grad_hipt_big_n100", **step(mb, synth.hash_uniform_torch((100, 192), seed=24), 2, True))
+    with torch.no_grad():  # CLAM_MB eval forward (no instance branch)
+        mb.eval()
+        logits, y_prob, y_hat, a_raw, res = mb(synth.hash_uniform_torch((333, 192), seed=25), return_features=True)
+        save("clam_mb_hipt_big_n333", logits=logits, Y_prob=y_prob, Y_hat=y_hat, A_raw=a_raw, M=res["features"])
+
+
 @torch.no_grad()
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="", help="'train': only the CLAM training-step fixtures")
     ap.add_argument("--skip-4096", action="store_true")
     args = ap.parse_args()
     vits, vits4k, clam = import_reference(args.ref)
+    clam_train_goldens(clam)
+    if args.only == "train":
+        return
     torch.manual_seed(0)
 
     # ---- (1)+(3) ViT-256, full config, two 256x256 patches (BASELINE config 2 uses patch 0) ----

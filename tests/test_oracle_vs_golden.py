@@ -198,3 +198,50 @@ def test_torch_cpu_oracle_clam_sb(name, size, base, shape, seed):
     assert maxdiff(a_raw.numpy(), g["A_raw"]) < TOL and maxdiff(logits.numpy(), g["logits"]) < TOL
     assert maxdiff(y_prob.numpy(), g["Y_prob"]) < TOL and maxdiff(M.numpy(), g["M"]) < TOL
     assert np.array_equal(y_hat.numpy(), g["Y_hat"])
+
+
+# ---------------------------------------------------------------------------------------------
+# CLAM training step: the reference's gradients (tests/golden/clam_*grad*.npz) pin the torch-CPU oracle's autograd step
+# and the host mirror's own CPU training path
+# ---------------------------------------------------------------------------------------------
+TRAIN_CASES = [
+    # name, size, base, (N, S0) seed, label, n_classes, multi, k, subtyping, instance_eval
+    ("clam_grad_hipt_big_n15", (192, 128, 64), 192, (15, 192), 21, 1, 2, False, 8, False, True),
+    ("clam_grad_hipt_big_n100", (192, 128, 64), 192, (100, 192), 22, 1, 2, False, 8, False, True),
+    ("clam_grad_hipt_big_n2000", (192, 128, 64), 192, (2000, 192), 23, 1, 2, False, 8, False, True),
+    ("clam_grad_hipt_big_n100_bagonly", (192, 128, 64), 192, (100, 192), 22, 0, 2, False, 8, False, False),
+    ("clam_grad_hipt_smallest_n100", (192, 8, 4), 8, (100, 192), 6, 0, 2, False, 4, True, True),
+    ("clam_mb_grad_hipt_big_n100", (192, 128, 64), 193, (100, 192), 24, 2, 3, True, 8, True, True),
+]
+
+
+@pytest.mark.parametrize("name,size,base,shape,seed,label,ncls,multi,k,subtyping,inst", TRAIN_CASES)
+def test_torch_cpu_oracle_train_step_gradients(name, size, base, shape, seed, label, ncls, multi, k, subtyping, inst):
+    import torch
+    from oracle import torch_cpu as TO
+    g = golden(name)
+    pn = P(synth.clam_param_specs(size, n_classes=ncls, multi=multi), base)
+    out, grads = TO.clam_train_step(torch.from_numpy(synth.hash_uniform_np(shape, seed)), pn, label, ncls, multi, k, inst, subtyping)
+    assert maxdiff(out["logits"].numpy(), g["logits"]) < 1e-5 and maxdiff(out["A_raw"].numpy(), g["A_raw"]) < 1e-5
+    assert abs(float(out["loss"]) - float(g["loss"])) < 1e-5
+    for key, gr in grads.items():
+        if key != "bag":
+            assert maxdiff(gr.numpy(), g["grad." + key]) < 1e-5, key
+
+
+@pytest.mark.parametrize("name,size,base,shape,seed,label,ncls,multi,k,subtyping,inst", TRAIN_CASES[1::2])
+def test_host_mirror_cpu_training_path_gradients(name, size, base, shape, seed, label, ncls, multi, k, subtyping, inst):
+    """The package's CLAM_SB / CLAM_MB on CPU tensors (PyTorch ops: main.py still trains where there is no GPU)."""
+    import torch
+    from hipt_abmil_atec23_amd import CLAM_MB, CLAM_SB
+    g = golden(name)
+    m = (CLAM_MB if multi else CLAM_SB)(size_arg=list(size), k_sample=k, n_classes=ncls, subtyping=subtyping)
+    m.load_state_dict(synth.make_state_dict(synth.clam_param_specs(size, n_classes=ncls, multi=multi), base))
+    m.train()
+    lab = torch.tensor([label])
+    logits, _, _, a_raw, res = m(torch.from_numpy(synth.hash_uniform_np(shape, seed)), label=lab, instance_eval=inst)
+    loss = torch.nn.functional.cross_entropy(logits, lab)
+    (0.7 * loss + 0.3 * res["instance_loss"] if inst else loss).backward()
+    assert maxdiff(a_raw.detach().numpy(), g["A_raw"]) < 1e-5
+    for key, p in m.named_parameters():
+        assert maxdiff((p.grad if p.grad is not None else torch.zeros_like(p)).numpy(), g["grad." + key]) < 1e-5, key
