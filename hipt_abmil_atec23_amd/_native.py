@@ -47,7 +47,7 @@ class ClamWeights(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("s0", C.c_int32), ("s1", C.c_int32), ("s2", C.c_int32),
                 ("n_classes", C.c_int32), ("reserved", C.c_int32),
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("wab", C.c_void_p), ("bab", C.c_void_p),
-                ("wc", C.c_void_p), ("bc", C.c_void_p), ("wcls", C.c_void_p), ("bcls", C.c_void_p)]
+                ("wc", C.c_void_p), ("bc", C.c_void_p), ("wcls", C.c_void_p), ("bcls", C.c_void_p), ("ring_pk", C.c_void_p)]
 
 
 class ClamTrainWeights(C.Structure):
@@ -93,6 +93,8 @@ SIGNATURES = {
     "hipt_u8_normalize": (_i, [_p, _i, C.c_int64, C.c_int64, _p, _i, _p]),
     "hipt_clam_workspace_bytes": (_sz, [_CW, _i]),
     "hipt_clam_ticket_offset": (_sz, [_CW, _i]),
+    "hipt_clam_ring_packed_bytes": (_sz, [_CW]),
+    "hipt_clam_pack_ring": (_i, [_CW, _p, _p]),
     "hipt_clam_sb_forward": (_i, [_CW, _p, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "hipt_attn_net_gated": (_i, [_CW, _p, _i, _p, _p, _sz, _p]),
     "hipt_clam_gather_h1": (_i, [_CW, _p, _p, _i, _p, _p]),

@@ -722,6 +722,17 @@ static int gated_scores(const hipt_clam_weights* w, const void* x, int xdtype, i
     return hipt_gate_launch(ab, n2, N, w->s2, w->wc, w->bc, A, st);
 }
 
+int hipt_clam_pack_ring(const hipt_clam_weights* w, void* out, void* stream) {
+    int rc = check_clam(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(out && w->w1 && w->wab, "clam_pack_ring: null pointer");
+    if (hipt_clam_ring_packed_bytes(w) == 0) {
+        hipt_set_error("clam_pack_ring: widths [%d,%d,%d] / dtype %d have no packed form", w->s0, w->s1, w->s2, w->dtype);
+        return HIPT_E_UNSUPPORTED;
+    }
+    return hipt_clam_ring_pack_launch(w, out, S(stream));
+}
+
 int hipt_clam_sb_forward(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, float* M,
                          float* logits, float* Y_prob, int64_t* Y_hat, void* workspace, size_t ws_bytes, void* stream) {
     int rc = check_clam(w);
@@ -743,7 +754,10 @@ int hipt_clam_sb_forward(const hipt_clam_weights* w, const void* bag, int N, int
     float* partials = (float*)c.take(clam_partials_bytes(w, N));
     float* gmax = (float*)c.take(256);
     int G = 0;
-    if (hipt_clam_stream_supported(w)) {  // bf16 [S0,128,64]: weight-stationary streaming kernel
+    if (hipt_clam_ring_supported(w)) {  // bf16 [384,128,64]: weights in registers, the bag through an LDS-DMA ring
+        PROF(PC_ABMIL, hipt_clam_ring_launch(w, bag, N, attention_only, A_raw, partials, &G, (unsigned*)gmax, M, logits, Y_prob, Y_hat, st));
+        if (!attention_only && G == 0) return HIPT_OK;
+    } else if (hipt_clam_stream_supported(w)) {  // bf16 [S0,128,64]: weight-stationary streaming kernel
         // (the gmax slot is unused on this path: it holds the finish ticket of the fused combine)
         PROF(PC_ABMIL, hipt_clam_stream_launch(w, bag, N, attention_only, A_raw, partials, &G, (unsigned*)gmax, M, logits, Y_prob, Y_hat, st));
         if (!attention_only && G == 0) return HIPT_OK;

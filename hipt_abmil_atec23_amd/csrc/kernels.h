@@ -131,6 +131,10 @@ bool hipt_clam_stream_supported(const hipt_clam_weights* w);
 int hipt_clam_stream_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw,
                             float* partials, int* n_partials, unsigned* ticket, float* M, float* logits, float* Y_prob,
                             int64_t* Y_hat, hipStream_t st);  // n_partials = 0: combine already done in the kernel
+int hipt_clam_ring_pack_launch(const hipt_clam_weights* w, void* out, hipStream_t st);
+bool hipt_clam_ring_supported(const hipt_clam_weights* w);  // bf16 [384,128,64]: weights in registers, bag through an LDS-DMA ring
+int hipt_clam_ring_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, float* partials,
+                          int* n_partials, unsigned* ticket, float* M, float* logits, float* Y_prob, int64_t* Y_hat, hipStream_t st);
 int hipt_clam_combine_launch(const float* partials, int G, const hipt_clam_weights* w, float* M, float* logits,
                              float* Y_prob, int64_t* Y_hat, hipStream_t st);
 int hipt_gate_launch(const float* ab, int64_t ld, int N, int S2, const float* wc, const float* bc, float* A,

@@ -419,6 +419,11 @@ class CLAM_SB(nn.Module):
             w.n_classes = self.classifiers.out_features
             for k, t in keep.items():
                 setattr(w, k, t.data_ptr())
+            nb = N.lib().hipt_clam_ring_packed_bytes(C_.byref(w))
+            if nb and os.environ.get("HIPT_ABMIL_RING"):  # register-order image for the opt-in bf16 [384,128,64] ring kernel
+                keep["ring_pk"] = torch.empty(nb, dtype=torch.uint8, device=device)
+                N.call("hipt_clam_pack_ring", C_.byref(w), N.ptr(keep["ring_pk"]), N.stream_ptr(device))
+                w.ring_pk = keep["ring_pk"].data_ptr()
             self._packed = (key, w, keep)
         return self._packed[1]
 

@@ -241,7 +241,15 @@ typedef struct hipt_clam_weights {
                                               rows [0,S2) = a, rows [S2,2*S2) = b; bias likewise */
     const float* wc;  const float* bc;     /* attention_c Linear(S2,1): [S2], [1]               */
     const float* wcls; const float* bcls;  /* classifiers Linear(S1,C): [C,S1], [C]             */
+    const void*  ring_pk;     /* optional (NULL = absent): w1 and wab as MFMA operand fragments in register order for the
+                                 bf16 [384,128,64] kernel, written by hipt_clam_pack_ring -- a cache of w1 / wab: re-pack
+                                 after the weights change                                                        */
 } hipt_clam_weights;
+
+/* Packed weight image of the ring kernel (hipt_clam_weights.ring_pk): its size (0: this dtype / shape has none, leave the
+ * pointer NULL) and the pack itself into `out` (device memory of that size).  Once per set of weights. */
+size_t hipt_clam_ring_packed_bytes(const hipt_clam_weights* w);
+int hipt_clam_pack_ring(const hipt_clam_weights* w, void* out, void* stream);
 
 /* Scratch of the calls below.  ONE piece of state lives in it: the 256-byte "ticket block" at byte offset
  * hipt_clam_ticket_offset() (the arrival counter of the in-kernel combine).  It must be ZERO before the first call that
