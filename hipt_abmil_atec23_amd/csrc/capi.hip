@@ -321,6 +321,9 @@ int embed4k(const hipt_vit_weights* w, const void* tokens, int nseq, float* x, h
 
 int default_chunk(int nseq) { return nseq < 2048 ? nseq : 2048; }
 
+// input image kinds: fp32 [.., 3, W, H], or uint8 in the same layout / interleaved [.., W, H, 3] (normalised on device)
+enum { IMG_F32 = 0, IMG_U8_CHW = 1, IMG_U8_HWC = 2 };
+
 }  // namespace
 
 extern "C" {
@@ -530,46 +533,29 @@ int hipt_vit_head(const hipt_vit_weights* w, const float* x, int nseq, int cls_o
 
 // images: fp32 [.., 3, W, H] (kind 0), or uint8 in the same layout (kind 1) / interleaved [.., W, H, 3] (kind 2), which
 // are normalised on device into the compute dtype
-enum { IMG_F32 = 0, IMG_U8_CHW = 1, IMG_U8_HWC = 2 };
 
 static size_t image_extra_bytes(const hipt_vit_weights* w, const hipt_image_layout* lay, int nseq, int kind) {
     // bf16 mode already holds a bf16 image in its workspace; fp32 mode needs an fp32 one for uint8 input
     return (kind != IMG_F32 && w->dtype == HIPT_F32) ? al256((size_t)image_elems(lay, nseq) * 4) : 0;
 }
 
-static int vit256_forward_impl(const hipt_vit_weights* w, const void* images, int kind, const hipt_image_layout* lay, int nseq, int chunk,
-                               float* out, void* workspace, size_t ws_bytes, void* stream) {
-    int rc = check_vit(w);
-    if (rc) return rc;
-    HIPT_CHECK_ARG(images && lay && out && nseq > 0, "vit256_forward: null/empty argument");
+// ViT-256 over the sequences [seq0, seq0 + nseq) of an image tensor that is ALREADY in the compute dtype, chunk by chunk:
+// out[i] = [CLS] feature of sequence seq0 + i.  Scratch: the residual stream of one chunk + its block scratch.
+static int vit256_range_impl(const hipt_vit_weights* w, const void* img, const hipt_image_layout* lay, int seq0, int nseq, int chunk, float* out,
+                             void* workspace, size_t ws_bytes, hipStream_t st) {
+    int rc;
     if (chunk <= 0) chunk = default_chunk(nseq);
     if (chunk > nseq) chunk = nseq;
-    hipStream_t st = S(stream);
     Carver c(workspace, ws_bytes);
     float* x = (float*)c.take((size_t)chunk * w->ntok * w->dim * 4);
     BlockScratch s = carve_blocks(c, w, chunk);
-    const void* img = images;
-    void* imgT = nullptr;
-    const int64_t n_img = image_elems(lay, nseq);
-    if (w->dtype == HIPT_BF16) imgT = c.take((size_t)n_img * 2);
-    else if (kind != IMG_F32) imgT = c.take((size_t)n_img * 4);
     if (!c.ok()) {
         hipt_set_error("vit256_forward: workspace %zu B too small / unaligned (need %zu)", ws_bytes, c.used);
         return HIPT_E_WORKSPACE;
     }
-    if (kind != IMG_F32) {
-        const int per = lay->grid_w * lay->grid_h;
-        HIPT_CHECK_ARG(nseq % per == 0, "vit256_forward: uint8 input must hold whole regions");
-        const int64_t plane = lay->batch_stride / 3;
-        PROF(PC_OTHER, hipt_u8_normalize_launch(images, kind == IMG_U8_HWC, nseq / per, plane, imgT, w->dtype, st));
-        img = imgT;
-    } else if (imgT) {
-        PROF(PC_OTHER, hipt_f32_to_bf16_launch((const float*)images, imgT, n_img, st));
-        img = imgT;
-    }
     for (int s0 = 0; s0 < nseq; s0 += chunk) {
         const int n = nseq - s0 < chunk ? nseq - s0 : chunk;
-        if ((rc = embed256(w, img, lay, s0, n, x, st))) return rc;
+        if ((rc = embed256(w, img, lay, seq0 + s0, n, x, st))) return rc;
         if (can_prune_last(w)) {
             float* xc = (float*)((char*)s.hid + 4096);  // (the hidden-tensor slot is free on this path; its head holds tile queues)
             bool have_xn = false, x_img = false;  // (x is this function's own buffer: it may come back as an activation image)
@@ -586,9 +572,80 @@ static int vit256_forward_impl(const hipt_vit_weights* w, const void* images, in
     return HIPT_OK;
 }
 
+static size_t vit256_range_bytes(const hipt_vit_weights* w, int nseq, int chunk) {
+    if (chunk <= 0) chunk = default_chunk(nseq);
+    if (chunk > nseq) chunk = nseq;
+    return al256((size_t)chunk * w->ntok * w->dim * 4) + block_scratch_bytes(w, chunk);
+}
+
+// the input image tensor in the compute dtype: fp32 input in fp32 mode is used where it lies (returns `images`), everything
+// else is converted / normalised into `dst`
+static int image_to_compute(const hipt_vit_weights* w, const void* images, int kind, const hipt_image_layout* lay, int nseq, void* dst,
+                            const void** img_out, hipStream_t st) {
+    int rc;
+    const int64_t n_img = image_elems(lay, nseq);
+    if (kind != IMG_F32) {
+        const int per = lay->grid_w * lay->grid_h;
+        HIPT_CHECK_ARG(nseq % per == 0, "vit256_forward: uint8 input must hold whole regions");
+        const int64_t plane = lay->batch_stride / 3;
+        PROF(PC_OTHER, hipt_u8_normalize_launch(images, kind == IMG_U8_HWC, nseq / per, plane, dst, w->dtype, st));
+        *img_out = dst;
+    } else if (w->dtype == HIPT_BF16) {
+        PROF(PC_OTHER, hipt_f32_to_bf16_launch((const float*)images, dst, n_img, st));
+        *img_out = dst;
+    } else {
+        *img_out = images;
+    }
+    return HIPT_OK;
+}
+
+static int vit256_forward_impl(const hipt_vit_weights* w, const void* images, int kind, const hipt_image_layout* lay, int nseq, int chunk,
+                               float* out, void* workspace, size_t ws_bytes, void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(images && lay && out && nseq > 0, "vit256_forward: null/empty argument");
+    hipStream_t st = S(stream);
+    const size_t nrange = vit256_range_bytes(w, nseq, chunk);
+    const int64_t n_img = image_elems(lay, nseq);
+    const size_t nimg = w->dtype == HIPT_BF16 ? al256((size_t)n_img * 2) : kind != IMG_F32 ? al256((size_t)n_img * 4) : 0;
+    if (ws_bytes < nrange + nimg || ((uintptr_t)workspace & 255)) {
+        hipt_set_error("vit256_forward: workspace %zu B too small / unaligned (need %zu)", ws_bytes, nrange + nimg);
+        return HIPT_E_WORKSPACE;
+    }
+    const void* img = images;
+    if ((rc = image_to_compute(w, images, kind, lay, nseq, (char*)workspace + nrange, &img, st))) return rc;
+    return vit256_range_impl(w, img, lay, 0, nseq, chunk, out, workspace, nrange, st);
+}
+
 int hipt_vit256_forward(const hipt_vit_weights* w, const float* images, const hipt_image_layout* lay, int nseq, int chunk,
                         float* out, void* workspace, size_t ws_bytes, void* stream) {
     return vit256_forward_impl(w, images, IMG_F32, lay, nseq, chunk, out, workspace, ws_bytes, stream);
+}
+
+size_t hipt_image_compute_bytes(const hipt_vit_weights* w, const hipt_image_layout* lay, int nseq, int input_kind) {
+    if (!w || !lay || nseq <= 0) return 0;
+    const int64_t n_img = image_elems(lay, nseq);
+    return w->dtype == HIPT_BF16 ? al256((size_t)n_img * 2) : input_kind != IMG_F32 ? al256((size_t)n_img * 4) : 0;
+}
+
+int hipt_image_to_compute(const hipt_vit_weights* w, const void* images, int input_kind, const hipt_image_layout* lay, int nseq, void* dst,
+                          void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(images && lay && nseq > 0 && input_kind >= IMG_F32 && input_kind <= IMG_U8_HWC, "image_to_compute: bad argument");
+    HIPT_CHECK_ARG(dst != nullptr && ((uintptr_t)dst & 255) == 0, "image_to_compute: null / unaligned destination");
+    const void* img = nullptr;
+    return image_to_compute(w, images, input_kind, lay, nseq, dst, &img, S(stream));
+}
+
+size_t hipt_vit256_range_workspace_bytes(const hipt_vit_weights* w, int nseq, int chunk) { return w && nseq > 0 ? vit256_range_bytes(w, nseq, chunk) : 0; }
+
+int hipt_vit256_forward_range(const hipt_vit_weights* w, const void* images_cd, const hipt_image_layout* lay, int seq0, int nseq, int chunk,
+                              float* out, void* workspace, size_t ws_bytes, void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(images_cd && lay && out && nseq > 0 && seq0 >= 0, "vit256_forward_range: null/empty argument");
+    return vit256_range_impl(w, images_cd, lay, seq0, nseq, chunk, out, workspace, ws_bytes, S(stream));
 }
 
 int hipt_vit4k_forward(const hipt_vit_weights* w, const float* tokens_in, int nseq, float* out, void* workspace,

@@ -35,7 +35,9 @@ class HIPT_4K(torch.nn.Module):
         # > 1: a batch of regions is cut into that many parts, each run on its own HIP stream with its own workspace.
         # Every kernel of the path occupies whole CUs (one persistent workgroup each), so the parts do not share CUs:
         # the second stream's kernels fill the CUs the first one's kernel frees in its last, partial round of tiles.
-        self.streams = 1
+        # Default 2: a batch of ONE region (the reference's call pattern) then runs as two half-size patch ranges on two streams
+        # (_run_patch_split: 162 -> 167 regions/s on MI355X), a batch of R >= 2 regions as two groups of regions.
+        self.streams = 2
         self._side_streams = {}
         if compute_dtype is not None:
             self.set_compute_dtype(compute_dtype)
@@ -107,6 +109,8 @@ class HIPT_4K(torch.nn.Module):
                     N.call("hipt_hipt4k_forward", pk256.ref, pk4k.ref, N.ptr(region[lo:hi]), n, W, H, self.chunk, N.ptr(sub_cls),
                            N.ptr(out[lo:hi]), N.ptr(ws), ws.numel(), N.stream_ptr(d256))
 
+            if int(self.streams) > nreg and nseq >= 32 * int(self.streams):
+                return self._run_patch_split(region, u8, hwc, nreg, w_256, h_256, W, H, pk256, d256, want_cls256)
             parts = max(1, min(int(self.streams), nreg))
             if parts == 1:
                 launch(0, nreg, 0)
@@ -131,6 +135,45 @@ class HIPT_4K(torch.nn.Module):
         cls256 = self.model256.forward_features(region, layout=lay, nseq=nseq, chunk=self.chunk)
         tokens = cls256.to(d4k, non_blocking=True).view(nreg, per, -1)
         return self.model4k.forward_tokens(tokens, w_256, h_256), cls256
+
+    def _run_patch_split(self, region, u8, hwc, nreg, w_256, h_256, W, H, pk256, dev, want_cls256):
+        """Fewer regions than streams (the reference's batch of ONE region, extract_features_fp.py:159-171): the PATCHES of the
+        call are spread over the streams instead.  One region is 256 patches = 257 rows per CU: every kernel of a single
+        stream ends in a ragged last round of tiles (2 x 128 rows + 1); two half-size streams fill each other's idle CUs.
+        The input is brought to the compute dtype once, each stream runs ViT-256 over its range of patches into the shared
+        [CLS] grid, ViT-4K follows on the caller's stream."""
+        import ctypes as C
+        per, nseq = w_256 * h_256, nreg * w_256 * h_256
+        lay = N.ImageLayout(w_256, h_256, 256, 256, H, W * H, 3 * W * H)
+        kind = (2 if hwc else 1) if u8 else 0
+        cur = torch.cuda.current_stream(dev)
+        nb = N.lib().hipt_image_compute_bytes(pk256.ref, C.byref(lay), nseq, kind)
+        img = region
+        if nb:
+            img = Fn.workspace(dev, nb, ("img", cur.cuda_stream))
+            N.call("hipt_image_to_compute", pk256.ref, N.ptr(region), kind, C.byref(lay), nseq, N.ptr(img), N.stream_ptr(dev))
+        cls256 = torch.empty((nseq, pk256.w.dim), dtype=torch.float32, device=dev)
+        parts = int(self.streams)
+        bounds = [(nseq * k // parts) // 16 * 16 for k in range(parts)] + [nseq]  # whole 16-sequence groups: whole MFMA row fragments
+        key = (dev.index, parts)
+        if key not in self._side_streams:
+            self._side_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(parts)]
+        for k, st in enumerate(self._side_streams[key]):
+            lo, n = bounds[k], bounds[k + 1] - bounds[k]
+            if n <= 0:
+                continue
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                need = N.lib().hipt_vit256_range_workspace_bytes(pk256.ref, n, self.chunk)
+                ws = Fn.workspace(dev, need, 1 + k)
+                N.call("hipt_vit256_forward_range", pk256.ref, N.ptr(img), C.byref(lay), lo, n, self.chunk, N.ptr(cls256[lo:lo + n]),
+                       N.ptr(ws), ws.numel(), N.stream_ptr(dev))
+            for t in (region, cls256):
+                t.record_stream(st)
+        for st in self._side_streams[key]:
+            cur.wait_stream(st)
+        out = self.model4k.forward_tokens(cls256.view(nreg, per, -1), w_256, h_256)
+        return out, (cls256 if want_cls256 else None)
 
     def forward(self, x):
         """[R,3,W',H'] float -> [R,192] ViT-4K [CLS] features (hipt_4k.py:48-76; the reference takes R = 1).

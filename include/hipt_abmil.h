@@ -196,6 +196,20 @@ int hipt_vit_head(const hipt_vit_weights* w, const float* x, int nseq, int cls_o
 int hipt_vit256_forward(const hipt_vit_weights* w, const float* images, const hipt_image_layout* lay,
                         int nseq, int chunk, float* out, void* workspace, size_t ws_bytes, void* stream);
 
+/* The same in two steps, for callers that spread the patches of ONE call over several HIP streams (a batch-of-one region on
+ * two streams: each stream's kernels fill the CUs the other's leave idle in their ragged last round of tiles):
+ *   hipt_image_to_compute  the input tensor in the compute dtype (input_kind 0: fp32 [..,3,W,H]; 1: uint8 [..,3,W,H]; 2: uint8
+ *                          interleaved [..,W,H,3], both normalised (x / 255 - 0.5) / 0.5) into dst
+ *                          (hipt_image_compute_bytes(); 0 = fp32 input in fp32 mode: use the input where it lies);
+ *   hipt_vit256_forward_range  ViT-256 over sequences [seq0, seq0 + nseq) of that tensor -> out[nseq, D]
+ *                          (workspace >= hipt_vit256_range_workspace_bytes(w, nseq, chunk)). */
+size_t hipt_image_compute_bytes(const hipt_vit_weights* w, const hipt_image_layout* lay, int nseq, int input_kind);
+int hipt_image_to_compute(const hipt_vit_weights* w, const void* images, int input_kind, const hipt_image_layout* lay,
+                          int nseq, void* dst, void* stream);
+size_t hipt_vit256_range_workspace_bytes(const hipt_vit_weights* w, int nseq, int chunk);
+int hipt_vit256_forward_range(const hipt_vit_weights* w, const void* images_cd, const hipt_image_layout* lay,
+                              int seq0, int nseq, int chunk, float* out, void* workspace, size_t ws_bytes, void* stream);
+
 /* Whole ViT-4K forward -> out[nseq, D] fp32. */
 int hipt_vit4k_forward(const hipt_vit_weights* w, const float* tokens_in, int nseq, float* out,
                        void* workspace, size_t ws_bytes, void* stream);

@@ -3,8 +3,8 @@ seeded inputs and against the golden vectors captured from the reference modules
 
 Tolerances (BASELINE.json north_star): fp32 mode 1e-4 absolute on attention weights / logits /
 features, indices bit-exact.  bf16 mode cannot meet 1e-4 (CPU bf16 autocast of the
-reference itself is 2.4e-2 max-abs off); its bar is rel-L2 <= 2e-2 and cosine >= 0.999 vs the fp32
-golden, stated per test.
+reference itself is 2.4e-2 max-abs off); SURVEY.md 8d recommends rel-L2 <= 2e-2 and cosine >= 0.999 vs the fp32
+golden; the tests hold the build to twice what it measures (rel-L2 <= 1.3e-2, cosine >= 0.9999), stated and printed per test.
 """
 import os
 
@@ -194,9 +194,11 @@ def test_vit256_bf16_vs_reference_golden(vit256):
     try:
         x = synth.hash_uniform_torch((2, 3, 256, 256), 2, device=DEV)
         out = vit256(x)
-        assert rel_l2(out, g["out"]) < 2e-2 and cosine(out, g["out"]) > 0.999
+        print(f"ViT-256 bf16 vs reference: rel-L2 {rel_l2(out, g['out']):.2e}, cosine {cosine(out, g['out']):.6f}")
+        assert rel_l2(out, g["out"]) < 1.3e-2 and cosine(out, g["out"]) > 0.9999  # 2 x measured (6.4e-3); SURVEY 8d allows 2e-2
         attn = vit256.get_last_selfattention(x)
-        assert md(attn[:, :, 0], g["attn_cls"]) < 5e-3
+        print(f"ViT-256 bf16 [CLS] attention row vs reference: max abs {md(attn[:, :, 0], g['attn_cls']):.2e}")
+        assert md(attn[:, :, 0], g["attn_cls"]) < 1e-3  # 2 x measured (4.6e-4)
     finally:
         vit256.set_compute_dtype("fp32")
 
@@ -231,7 +233,8 @@ def test_vit4k_vs_reference_golden(vit4k):
     vit4k.set_compute_dtype("bf16")
     try:
         o = vit4k(g16)
-        assert rel_l2(o, g["out16"]) < 2e-2 and cosine(o, g["out16"]) > 0.999
+        print(f"ViT-4K bf16 vs reference: rel-L2 {rel_l2(o, g['out16']):.2e}")
+        assert rel_l2(o, g["out16"]) < 1.2e-2 and cosine(o, g["out16"]) > 0.9999  # 2 x measured (5.5e-3)
     finally:
         vit4k.set_compute_dtype("fp32")
 
@@ -394,6 +397,7 @@ def test_hipt4k_region_batch_equals_single_regions(hipt):
     # the same batch cut over two HIP streams (own workspace each): identical bits
     hipt.set_compute_dtype("bf16")
     try:
+        hipt.streams = 1
         one = hipt(x)
         hipt.streams = 2
         two = hipt(x)
@@ -405,6 +409,7 @@ def test_hipt4k_region_batch_equals_single_regions(hipt):
     x2 = synth.hash_uniform_torch((2, 3, 1024, 1024), 34, device=DEV)
     hipt.set_compute_dtype("bf16")
     try:
+        hipt.streams = 1
         one = hipt(x2)
         hipt.streams = 2
         two = hipt(x2)
@@ -414,6 +419,32 @@ def test_hipt4k_region_batch_equals_single_regions(hipt):
     assert torch.equal(one, two) and torch.equal(one[1:], two[1:])
     with pytest.raises(ValueError):
         hipt.forward_asset_dict(x)
+
+
+def test_hipt4k_one_region_split_over_streams_by_patches(hipt):
+    """Fewer regions than streams (the reference's batch of one): the call's PATCHES are spread over the streams
+    (HIPT_4K._run_patch_split: image brought to the compute dtype once, hipt_vit256_forward_range per stream into the shared
+    [CLS] grid, ViT-4K behind the join).  Same bits as one stream, for float and uint8 input, and for forward_asset_dict."""
+    x = synth.hash_uniform_torch((1, 3, 2048, 2048), 35, device=DEV)  # 64 patches -> 2 x 32
+    xu = ((x * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8)
+    try:
+        for dt in ("bf16", "fp32"):
+            hipt.set_compute_dtype(dt)
+            hipt.streams = 1
+            one, one_u = hipt(x), hipt(xu)
+            d1 = hipt.forward_asset_dict(x)
+            before = N.calls
+            hipt.streams = 2
+            two, two_u = hipt(x), hipt(xu)
+            d2 = hipt.forward_asset_dict(x)
+            assert N.calls - before >= 3 * 3  # convert (bf16) / 2 ranges / ViT-4K per call
+            assert torch.equal(one, two) and torch.equal(one_u, two_u), dt
+            assert np.array_equal(d1["features_cls256"], d2["features_cls256"]) and np.array_equal(d1["features_cls4k"], d2["features_cls4k"])
+        hipt.streams = 3  # uneven ranges (16-sequence groups: 16 / 16 / 32)
+        assert torch.equal(hipt(x), one)
+    finally:
+        hipt.streams = 1
+        hipt.set_compute_dtype("fp32")
 
 
 def test_hipt4k_uint8_input_equals_normalised_float(hipt):
@@ -475,8 +506,9 @@ def test_hipt4k_full_region_fp32_and_bf16(hipt):
         d = hipt.forward_asset_dict(x)
         c = torch.from_numpy(d["features_cls256"])
         o = torch.from_numpy(d["features_cls4k"])
-        assert rel_l2(c, g["cls256"]) < 2e-2 and cosine(c, g["cls256"]) > 0.999
-        assert rel_l2(o, g["out"]) < 3e-2 and cosine(o, g["out"]) > 0.999
+        print(f"HIPT_4K 4096x4096 bf16 vs reference: cls256 rel-L2 {rel_l2(c, g['cls256']):.2e}, [1,192] rel-L2 {rel_l2(o, g['out']):.2e}, cosine {cosine(o, g['out']):.6f}")
+        assert rel_l2(c, g["cls256"]) < 1.3e-2 and cosine(c, g["cls256"]) > 0.9999  # 2 x measured (6.3e-3)
+        assert rel_l2(o, g["out"]) < 1.2e-2 and cosine(o, g["out"]) > 0.9999       # 2 x measured (6.0e-3); SURVEY.md 8d bar: 2e-2
         # idempotence: same input, same bits
         assert np.array_equal(hipt.forward_asset_dict(x)["features_cls4k"], d["features_cls4k"])
     finally:
@@ -534,9 +566,10 @@ def test_clam_sb_bf16_config1():
     h = synth.hash_uniform_torch((2000, 384), 1, device=DEV)
     with torch.no_grad():
         logits, y_prob, y_hat, a_raw, res = m(h, return_features=True)
-    # bf16 operands: A_raw spans [-6.3, 3.3]; bar = 5e-2 abs on A_raw, 2e-2 rel-L2 on M, same argmax
-    assert md(a_raw, g["A_raw"]) < 5e-2
-    assert rel_l2(res["features"], g["M"]) < 2e-2 and md(logits, g["logits"]) < 2e-2
+    # bf16 operands: A_raw spans [-6.3, 3.3]; bars = 2 x measured: 4e-2 abs on A_raw (1.7e-2), 2e-3 rel-L2 on M (5e-4), same argmax
+    print(f"CLAM_SB bf16 2000x384 vs reference: A_raw max abs {md(a_raw, g['A_raw']):.2e}, M rel-L2 {rel_l2(res['features'], g['M']):.2e}, logits max abs {md(logits, g['logits']):.2e}")
+    assert md(a_raw, g["A_raw"]) < 4e-2
+    assert rel_l2(res["features"], g["M"]) < 2e-3 and md(logits, g["logits"]) < 1e-3
     assert np.array_equal(y_hat.cpu().numpy(), g["Y_hat"])
 
 
@@ -553,9 +586,17 @@ def test_attn_net_gated_vs_reference_golden():
     with torch.no_grad():
         A, x = m(h)
     assert x is h and A.shape == (2000, 1) and md(A, g["A"]) < TOL
+    with torch.no_grad():  # nn.Linear semantics: any leading dims; a wrong feature width is an error, not an out-of-bounds read
+        A3, x3 = m(h.view(4, 500, 384))
+        assert A3.shape == (4, 500, 1) and torch.equal(A3.view(2000, 1), A) and x3.shape == (4, 500, 384)
+        with pytest.raises(RuntimeError, match="does not end in"):
+            m(h[:, :256])
+        cpu_module = Attn_Net_Gated(L=384, D=256, dropout=0.0, n_classes=1).eval()  # parameters never moved: clean error, no GPU fault
+        with pytest.raises(RuntimeError, match="expected all tensors on"):
+            cpu_module(h)
 
 
-@pytest.mark.parametrize("dtype,tolA,tolM", [("fp32", 1e-4, 1e-4), ("bf16", 6e-2, 2e-2)])
+@pytest.mark.parametrize("dtype,tolA,tolM", [("fp32", 1e-4, 1e-4), ("bf16", 4e-2, 2e-3)])  # bf16: 2 x measured (2.0e-2 / 3.7e-4)
 def test_clam_full_size_100k_properties(dtype, tolA, tolM):
     """BASELINE config 4 shape (100 000 x 384): oracle on the full bag + size-independent properties."""
     n = 100_000
@@ -565,6 +606,8 @@ def test_clam_full_size_100k_properties(dtype, tolA, tolM):
     with torch.no_grad():
         logits, y_prob, y_hat, a_raw, res = m(h, return_features=True)
     r = O.clam_sb_forward(h.cpu().numpy().astype(np.float64), {k: v.astype(np.float64) for k, v in p.items()})
+    print(f"CLAM_SB {dtype} 100000x384 vs fp64 oracle: A_raw max abs {md(a_raw, r['A_raw']):.2e}, M rel-L2 {rel_l2(res['features'], r['M']):.2e}, "
+          f"logits max abs {md(logits, r['logits']):.2e}")
     assert md(a_raw, r["A_raw"]) < tolA
     assert rel_l2(res["features"], r["M"]) < tolM and md(logits, r["logits"]) < max(tolM, 1e-4)
     assert np.array_equal(y_hat.cpu().numpy(), r["Y_hat"])
@@ -579,6 +622,29 @@ def test_clam_full_size_100k_properties(dtype, tolA, tolM):
         l2, _, _, a_p, res2 = m(h[perm].contiguous(), return_features=True)
     assert torch.equal(a_p[0], a_raw[0, perm])
     assert md(l2, logits.cpu().numpy()) < 1e-4 and md(res2["features"], res["features"].cpu().numpy()) < 1e-4
+
+
+def test_clam_two_streams_do_not_share_partials_or_ticket():
+    """Every stream gets its own scratch (partials + the self-resetting finish ticket): concurrent CLAM_SB calls on two
+    streams, repeated, give the bits of the serial calls; the ticket block is zero again after every call."""
+    m = make_clam("hipt_384", (384, 128, 64), 384, 8, False, 0.0).set_compute_dtype("bf16")
+    bags = [synth.hash_uniform_torch((50000 + 777 * i, 384), 70 + i, device=DEV).bfloat16() for i in range(2)]
+    with torch.no_grad():
+        ref = [m(b)[0].clone() for b in bags]
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        for _ in range(20):
+            with torch.cuda.stream(s1):
+                o1 = m(bags[0])[0]
+            with torch.cuda.stream(s2):
+                o2 = m(bags[1])[0]
+            torch.cuda.synchronize()
+            assert torch.equal(o1, ref[0]) and torch.equal(o2, ref[1])
+    for key, ws in Fn._workspaces.items():
+        if isinstance(key[2], tuple) and key[2][0] == "clam":
+            w = m._pack(torch.device(DEV))
+            off = N.lib().hipt_clam_ticket_offset(__import__("ctypes").byref(w), 50000)
+            assert int(ws[off:off + 256].sum()) == 0, key
 
 
 # ---------------------------------------------------------------------------------------------
