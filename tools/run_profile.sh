@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 cd /tmp
 # one stream: with the default three, launches of different streams share the CUs and a kernel's duration in the
 # trace is no longer its own (the roofline leg inside bench.py measures on one stream for the same reason)
-CMD="python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1"
+CMD="python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --slides 0 --streams 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -o prof -- $CMD > $REPO/gpurun_out/prof_$TAG.log 2>&1
 echo "kernel trace done"
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $REPO/gpurun_out/pmc_fetch_$TAG -o pmc -- $CMD > $REPO/gpurun_out/pmc_fetch_$TAG.log 2>&1
