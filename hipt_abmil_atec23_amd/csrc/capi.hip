@@ -86,6 +86,8 @@ int check_vit(const hipt_vit_weights* w) {
 }
 
 // Attention.scale (vision_transformer.py:112): qk_scale when the module was built with one, else head_dim ** -0.5
+// which of the two fused-MLP weight images HIPT_PACK_MLP holds for this model (one answer per process: pack and launch agree)
+inline int mlp_pk_fmt(const hipt_vit_weights* w) { return hipt_mlp32_supported(w->dtype, w->dim, w->hidden) ? 1 : 0; }
 inline float attn_scale(const hipt_vit_weights* w) { return w->attn_scale > 0.f ? w->attn_scale : 1.0f / sqrtf((float)(w->dim / w->heads)); }
 
 struct BlockScratch {
@@ -187,7 +189,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             MlpParams m;
             memset(&m, 0, sizeof(m));
             m.x = x; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
-            m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.M = M; m.D = D; m.hidden = w->hidden;
+            m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.wpk_fmt = mlp_pk_fmt(w); m.M = M; m.D = D; m.hidden = w->hidden;
             m.counter = (int*)s.hid;
             have_xn = chain && (i + 1 < b1 || emit_last) && i + 1 < w->depth;
             if (have_xn) {
@@ -254,7 +256,7 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
     MlpParams m;
     memset(&m, 0, sizeof(m));
     m.x = xc; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
-    m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.M = nseq; m.D = D; m.hidden = w->hidden;
+    m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.wpk_fmt = mlp_pk_fmt(w); m.M = nseq; m.D = D; m.hidden = w->hidden;
     m.counter = (int*)s.hid;
     PROF(PC_LASTCLS, hipt_mlp_launch(m, st));
     return HIPT_OK;
@@ -518,7 +520,9 @@ int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* 
     switch (what) {
         case HIPT_PACK_QKV: return hipt_seqgemm_pack_launch(b.qkv_w, 3 * D, D, out, st);
         case HIPT_PACK_PROJ: return hipt_seqgemm_pack_launch(b.proj_w, D, D, out, st);
-        default: return hipt_mlp_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
+        default:
+            if (mlp_pk_fmt(w) == 1) return hipt_mlp32_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
+            return hipt_mlp_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
     }
 }
 

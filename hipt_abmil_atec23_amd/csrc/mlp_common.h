@@ -28,6 +28,22 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
     return x * r;
 }
 
+
+// The same sigmoid form for ONE element, un-packed and with a degree-2 q (3 coefficients, x^2 clamped at 64 so that the positive
+// leading term never flips the sign of the exponent): |gelu error| <= 2.6e-5 for every finite fp32 x (tools/fit_gelu.py 3).
+// Why un-packed: v_pk_{mul,fma,add}_f32 do NOT run beside an MFMA -- tools/issue_mix_probe.hip: 16 packed FMAs in the gaps of
+// four 32x32x16 MFMAs take the four MFMAs' 128 cycles PLUS 8 cycles each, with one or with two waves per SIMD, while plain v_fma_f32
+// / v_exp_f32 issue in the 24 cycles per MFMA the matrix pipe leaves free.  mlp32.hip is compiled with -fno-slp-vectorize so
+// that hipcc does not re-pack these.
+__device__ __forceinline__ float gelu1(float x) {
+#pragma clang fp contract(off)
+    const float t = __builtin_fminf(x * x, 64.0f);
+    float q = __builtin_fmaf(t, 1.014264505e-03f, -1.067757332e-01f);
+    q = __builtin_fmaf(q, t, -2.301121329e+00f);
+    const float d = __builtin_amdgcn_exp2f(x * q) + 1.0f;
+    return x * __builtin_amdgcn_rcpf(d);
+}
+
 template <int NCH>
 __device__ __forceinline__ void ln_rows(f32x4 (&v)[NCH][2], const float* gam, const float* bet, int K, float eps, int g,
                                         u32x4 (&out)[NCH]) {

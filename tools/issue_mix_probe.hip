@@ -1,0 +1,310 @@
+// Microbenchmark: what one wave per SIMD pays for the things the fused-MLP kernel puts between its MFMAs.
+// A "group" = 4 x v_mfma_f32_32x32x16_bf16 (128 matrix-pipe cycles) plus, by variant:
+//   reads : 4 x ds_read_b128 of conflict-free 1 KiB fragments, either all at the top of the group followed by a counted wait
+//           (the kernel's form) or one after each MFMA with lgkmcnt(3) in front of every MFMA
+//   dma   : LDS-DMA pieces (1 KiB each, L2-resident source): one after the first MFMA, or two after the last
+//   valu  : NV independent v_fma_f32 after each MFMA (NV = 3, 5, 6), or 2 v_exp_f32 + 3 v_fma_f32
+// 4 waves per CU (one per SIMD), 256 CUs, every wave runs the same stream; reports core cycles per group.
+//   hipcc -O3 --offload-arch=gfx950 tools/issue_mix_probe.hip -o tools/probe_bin/issue_mix_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define LDS_AS __attribute__((address_space(3)))
+constexpr int LDS = 144 * 1024;
+
+enum { RD_NONE = 0, RD_TOP = 1, RD_MIX = 2 };
+enum { DMA_NONE = 0, DMA_1 = 1, DMA_2END = 2, DMA_1SKEW = 3 };
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define WAITL(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+
+template <int RD, int DMA, int NV, int TRANS>
+__global__ __launch_bounds__(256, 1) void k(const char* src, int iters, unsigned long long* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // fill the read region with small bf16 values
+    for (int i = threadIdx.x; i < 96 * 1024 / 4; i += 256) ((uint32_t*)smem)[i] = 0x3c003c00u;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 2359296, 0x00020000);
+    const uint32_t fb = (uint32_t)(uintptr_t)(LDS_AS char*)smem + lane * 16;
+    const uint32_t ilane = wave * 1024 + lane * 16;
+    f32x16 a0, a1;
+    for (int e = 0; e < 16; ++e) a0[e] = a1[e] = 0.f;
+    u32x4 w0[4], w1[4], b = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    for (int i = 0; i < 4; ++i) w0[i] = w1[i] = b;
+    float f0 = 1.f, f1 = 1.f, f2 = 1.f, f3 = 1.f, f4 = 1.f, f5 = 1.f, c = 0.999f, d = 1e-3f;
+    int ioff = 0, slot = 0;
+    auto mma = [&](f32x16& acc, const u32x4& a) __attribute__((always_inline)) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    };
+    auto valu = [&]() __attribute__((always_inline)) {
+        if constexpr (TRANS) {
+            asm volatile("v_exp_f32 %0, %0" : "+v"(f0));
+            asm volatile("v_exp_f32 %0, %0" : "+v"(f1));
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f2) : "v"(c), "v"(d));
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f3) : "v"(c), "v"(d));
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f4) : "v"(c), "v"(d));
+        } else {
+            if constexpr (NV > 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f0) : "v"(c), "v"(d));
+            if constexpr (NV > 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f1) : "v"(c), "v"(d));
+            if constexpr (NV > 2) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f2) : "v"(c), "v"(d));
+            if constexpr (NV > 3) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f3) : "v"(c), "v"(d));
+            if constexpr (NV > 4) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f4) : "v"(c), "v"(d));
+            if constexpr (NV > 5) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f5) : "v"(c), "v"(d));
+        }
+    };
+    auto dma = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(smem + 96 * 1024 + slot * 4096 + wave * 1024), 16, ilane, ioff, 0, 0);
+        ioff = ioff + 4096 >= 2359296 ? 0 : ioff + 4096;
+        slot = (slot + 1) % 12;
+    };
+    // one group; the fragments it multiplies are in `cur`, the reads it issues fill `nxt`
+    auto group = [&](u32x4(&cur)[4], u32x4(&nxt)[4], uint32_t ra) __attribute__((always_inline)) {
+        u32x4 &n0 = nxt[0], &n1 = nxt[1], &n2 = nxt[2], &n3 = nxt[3];
+        if constexpr (RD == RD_TOP) {
+            DSR(n0, ra, 0);
+            DSR(n1, ra, 1024);
+            DSR(n2, ra, 2048);
+            DSR(n3, ra, 3072);
+            WAITL(4);
+            SB();
+        }
+        if constexpr (RD == RD_MIX) WAITL(3);
+        mma(a0, cur[0]);
+        SB();
+        if constexpr (RD == RD_MIX) DSR(n0, ra, 0);
+        if constexpr (DMA == DMA_1) dma();
+        if constexpr (DMA == DMA_1SKEW) if (wave == 0) dma();
+        valu();
+        SB();
+        if constexpr (RD == RD_MIX) WAITL(3);
+        mma(a1, cur[1]);
+        SB();
+        if constexpr (RD == RD_MIX) DSR(n1, ra, 1024);
+        if constexpr (DMA == DMA_1SKEW) if (wave == 1) dma();
+        valu();
+        SB();
+        if constexpr (RD == RD_MIX) WAITL(3);
+        mma(a0, cur[2]);
+        SB();
+        if constexpr (RD == RD_MIX) DSR(n2, ra, 2048);
+        if constexpr (DMA == DMA_1SKEW) if (wave == 2) dma();
+        valu();
+        SB();
+        if constexpr (RD == RD_MIX) WAITL(3);
+        mma(a1, cur[3]);
+        SB();
+        if constexpr (RD == RD_MIX) DSR(n3, ra, 3072);
+        if constexpr (DMA == DMA_1SKEW) if (wave == 3) dma();
+        if constexpr (DMA == DMA_2END) {
+            dma();
+            dma();
+        }
+        valu();
+        if constexpr (DMA != DMA_NONE) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        SB();
+    };
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    uint32_t ra = fb;
+    for (int it = 0; it < iters; it += 2) {
+        group(w0, w1, ra);
+        group(w1, w0, ra + 4096);
+        ra = ra + 8192 >= fb + 96 * 1024 ? fb : ra + 8192;
+    }
+    WAITL(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = f0 + f1 + f2 + f3 + f4 + f5;
+    for (int e = 0; e < 16; ++e) s += a0[e] + a1[e];
+    for (int i = 0; i < 4; ++i) s += __builtin_bit_cast(float, w0[i][0] ^ w1[i][1]);
+    if (lane == 0) out[blockIdx.x * 4 + wave] = t1 - t0;
+    if (s == 123.456f) out[0] = 0;  // keep everything alive
+}
+
+
+// ---- spec-driven variant: what sits in each of the 4 gaps of a group ----
+// gap spec bits: 0-3 #v_fma, 4-7 #v_exp (each followed later by nothing), 8 one ds_read_b128, 9 one DMA piece,
+//                10 DMA goes AFTER the valu work instead of before it, 11 s_nop 7 after the DMA, 12 pk_fma instead of fma
+constexpr uint32_t F(int n) { return n; }
+constexpr uint32_t T(int n) { return n << 4; }
+constexpr uint32_t R = 1 << 8, Dm = 1 << 9, DL = 1 << 10, NOP = 1 << 11, PK = 1 << 12;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <uint32_t G0, uint32_t G1, uint32_t G2, uint32_t G3, int NT = 256>
+__global__ __launch_bounds__(NT, 1) void k2(const char* src, int iters, unsigned long long* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 96 * 1024 / 4; i += NT) ((uint32_t*)smem)[i] = 0x3c003c00u;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 2359296, 0x00020000);
+    const uint32_t fb = (uint32_t)(uintptr_t)(LDS_AS char*)smem + lane * 16;
+    const uint32_t ilane = (wave & 3) * 1024 + lane * 16;
+    f32x16 a0, a1;
+    for (int e = 0; e < 16; ++e) a0[e] = a1[e] = 0.f;
+    u32x4 w0[4], w1[4], b = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    for (int i = 0; i < 4; ++i) w0[i] = w1[i] = b;
+    float f[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, c = 0.999f, d = 1e-3f;
+    f32x2 p[4] = {{1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}}, pc = {0.999f, 0.999f}, pd = {1e-3f, 1e-3f};
+    float e0 = 0.5f, e1 = 0.5f, e2 = 0.5f, e3 = 0.5f;
+    int ioff = 0, slot = 0;
+    constexpr int NRD = ((G0 >> 8) & 1) + ((G1 >> 8) & 1) + ((G2 >> 8) & 1) + ((G3 >> 8) & 1);  // 0 or 4
+    constexpr bool ANYDMA = ((G0 | G1 | G2 | G3) & Dm) != 0;
+    auto mma = [&](f32x16& acc, const u32x4& a) __attribute__((always_inline)) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    };
+    auto dma = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(smem + 96 * 1024 + slot * 4096 + (wave & 3) * 1024), 16, ilane, ioff, 0, 0);
+        ioff = ioff + 4096 >= 2359296 ? 0 : ioff + 4096;
+        slot = (slot + 1) % 12;
+    };
+    auto gap = [&](auto S_, u32x4& dst, uint32_t ra, auto OFF_) __attribute__((always_inline)) {
+        constexpr uint32_t S = decltype(S_)::value;
+        constexpr int off = decltype(OFF_)::value;
+        if constexpr (S & R) DSR(dst, ra, off);
+        if constexpr ((S & Dm) && !(S & DL)) {
+            dma();
+            if constexpr (S & NOP) asm volatile("s_nop 7");
+        }
+        constexpr int nf = S & 15, nt = (S >> 4) & 15;
+        if constexpr (nt > 0) asm volatile("v_exp_f32 %0, %0" : "+v"(e0));
+        if constexpr (nt > 1) asm volatile("v_exp_f32 %0, %0" : "+v"(e1));
+        if constexpr (nt > 2) asm volatile("v_rcp_f32 %0, %0" : "+v"(e2));
+        if constexpr (nt > 3) asm volatile("v_rcp_f32 %0, %0" : "+v"(e3));
+        if constexpr (S & PK) {
+#pragma unroll
+            for (int i = 0; i < nf; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i & 3]) : "v"(pc), "v"(pd));
+        } else {
+#pragma unroll
+            for (int i = 0; i < nf; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i & 7]) : "v"(c), "v"(d));
+        }
+        if constexpr ((S & Dm) && (S & DL)) dma();
+        if constexpr (NRD) WAITL(3);
+        SB();
+    };
+    auto group = [&](u32x4(&cur)[4], u32x4(&nxt)[4], uint32_t ra) __attribute__((always_inline)) {
+        mma(a0, cur[0]);
+        SB();
+        gap(std::integral_constant<uint32_t, G0>{}, nxt[0], ra, std::integral_constant<int, 0>{});
+        mma(a1, cur[1]);
+        SB();
+        gap(std::integral_constant<uint32_t, G1>{}, nxt[1], ra, std::integral_constant<int, 1024>{});
+        mma(a0, cur[2]);
+        SB();
+        gap(std::integral_constant<uint32_t, G2>{}, nxt[2], ra, std::integral_constant<int, 2048>{});
+        mma(a1, cur[3]);
+        SB();
+        gap(std::integral_constant<uint32_t, G3>{}, nxt[3], ra, std::integral_constant<int, 3072>{});
+        if constexpr (ANYDMA) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        SB();
+    };
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    uint32_t ra = fb;
+    for (int it = 0; it < iters; it += 2) {
+        group(w0, w1, ra);
+        group(w1, w0, ra + 4096);
+        ra = ra + 8192 >= fb + 96 * 1024 ? fb : ra + 8192;
+    }
+    WAITL(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = e0 + e1 + e2 + e3;
+    for (int i = 0; i < 8; ++i) s += f[i];
+    for (int i = 0; i < 4; ++i) s += p[i][0] + p[i][1];
+    for (int e = 0; e < 16; ++e) s += a0[e] + a1[e];
+    for (int i = 0; i < 4; ++i) s += __builtin_bit_cast(float, w0[i][0] ^ w1[i][1]);
+    if (lane == 0) out[blockIdx.x * (NT / 64) + wave] = t1 - t0;
+    if (s == 123.456f) out[0] = 0;
+}
+#define RUN2(name, g0, g1, g2, g3) run(name, k2<(g0), (g1), (g2), (g3)>, out)
+#define RUN2W(name, g0, g1, g2, g3) run(name, k2<(g0), (g1), (g2), (g3), 512>, out, 512)
+
+template <typename K> void run(const char* name, K kern, unsigned long long* out, int nt = 256) {
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    static char* buf = nullptr;
+    if (!buf) {
+        CK(hipMalloc(&buf, 2359296));
+        CK(hipMemset(buf, 0x3c, 2359296));
+    }
+    const int iters = 20000, grid = 256;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), LDS, 0, buf, 2000, out);
+    CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), LDS, 0, buf, iters, out);
+    CK(hipDeviceSynchronize());
+    static unsigned long long h[256 * 8];
+    const int nw = nt / 64;
+    CK(hipMemcpy(h, out, (size_t)grid * nw * 8, hipMemcpyDeviceToHost));
+    double t = 0;
+    for (int b = 0; b < grid; ++b) {  // a block is done when its last wave is (with 2 waves per SIMD the older one runs ahead)
+        unsigned long long m = 0;
+        for (int w = 0; w < nw; ++w) m = h[b * nw + w] > m ? h[b * nw + w] : m;
+        t += (double)m;
+    }
+    // with 2 waves per SIMD each wave runs `iters` groups: per SIMD that is 2 groups per loop trip
+    printf("%-64s %.1f cycles / group (4 MFMAs = 128)%s\n", name, t / grid / iters / (nw / 4), nw == 8 ? "  [2 waves / SIMD]" : "");
+}
+
+int main() {
+    unsigned long long* out;
+    CK(hipMalloc(&out, 256 * 8 * 8));
+    run("MFMA only", k<RD_NONE, DMA_NONE, 0, 0>, out);
+    run("reads at the top + wait", k<RD_TOP, DMA_NONE, 0, 0>, out);
+    run("reads one per gap", k<RD_MIX, DMA_NONE, 0, 0>, out);
+    run("3 v_fma per gap", k<RD_NONE, DMA_NONE, 3, 0>, out);
+    run("5 v_fma per gap", k<RD_NONE, DMA_NONE, 5, 0>, out);
+    run("6 v_fma per gap", k<RD_NONE, DMA_NONE, 6, 0>, out);
+    run("2 v_exp + 3 v_fma per gap", k<RD_NONE, DMA_NONE, 0, 1>, out);
+    run("1 DMA piece per group", k<RD_NONE, DMA_1, 0, 0>, out);
+    run("1 DMA piece per group, one wave per gap", k<RD_NONE, DMA_1SKEW, 0, 0>, out);
+    run("2 DMA pieces at the end of a group", k<RD_NONE, DMA_2END, 0, 0>, out);
+    run("reads per gap + 1 DMA", k<RD_MIX, DMA_1, 0, 0>, out);
+    run("reads per gap + 3 v_fma per gap", k<RD_MIX, DMA_NONE, 3, 0>, out);
+    run("reads per gap + 5 v_fma per gap", k<RD_MIX, DMA_NONE, 5, 0>, out);
+    run("reads per gap + 3 v_fma per gap + 1 DMA", k<RD_MIX, DMA_1, 3, 0>, out);
+    run("reads per gap + 5 v_fma per gap + 1 DMA", k<RD_MIX, DMA_1, 5, 0>, out);
+    run("reads per gap + 5 v_fma per gap + 1 DMA (one wave per gap)", k<RD_MIX, DMA_1SKEW, 5, 0>, out);
+    run("reads at the top + 5 v_fma per gap + 2 DMA at the end", k<RD_TOP, DMA_2END, 5, 0>, out);
+    run("reads per gap + (2 v_exp + 3 v_fma) per gap + 1 DMA", k<RD_MIX, DMA_1, 0, 1>, out);
+
+    printf("---- per-gap specs (r = read, D = DMA piece first in its gap, Dl = DMA last, nF = n v_fma, nT = n transcendental, pk = packed fma)\n");
+    RUN2("r | r | r | r", R, R, R, R);
+    RUN2("r 2T | r 2T | r 2T | r 2T", R | T(2), R | T(2), R | T(2), R | T(2));
+    RUN2("r 2T 3F | x4", R | T(2) | F(3), R | T(2) | F(3), R | T(2) | F(3), R | T(2) | F(3));
+    RUN2("r 1T 4F | x4", R | T(1) | F(4), R | T(1) | F(4), R | T(1) | F(4), R | T(1) | F(4));
+    RUN2("2T 3F | x4 + D in gap 0 (no reads)", Dm | T(2) | F(3), T(2) | F(3), T(2) | F(3), T(2) | F(3));
+    RUN2("r D | r 6F | r 6F | r 6F", R | Dm, R | F(6), R | F(6), R | F(6));
+    RUN2("r D | r 5F | r 5F | r 5F", R | Dm, R | F(5), R | F(5), R | F(5));
+    RUN2("r D | r 4F | r 4F | r 4F", R | Dm, R | F(4), R | F(4), R | F(4));
+    RUN2("r D | r 2T 3F | r 2T 3F | r 5F", R | Dm, R | T(2) | F(3), R | T(2) | F(3), R | F(5));
+    RUN2("r D | r 2T 2F | r 2T 2F | r 4F", R | Dm, R | T(2) | F(2), R | T(2) | F(2), R | F(4));
+    RUN2("r D | r 1T 4F | r 2T 2F | r 1T 4F", R | Dm, R | T(1) | F(4), R | T(2) | F(2), R | T(1) | F(4));
+    RUN2("r Dl | r 5F | r 5F | r 5F", R | Dm | DL, R | F(5), R | F(5), R | F(5));
+    RUN2("r D nop | r 5F | r 5F | r 5F", R | Dm | NOP, R | F(5), R | F(5), R | F(5));
+    RUN2("r D | r 5pk | r 5pk | r 5pk", R | Dm, R | F(5) | PK, R | F(5) | PK, R | F(5) | PK);
+    RUN2("r 4pk | x4", R | F(4) | PK, R | F(4) | PK, R | F(4) | PK, R | F(4) | PK);
+    RUN2("r 5pk | x4", R | F(5) | PK, R | F(5) | PK, R | F(5) | PK, R | F(5) | PK);
+    RUN2("r 5F | x4", R | F(5), R | F(5), R | F(5), R | F(5));
+    RUN2("r 4F | x4", R | F(4), R | F(4), R | F(4), R | F(4));
+    RUN2("r 3F | x4", R | F(3), R | F(3), R | F(3), R | F(3));
+    RUN2("D only in gap 0", Dm, 0, 0, 0);
+    RUN2("D 3F | 3F | 3F | 3F", Dm | F(3), F(3), F(3), F(3));
+    RUN2("r D 3F | r 3F | r 3F | r 3F", R | Dm | F(3), R | F(3), R | F(3), R | F(3));
+
+    printf("---- the same streams, 8 waves per CU (2 per SIMD)\n");
+    RUN2W("MFMA only", 0, 0, 0, 0);
+    RUN2W("r | r | r | r", R, R, R, R);
+    RUN2W("r 5F | x4", R | F(5), R | F(5), R | F(5), R | F(5));
+    RUN2W("r 2T 3F | x4", R | T(2) | F(3), R | T(2) | F(3), R | T(2) | F(3), R | T(2) | F(3));
+    RUN2W("r 4pk | x4", R | F(4) | PK, R | F(4) | PK, R | F(4) | PK, R | F(4) | PK);
+    RUN2W("r D | r 5F | r 5F | r 5F", R | Dm, R | F(5), R | F(5), R | F(5));
+    RUN2W("r D | r 2T 3F | r 2T 3F | r 5F", R | Dm, R | T(2) | F(3), R | T(2) | F(3), R | F(5));
+    RUN2W("r D 2T 4pk | r 2T 4pk | r D 2T 4pk | r 2T 4pk", R | Dm | T(2) | F(4) | PK, R | T(2) | F(4) | PK, R | Dm | T(2) | F(4) | PK, R | T(2) | F(4) | PK);
+    RUN2W("r D | r D | r | r", R | Dm, R | Dm, R, R);
+    return 0;
+}

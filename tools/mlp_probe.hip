@@ -12,6 +12,10 @@
 bool hipt_mlp_pipe_supported(int, int, int) { return false; }
 int hipt_mlp_pipe_launch(const MlpParams&, hipStream_t) { return -1; }
 #define LAUNCH(DBG, p) launch<6, DBG>(p, 0)
+#elif defined(PROBE_32)  // the 32x32x16 form (mlp32.hip); -DPROBE_32
+#include "../hipt_abmil_atec23_amd/csrc/mlp32.hip"
+#define LAUNCH(DBG, p) hipt_mlp32_launch_dbg<DBG>(p, 0)
+#define hipt_mlp_pack_launch hipt_mlp32_pack_launch
 #else  // the pipelined D = 384 kernel (mlp_pipe.hip)
 #include "../hipt_abmil_atec23_amd/csrc/mlp_pipe.hip"
 #define LAUNCH(DBG, p) hipt_mlp_pipe_launch_dbg<DBG>(p, 0)
@@ -105,8 +109,16 @@ int main(int argc, char** argv) {
         if (hipt_mlp_pack_launch(w1, w2, D, H, pk, 0) != 0) { printf("pack failed\n"); return 1; }
         CK(hipDeviceSynchronize());
         p.wpk = pk;
+#ifdef PROBE_32
+        p.wpk_fmt = 1;
+#endif
     }
 #endif
+    if (getenv("PROBE_IMG") && !check) {  // as inside the pipeline: activation images + the next block's LayerNorm-1 output
+        void* xn;
+        CK(hipMalloc(&xn, hy.size() * 2));
+        p.img = 3; p.xn_out = xn; p.ln_next_w = (float*)g; p.ln_next_b = (float*)bt;
+    }
     if (check) {
         LAUNCH(0, p);
         CK(hipDeviceSynchronize());
@@ -169,6 +181,11 @@ int main(int argc, char** argv) {
     std::vector<int> masks;
     for (int i = 2; i < argc; ++i) masks.push_back(atoi(argv[i]));
     if (masks.empty()) masks = {0, 1, 2, 3, 4, 5, 6, 7};
+#ifdef PROBE_32
+    masks.push_back(8);
+    masks.push_back(12);
+    masks.push_back(15);
+#endif
     for (int m : masks) switch (m) {
             case 0: run<0>(p, iters); break;
             case 1: run<1>(p, iters); break;
@@ -178,6 +195,11 @@ int main(int argc, char** argv) {
             case 5: run<5>(p, iters); break;
             case 6: run<6>(p, iters); break;
             case 7: run<7>(p, iters); break;
+#ifdef PROBE_32
+            case 8: run<8>(p, iters); break;
+            case 12: run<12>(p, iters); break;
+            case 15: run<15>(p, iters); break;
+#endif
         }
     return 0;
 }
