@@ -27,7 +27,8 @@ c_f32p = C.c_void_p  # device pointers travel as integers
 class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
-        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "qkv_pk", "proj_pk", "mlp_pk")]
+        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "qkv_pk", "proj_pk", "mlp_pk")] + [
+        ("mlp_pk_fmt", C.c_int32), ("reserved", C.c_int32)]
 
 
 class VitWeights(C.Structure):
@@ -76,6 +77,7 @@ SIGNATURES = {
     "hipt_attention": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "hipt_vit_workspace_bytes": (_sz, [_VW, _i]),
     "hipt_vit_packed_bytes": (_sz, [_VW, _i]),
+    "hipt_vit_mlp_pack_format": (_i, [_VW]),
     "hipt_vit_pack_weights": (_i, [_VW, _i, _i, _p, _p]),
     "hipt_vit256_forward_workspace_bytes": (_sz, [_VW, _IL, _i, _i]),
     "hipt_vit4k_forward_workspace_bytes": (_sz, [_VW, _i]),

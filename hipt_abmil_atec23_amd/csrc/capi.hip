@@ -86,8 +86,6 @@ int check_vit(const hipt_vit_weights* w) {
 }
 
 // Attention.scale (vision_transformer.py:112): qk_scale when the module was built with one, else head_dim ** -0.5
-// which of the two fused-MLP weight images HIPT_PACK_MLP holds for this model (one answer per process: pack and launch agree)
-inline int mlp_pk_fmt(const hipt_vit_weights* w) { return hipt_mlp32_supported(w->dtype, w->dim, w->hidden) ? 1 : 0; }
 inline float attn_scale(const hipt_vit_weights* w) { return w->attn_scale > 0.f ? w->attn_scale : 1.0f / sqrtf((float)(w->dim / w->heads)); }
 
 struct BlockScratch {
@@ -189,7 +187,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             MlpParams m;
             memset(&m, 0, sizeof(m));
             m.x = x; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
-            m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.wpk_fmt = mlp_pk_fmt(w); m.M = M; m.D = D; m.hidden = w->hidden;
+            m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.wpk_fmt = b.mlp_pk_fmt; m.M = M; m.D = D; m.hidden = w->hidden;
             m.counter = (int*)s.hid;
             have_xn = chain && (i + 1 < b1 || emit_last) && i + 1 < w->depth;
             if (have_xn) {
@@ -256,7 +254,7 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
     MlpParams m;
     memset(&m, 0, sizeof(m));
     m.x = xc; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
-    m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.wpk_fmt = mlp_pk_fmt(w); m.M = nseq; m.D = D; m.hidden = w->hidden;
+    m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.wpk_fmt = b.mlp_pk_fmt; m.M = nseq; m.D = D; m.hidden = w->hidden;
     m.counter = (int*)s.hid;
     PROF(PC_LASTCLS, hipt_mlp_launch(m, st));
     return HIPT_OK;
@@ -494,6 +492,13 @@ int hipt_vit_cls_attention(const hipt_vit_weights* w, float* x, int nseq, float*
     return hipt_attn_cls_probs_launch(s.qkv, probs_cls, nseq, w->ntok, w->heads, dh, attn_scale(w), w->dtype, st);
 }
 
+int hipt_vit_mlp_pack_format(const hipt_vit_weights* w) {
+    if (!w) return 0;
+    if (getenv("HIPT_MLP_WS") && hipt_mlp_ws_supported(w->dtype, w->dim, w->hidden)) return 2;
+    if (!getenv("HIPT_NO_MLP32") && hipt_mlp32_supported(w->dtype, w->dim, w->hidden)) return 1;
+    return 0;
+}
+
 size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {
     if (!w || w->dtype != HIPT_BF16) return 0;
     const int D = w->dim;
@@ -521,7 +526,13 @@ int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* 
         case HIPT_PACK_QKV: return hipt_seqgemm_pack_launch(b.qkv_w, 3 * D, D, out, st);
         case HIPT_PACK_PROJ: return hipt_seqgemm_pack_launch(b.proj_w, D, D, out, st);
         default:
-            if (mlp_pk_fmt(w) == 1) return hipt_mlp32_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
+            // the format the caller recorded beside the pointer (hipt_vit_mlp_pack_format): pack and launch read the same field
+            if (b.mlp_pk_fmt == 2 && hipt_mlp_ws_supported(w->dtype, D, w->hidden)) return hipt_mlp_ws_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
+            if (b.mlp_pk_fmt == 1 && hipt_mlp32_supported(w->dtype, D, w->hidden)) return hipt_mlp32_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
+            if (b.mlp_pk_fmt != 0) {
+                hipt_set_error("hipt_vit_pack_weights: blocks[%d].mlp_pk_fmt = %d is not a format this model has", block, b.mlp_pk_fmt);
+                return HIPT_E_BADARG;
+            }
             return hipt_mlp_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
     }
 }

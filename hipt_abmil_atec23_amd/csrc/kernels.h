@@ -44,7 +44,7 @@ struct SeqGemmParams {
     float ln_eps;
     const void* W;       // bf16 [N, K]
     const void* wpk;     // optional (pipelined kernel only): W pre-packed in ring order (hipt_seqgemm_pack_launch)
-    int wpk_fmt;         // format of wpk: 0 = mlp_pipe.hip's ring image, 1 = mlp32.hip's fragment image (hipt_mlp32_pack_launch)
+    int wpk_fmt;         // format of wpk: 0 = mlp_pipe.hip's ring image, 1 = mlp32.hip's fragment image, 2 = mlp_ws.hip's step image
     int img;             // (pipelined kernel only) activation images: bit 0 = A (bf16, no LayerNorm), bit 1 = out (N = 384);
                          // bit 2 = out (N = 1152) head-major [sequence][q/k/v][head][token][64], out_ntok tokens per sequence
     int out_ntok;
@@ -80,7 +80,7 @@ struct MlpParams {
     const float* b2;
     int M, D, hidden;
     const void* wpk;     // optional (pipelined kernel only): both weights pre-packed in ring order (hipt_mlp_pack_launch)
-    int wpk_fmt;         // format of wpk: 0 = mlp_pipe.hip's ring image, 1 = mlp32.hip's fragment image (hipt_mlp32_pack_launch)
+    int wpk_fmt;         // format of wpk: 0 = mlp_pipe.hip's ring image, 1 = mlp32.hip's fragment image, 2 = mlp_ws.hip's step image
     int img;             // (pipelined kernel only) activation images: bit 0 = y1, xn_out and the updated x, bit 1 = x on entry
     int* counter;        // device int the launcher zeroes on the stream: the kernel's tile queue
     // optional (pipelined kernel only): LayerNorm-1 of the NEXT block applied to the updated rows, written as bf16
@@ -102,9 +102,13 @@ int hipt_mlp_pipe_launch(const MlpParams& p, hipStream_t st);
 // A DMA piece then reads 1 KiB of consecutive bytes instead of 8 row segments of 128 B (2.4x the L2 -> LDS rate).
 int hipt_mlp_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);
 // The 32x32x16-MFMA form of the pipelined kernel (mlp32.hip): packed weights only, its own image format (same size).
-bool hipt_mlp32_supported(int dtype, int D, int hidden);  // (opt-in: false unless HIPT_MLP32 is set)
+bool hipt_mlp32_supported(int dtype, int D, int hidden);  // (shapes only: hipt_vit_mlp_pack_format chooses the kernel)
 int hipt_mlp32_launch(const MlpParams& p, hipStream_t st);
 int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);
+// The wave-specialised form (mlp_ws.hip: 8 waves, fc1 + GELU waves and fc2 waves sharing rows): image format 2.
+bool hipt_mlp_ws_supported(int dtype, int D, int hidden);  // (shapes only; opt-in through hipt_vit_mlp_pack_format)
+int hipt_mlp_ws_launch(const MlpParams& p, hipStream_t st);
+int hipt_mlp_ws_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);
 
 int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, const float* b, void* out, int out_dtype,
                           int64_t out_stride, int rows, int D, float eps, hipStream_t st);

@@ -120,9 +120,12 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     const int nchunk = p.hidden / 128;
     const int upt = 4 * nchunk;  // ring units (phases) per tile pass
 
-    // ---- weight DMA: unit pos of the image = 48 pieces of 1 KiB, byte for byte what its ring slot holds; piece 4 t + wave ----
+    // ---- weight DMA: unit pos of the image = 48 pieces of 1 KiB, byte for byte what its ring slot holds; wave w issues pieces
+    // 12 w .. 12 w + 11.  An LDS-DMA instruction takes its LDS base from M0, and it is WRITING M0 that makes a piece expensive
+    // (tools/issue_mix_probe.hip: +36 cycles per piece with a new M0, +2 with the same M0 and the piece selected by the instruction's
+    // immediate offset, which is added to the LDS and to the global address alike): four consecutive pieces share one M0.
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, 2 * p.hidden * D * 2, 0x00020000);
-    const uint32_t ilane = (uint32_t)(wave * 1024 + lane * 16);
+    const uint32_t ilane = (uint32_t)(12 * wave * 1024 + lane * 16);
     int ioff = 0, islot = 0, ipos = 0;
     auto set_issue = [&](int pos, int slot) {
         ioff = pos * UNIT;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     auto dma_piece = [&](auto T_) __attribute__((always_inline)) {
         constexpr int t = decltype(T_)::value;
         if constexpr ((DBG & 1) == 0)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(smem + islot * UNIT + (4 * t + wave) * 1024), 16, ilane, ioff + t * 4096, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(smem + islot * UNIT + (12 * wave + (t & ~3)) * 1024), 16, ilane, ioff + (t & ~3) * 1024, (t & 3) * 1024, 0);
     };
 
     for (int i = tid; i < D; i += 256) {
@@ -149,6 +152,14 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     int tile = __builtin_amdgcn_readfirstlane(tile_s[0]);
     if (HIPT_STAMPS_ON(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
 
+    if (p.stagger > 0) {
+        // Start the workgroups in four groups a quarter of a tile time apart ((block / 8) & 3 mixes the groups inside every XCD):
+        // the row phases of a tile move 0.9 MB per CU and run at 24 GB/s per CU when all 256 CUs are in theirs, at 50-60 when a
+        // quarter of them is.  The tile queue evens the late starters out.
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)(((blockIdx.x >> 3) & 3) * p.stagger);
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
+    }
     const uint32_t lbase = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
     const uint32_t fbase = lbase + lane * 16;                                         // + slot * UNIT + fragment * 1024
     const uint32_t b1base = (uint32_t)(uintptr_t)(LDS_AS char*)b1s + 16 * h;          // b1[Hb + 32 U + 8 q + 4 h ..]: + (Hb + 32 U + 8 q) * 4
@@ -538,8 +549,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
 }  // namespace
 
 bool hipt_mlp32_supported(int dtype, int D_, int hidden) {
-    static const bool on = getenv("HIPT_MLP32") != nullptr;  // opt-in while it is being tuned (the default stays mlp_pipe.hip)
-    return on && dtype == HIPT_BF16 && D_ == 384 && hidden % 128 == 0 && hidden >= 256 && hidden <= 1536;
+    return dtype == HIPT_BF16 && D_ == 384 && hidden % 128 == 0 && hidden >= 256 && hidden <= 1536;
 }
 
 int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D_, int hidden, void* packed, hipStream_t st) {
@@ -589,7 +599,9 @@ int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     const int tail_rows = p.M - p.full_tiles * TMR;
     p.ntiles = p.full_tiles + (tail_rows > 0 ? (tail_rows + 15) / 16 : 0);
     const int grid = p.ntiles < ncu ? p.ntiles : ncu;
-    p.stagger = 0;
+    static const char* stag_env = getenv("HIPT_MLP_STAGGER_US");
+    const int stag_us = stag_env ? atoi(stag_env) : 0;
+    p.stagger = (p.full_tiles >= 6 * ncu) ? stag_us * 100 : 0;
     if (hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
         hipt_set_error("mlp32: hipMemsetAsync(counter) failed");
         return HIPT_E_LAUNCH;

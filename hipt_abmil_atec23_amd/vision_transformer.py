@@ -90,8 +90,12 @@ class _PackedVit:
             nbytes = lib.hipt_vit_packed_bytes(C.byref(self.w), what)
             if not nbytes:
                 continue
+            # (the library has several fused-MLP kernels, each with its own image order: the format travels with the image)
+            fmt = lib.hipt_vit_mlp_pack_format(C.byref(self.w)) if what == N.PACK_MLP else 0
             for i in range(depth):
                 img = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                if what == N.PACK_MLP:
+                    self.blocks[i].mlp_pk_fmt = fmt  # (read by hipt_vit_pack_weights' twin at launch time, set before either)
                 N.call("hipt_vit_pack_weights", C.byref(self.w), i, what, N.ptr(img), N.stream_ptr(dev))
                 self.keep.append(img)
                 setattr(self.blocks[i], field, img.data_ptr())

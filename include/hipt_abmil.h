@@ -73,11 +73,14 @@ typedef struct hipt_block_weights {
      * one run of consecutive bytes instead of eight 128-byte row segments (2.4x the L2->LDS rate on MI355X).  They
      * are a cache of qkv_w / proj_w / fc1_w+fc2_w: re-pack after the weights change. */
     const void*  qkv_pk;  const void* proj_pk;  const void* mlp_pk;
+    /* Which fused-MLP kernel mlp_pk was packed for: the value hipt_vit_mlp_pack_format returned when it was packed (the
+     * library has more than one fused-MLP kernel, each with its own image order; an image is only valid with its format). */
+    int32_t      mlp_pk_fmt;  int32_t reserved;
 } hipt_block_weights;
 
 #define HIPT_PACK_QKV  0
 #define HIPT_PACK_PROJ 1
-#define HIPT_PACK_MLP  2   /* fc1 and fc2 in one image */
+#define HIPT_PACK_MLP  2   /* fc1 and fc2 in one image, in the format hipt_vit_mlp_pack_format names */
 
 /* One ViT (ViT-256 `vit_small` or ViT-4K `vit4k_xs`, or any width the classes are built with).
  * `pos` is the ALREADY INTERPOLATED positional table for this token grid
@@ -152,9 +155,15 @@ size_t hipt_vit_workspace_bytes(const hipt_vit_weights* w, int nseq);
 
 /* Pre-packed weight images (hipt_block_weights.*_pk).  hipt_vit_packed_bytes: size of the image of matrix `what`
  * (HIPT_PACK_*) of one block, 0 when this dtype / shape has no packed form (then leave the pointer NULL).
- * hipt_vit_pack_weights: write the image of block `block` into `out` (device memory of that size) from w->blocks[block].
+ * hipt_vit_pack_weights: write the image of block `block` into `out` (device memory of that size) from w->blocks[block]
+ * (HIPT_PACK_MLP: in the format w->blocks[block].mlp_pk_fmt names -- set it first, from hipt_vit_mlp_pack_format).
  * Done once per set of weights by the module that owns them (vision_transformer.py:_PackedVit here). */
 size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what);
+/* The fused-MLP image format hipt_vit_pack_weights(.., HIPT_PACK_MLP, ..) writes for this model, to be stored in
+ * hipt_block_weights.mlp_pk_fmt beside the pointer: 1 = the 32x32x16-MFMA kernel (default), 0 = the 16x16x32-MFMA kernel
+ * (HIPT_NO_MLP32 in the environment, or a shape the other one does not take), 2 = the wave-specialised kernel (HIPT_MLP_WS,
+ * experimental).  The environment is read on every call; a packed image keeps the format it was made with. */
+int hipt_vit_mlp_pack_format(const hipt_vit_weights* w);
 int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* out, void* stream);
 /* Scratch of the whole-forward calls below (residual stream + block scratch + bf16 input copy). */
 size_t hipt_vit256_forward_workspace_bytes(const hipt_vit_weights* w, const hipt_image_layout* lay,

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void k(const char* src, int iters, unsigned
 //                10 DMA goes AFTER the valu work instead of before it, 11 s_nop 7 after the DMA, 12 pk_fma instead of fma
 constexpr uint32_t F(int n) { return n; }
 constexpr uint32_t T(int n) { return n << 4; }
-constexpr uint32_t R = 1 << 8, Dm = 1 << 9, DL = 1 << 10, NOP = 1 << 11, PK = 1 << 12;
+constexpr uint32_t R = 1 << 8, Dm = 1 << 9, DL = 1 << 10, NOP = 1 << 11, PK = 1 << 12, IMM = 1 << 13;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <uint32_t G0, uint32_t G1, uint32_t G2, uint32_t G3, int NT = 256>
@@ -163,11 +163,18 @@ __global__ __launch_bounds__(NT, 1) void k2(const char* src, int iters, unsigned
         ioff = ioff + 4096 >= 2359296 ? 0 : ioff + 4096;
         slot = (slot + 1) % 12;
     };
+    // the same piece stream with ONE LDS base (M0 written once per group) and the piece chosen by the instruction's immediate offset
+    auto dma_imm = [&](auto OFF_) __attribute__((always_inline)) {
+        constexpr int off = decltype(OFF_)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(smem + 96 * 1024 + (wave & 3) * 4096), 16, ilane, ioff, off, 0);
+    };
     auto gap = [&](auto S_, u32x4& dst, uint32_t ra, auto OFF_) __attribute__((always_inline)) {
         constexpr uint32_t S = decltype(S_)::value;
         constexpr int off = decltype(OFF_)::value;
         if constexpr (S & R) DSR(dst, ra, off);
-        if constexpr ((S & Dm) && !(S & DL)) {
+        if constexpr ((S & Dm) && (S & IMM)) {
+            dma_imm(OFF_);
+        } else if constexpr ((S & Dm) && !(S & DL)) {
             dma();
             if constexpr (S & NOP) asm volatile("s_nop 7");
         }
@@ -293,6 +300,11 @@ int main() {
     RUN2("r 4F | x4", R | F(4), R | F(4), R | F(4), R | F(4));
     RUN2("r 3F | x4", R | F(3), R | F(3), R | F(3), R | F(3));
     RUN2("D only in gap 0", Dm, 0, 0, 0);
+    RUN2("D (imm offset, fixed M0) only in gap 0", Dm | IMM, 0, 0, 0);
+    RUN2("D in every gap", Dm, Dm, Dm, Dm);
+    RUN2("D (imm offset, fixed M0) in every gap", Dm | IMM, Dm | IMM, Dm | IMM, Dm | IMM);
+    RUN2("r D(imm) | r D(imm) | r | r", R | Dm | IMM, R | Dm | IMM, R, R);
+    RUN2("r D | r D | r | r", R | Dm, R | Dm, R, R);
     RUN2("D 3F | 3F | 3F | 3F", Dm | F(3), F(3), F(3), F(3));
     RUN2("r D 3F | r 3F | r 3F | r 3F", R | Dm | F(3), R | F(3), R | F(3), R | F(3));
 
@@ -306,5 +318,6 @@ int main() {
     RUN2W("r D | r 2T 3F | r 2T 3F | r 5F", R | Dm, R | T(2) | F(3), R | T(2) | F(3), R | F(5));
     RUN2W("r D 2T 4pk | r 2T 4pk | r D 2T 4pk | r 2T 4pk", R | Dm | T(2) | F(4) | PK, R | T(2) | F(4) | PK, R | Dm | T(2) | F(4) | PK, R | T(2) | F(4) | PK);
     RUN2W("r D | r D | r | r", R | Dm, R | Dm, R, R);
+    RUN2W("r D(imm) | r D(imm) | r | r", R | Dm | IMM, R | Dm | IMM, R, R);
     return 0;
 }

@@ -12,6 +12,10 @@
 bool hipt_mlp_pipe_supported(int, int, int) { return false; }
 int hipt_mlp_pipe_launch(const MlpParams&, hipStream_t) { return -1; }
 #define LAUNCH(DBG, p) launch<6, DBG>(p, 0)
+#elif defined(PROBE_WS)  // the wave-specialised form (mlp_ws.hip); -DPROBE_WS
+#include "../hipt_abmil_atec23_amd/csrc/mlp_ws.hip"
+#define LAUNCH(DBG, p) hipt_mlp_ws_launch_dbg<DBG>(p, 0)
+#define hipt_mlp_pack_launch hipt_mlp_ws_pack_launch
 #elif defined(PROBE_32)  // the 32x32x16 form (mlp32.hip); -DPROBE_32
 #include "../hipt_abmil_atec23_amd/csrc/mlp32.hip"
 #define LAUNCH(DBG, p) hipt_mlp32_launch_dbg<DBG>(p, 0)
@@ -112,6 +116,9 @@ int main(int argc, char** argv) {
 #ifdef PROBE_32
         p.wpk_fmt = 1;
 #endif
+#ifdef PROBE_WS
+        p.wpk_fmt = 2;
+#endif
     }
 #endif
     if (getenv("PROBE_IMG") && !check) {  // as inside the pipeline: activation images + the next block's LayerNorm-1 output
@@ -181,7 +188,7 @@ int main(int argc, char** argv) {
     std::vector<int> masks;
     for (int i = 2; i < argc; ++i) masks.push_back(atoi(argv[i]));
     if (masks.empty()) masks = {0, 1, 2, 3, 4, 5, 6, 7};
-#ifdef PROBE_32
+#if defined(PROBE_32) || defined(PROBE_WS)
     masks.push_back(8);
     masks.push_back(12);
     masks.push_back(15);
@@ -195,10 +202,20 @@ int main(int argc, char** argv) {
             case 5: run<5>(p, iters); break;
             case 6: run<6>(p, iters); break;
             case 7: run<7>(p, iters); break;
-#ifdef PROBE_32
+#if defined(PROBE_32) || defined(PROBE_WS)
             case 8: run<8>(p, iters); break;
             case 12: run<12>(p, iters); break;
             case 15: run<15>(p, iters); break;
+#endif
+#ifdef PROBE_WS
+            case 16: run<16>(p, iters); break;
+            case 17: run<17>(p, iters); break;
+            case 18: run<18>(p, iters); break;
+            case 19: run<19>(p, iters); break;
+            case 20: run<20>(p, iters); break;
+            case 23: run<23>(p, iters); break;
+            case 24: run<24>(p, iters); break;
+            case 31: run<31>(p, iters); break;
 #endif
         }
     return 0;
