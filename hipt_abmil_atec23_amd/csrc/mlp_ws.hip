@@ -167,22 +167,29 @@ __global__ __launch_bounds__(512, 1) void mlp_ws_kernel(const MlpParams p) {
     const int h = lane >> 5, m = (lane >> 4) & 1;   // the MFMA view: lane = 32 h + 16 m + li holds row (fragment m, li), k half h
     const int ntile = p.hidden / 32, upt = 2 * ntile;
 
-    // ---- weight DMA: the F2 waves issue it (their streams have the issue slots to spare): wave pw pieces 6 pw .. 6 pw + 5 of a unit ----
+    // ---- weight DMA: every wave issues pieces 3 w .. 3 w + 2 of each unit ----
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, 2 * p.hidden * D * 2, 0x00020000);
-    const uint32_t ilane = (uint32_t)(6 * pw * 1024 + lane * 16);
+    const uint32_t ilane = (uint32_t)(3 * wave8 * 1024 + lane * 16);
     int ig_slot = 0, ig_off = 0;  // the unit being issued: ring slot, image offset
-    // Piece t (0..5) of the wave's six.  An LDS-DMA instruction takes its LDS base from M0, and WRITING M0 is what makes a piece
+    // Piece t (0..2) of the wave's three.  An LDS-DMA instruction takes its LDS base from M0, and WRITING M0 is what makes a piece
     // expensive (tools/issue_mix_probe.hip: +36 cycles per piece with a new M0, +2 with the same M0 and the piece selected by the
-    // instruction's immediate offset, which is added to the LDS and to the global address alike): pieces 0..3 share one M0, 4..5 another.
+    // instruction's immediate offset, which is added to the LDS and to the global address alike): a unit's three share one M0.
     auto dma_t = [&](auto T_) __attribute__((always_inline)) {
         constexpr int t = decltype(T_)::value;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(smem + ig_slot * UNIT + (6 * pw + (t & ~3)) * 1024), 16, ilane, ig_off + (t & ~3) * 1024, (t & 3) * 1024, 0);
-        if constexpr (t == 5) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(smem + ig_slot * UNIT + 3 * wave8 * 1024), 16, ilane, ig_off, t * 1024, 0);
+        if constexpr (t == 2) {
             ig_slot = ig_slot == NSLOT - 1 ? 0 : ig_slot + 1;
             ig_off = ig_off + UNIT == upt * UNIT ? 0 : ig_off + UNIT;
         }
     };
-    auto dma_unit = [&]() __attribute__((always_inline)) { sfor<0, 6>(dma_t); };
+    auto dma_unit = [&]() __attribute__((always_inline)) { sfor<0, 3>(dma_t); };
+    // the pieces of NU units (0, 1 or 2) spread over a step's 24 MFMA gaps: is gap s one, and which piece
+#define WS_DMA_IN_GAP(NU, s)                                                                 \
+    do {                                                                                     \
+        if constexpr ((NU) > 0 && !(DBG & 1)) {                                              \
+            if constexpr ((s) % (8 / (NU)) == 0) dma_t(std::integral_constant<int, ((s) / (8 / (NU))) % 3>{}); \
+        }                                                                                    \
+    } while (0)
 
     for (int i = tid; i < D; i += 512) {
         gam[i] = p.ln_w[i];
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void mlp_ws_kernel(const MlpParams p) {
     const uint32_t g1base = (uint32_t)(uintptr_t)(LDS_AS char*)gam1 + 16 * h;            // next LN-1 gamma (beta: + D * 4)
 
     // ---- prime the ring: the first NSLOT - 1 units of the stream (step 0 issues the one that fills it) ----
-    if (role == 1 && tile < p.ntiles) {
+    if (tile < p.ntiles) {
 #pragma unroll
         for (int i = 0; i < NSLOT - 1; ++i) dma_unit();
     }
@@ -323,8 +330,8 @@ __global__ __launch_bounds__(512, 1) void mlp_ws_kernel(const MlpParams p) {
     // ---- F1 step: MF: the 24 MFMAs of hidden tile kt into acc1[PAR]; GE: tile kt - 1 (acc1[PAR ^ 1]) leaves for F2 through
     // hbuf[PAR ^ 1]: accumulator registers 8..15 + bias as fp32 (F2 finishes them itself), registers 0..7 GELU'd here (4 units,
     // one stage every other MFMA gap) as the fc2 operand fragment of k-step 0.  slot = ring slot of W1(kt)
-    auto f1_step = [&](auto PAR_, auto MF_, auto GE_, int kt, int slot) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(PAR_)::value;
+    auto f1_step = [&](auto PAR_, auto MF_, auto GE_, auto NU_, int kt, int slot) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value, NU = decltype(NU_)::value;
         constexpr bool MF = decltype(MF_)::value != 0, GE = decltype(GE_)::value != 0;
         const uint32_t sa = fbase + slot * UNIT, hw = hbase + (PAR ^ 1) * HB_PAR;
         f32x4 bq[4];  // bias of tile kt - 1: bq[q][e] = b1[32 (kt-1) + 8 q + 4 h + e] = the lane's accumulator register 4 q + e
@@ -376,6 +383,7 @@ __global__ __launch_bounds__(512, 1) void mlp_ws_kernel(const MlpParams p) {
                     WS_RD(fn, sa, (s + 3) * 1024);
                 }
             }
+            WS_DMA_IN_GAP(NU, s);
             if constexpr (GE && s == 0) {
                 // hipcc reads acc1[PAR ^ 1] from the accumulator file wherever it likes AFTER this statement -- not before: it does
                 // not know that an MFMA (inside asm) wrote it at the end of the previous step and needs ~11 issue slots to land
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(512, 1) void mlp_ws_kernel(const MlpParams p) {
     // ---- F2 step: the fc2 MFMAs of one hidden tile.  From hbuf[PARH]: the operand fragment of k-step 0 and the fp32 accumulator
     // registers 8..15, which it GELUs itself (4 units, one stage per gap of the first twelve MFMAs) into the fragment of k-step 1;
     // MFMA i < 12: output tile i, k-step 0; i >= 12: output tile i - 12, k-step 1 (the W2 unit lists its fragments in that order).
-    // Weights from ring slot `slot`; issues the LDS-DMA pieces of NU units (6 per unit) in its MFMA gaps.  jt = hidden tile.
+    // Weights from ring slot `slot`; issues its LDS-DMA pieces of NU units (3 per unit and wave) in its MFMA gaps.  jt = hidden tile.
     auto f2_step = [&](auto PARH_, auto NU_, int jt, int slot) __attribute__((always_inline)) {
         constexpr int PARH = decltype(PARH_)::value, NU = decltype(NU_)::value;
         const uint32_t sa = fbase + slot * UNIT, ha = hbase + PARH * HB_PAR;
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(512, 1) void mlp_ws_kernel(const MlpParams p) {
                 u32x4& fn = wA[(s + 3) & 3];
                 WS_RD(fn, sa, (s + 3) * 1024);
             }
-            if constexpr (s % (4 / NU) == 0 && !(DBG & 1)) dma_t(std::integral_constant<int, (s / (4 / NU)) % 6>{});
+            WS_DMA_IN_GAP(NU, s);
             if constexpr (s < 12) {
                 constexpr int u = s / 3, st = s % 3;  // unit u: accumulator registers 8 + 2 u, 9 + 2 u
                 if constexpr (DBG & 2) {
@@ -588,8 +596,8 @@ __global__ __launch_bounds__(512, 1) void mlp_ws_kernel(const MlpParams p) {
 
     int gfirst = 0;  // ring slot of the first unit of the current step
     unsigned long long barw = 0, vmw = 0, tstart = __builtin_amdgcn_s_memtime();  // (debug stamps: cycles spent in the step barriers / DMA waits)
-    // A step ends with the workgroup's barrier; the ring advances by the n units the step consumed.  F2 first waits until its pieces
-    // of the NEXT step's units have landed: all but the 6 newest, which belong to the step after.
+    // A step ends with the workgroup's barrier; the ring advances by the n units the step consumed.  Every wave first waits until its pieces
+    // of the NEXT step's units have landed: all but the 3 newest, which belong to the step after.
     // The two roles run their own tile loops (so that hipcc sees each role's registers live only in its own loop); both execute the
     // same number of barriers per tile: ntile + 2.
     auto ring = [&](int o) __attribute__((always_inline)) { return gfirst + o >= NSLOT ? gfirst + o - NSLOT : gfirst + o; };
@@ -612,6 +620,7 @@ __global__ __launch_bounds__(512, 1) void mlp_ws_kernel(const MlpParams p) {
     } while (0)
 #define WS_END_F1(n)                     \
     do {                                 \
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); \
         WS_BAR();    \
         WS_ADVANCE(n);                   \
     } while (0)
@@ -619,10 +628,10 @@ __global__ __launch_bounds__(512, 1) void mlp_ws_kernel(const MlpParams p) {
     do {                                                      \
         if (HIPT_STAMPS_ON(p.stamps)) {                       \
             const unsigned long long tv0 = __builtin_amdgcn_s_memtime(); \
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); \
             vmw += __builtin_amdgcn_s_memtime() - tv0;        \
         } else {                                              \
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); \
         }                                                     \
         WS_BAR();                         \
         WS_ADVANCE(n);                                        \
@@ -642,28 +651,29 @@ __global__ __launch_bounds__(512, 1) void mlp_ws_kernel(const MlpParams p) {
                 const int nt = atomicAdd(p.counter, 1);
                 asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt) : "memory");
             }
-            f1_step(I0{}, I1{}, I0{}, 0, gfirst);  // steps 0, 1: fc1 tiles 0, 1 (F2 only feeds the ring)
+            f1_step(I0{}, I1{}, I0{}, I1{}, 0, gfirst);  // steps 0, 1: fc1 tiles 0, 1 (F2 only feeds the ring)
             WS_END_F1(1);
-            f1_step(I1{}, I1{}, I1{}, 1, gfirst);
+            f1_step(I1{}, I1{}, I1{}, I1{}, 1, gfirst);
             WS_END_F1(1);
-            f1_step(I0{}, I1{}, I1{}, 2, gfirst);
+            f1_step(I0{}, I1{}, I1{}, I1{}, 2, gfirst);
             WS_END_F1(2);
             PSTAMP(2);
             for (int kk = 3; kk + 1 < ntile; kk += 2) {
-                f1_step(I1{}, I1{}, I1{}, kk, gfirst);
+                f1_step(I1{}, I1{}, I1{}, I2{}, kk, gfirst);
                 WS_END_F1(2);
-                f1_step(I0{}, I1{}, I1{}, kk + 1, gfirst);
+                f1_step(I0{}, I1{}, I1{}, I2{}, kk + 1, gfirst);
                 WS_END_F1(2);
             }
-            f1_step(I1{}, I1{}, I1{}, ntile - 1, gfirst);
+            f1_step(I1{}, I1{}, I1{}, I2{}, ntile - 1, gfirst);
             WS_END_F1(2);
-            f1_step(I0{}, I0{}, I1{}, ntile, gfirst);  // step ntile: GELU of the last fc1 tile
+            f1_step(I0{}, I0{}, I1{}, I2{}, ntile, gfirst);  // step ntile: GELU of the last fc1 tile
             WS_END_F1(1);
             PSTAMP(3);
             // step ntile + 1: the next tile's row phase (beside F2's last step + row phase of this tile)
             int nt;
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nt) : "v"(tsbase + 4 * ((seq + 1) & 1)) : "memory");
             tile = __builtin_amdgcn_readfirstlane(nt);
+            if constexpr (!(DBG & 1)) dma_unit();
             if (tile < p.ntiles) {
                 tile_rows(tile, row0, nrows);
                 if constexpr (!(DBG & 16)) prologue(row0, nrows);
