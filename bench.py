@@ -113,7 +113,7 @@ def kernel_flops(cat, rows, D=384, H=1536, heads=6, ntok=257):
 
 
 # rocprofv3 kernel names of the categories, most specific first (keys of profiles/<tag>_traffic.json)
-TRAFFIC_KEYS = {"mlp_fused": ["void mlp_pipe_kernel<0, true, true, true>", "void mlp_pipe_kernel<0, true, false, false>", "void mlp_pipe_kernel<0>"],
+TRAFFIC_KEYS = {"mlp_fused": ["void mlp32_kernel<true, true, 0>", "void mlp_pipe_kernel<0, true, true, true>", "void mlp_pipe_kernel<0, true, false, false>", "void mlp_pipe_kernel<0>"],
                 "qkv_gemm": ["void seqgemm_pipe_kernel<false, 0, true, true, false, true>", "void seqgemm_pipe_kernel<true, 0, true, false, false, false>",
                              "void seqgemm_pipe_kernel<true, 0>"],
                 "proj_gemm": ["void seqgemm_pipe_kernel<false, 0, true, true, true, false>", "void seqgemm_pipe_kernel<false, 0, true, false, false, false>",
