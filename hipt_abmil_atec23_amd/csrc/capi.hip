@@ -297,6 +297,37 @@ int embed256(const hipt_vit_weights* w, const void* img, const hipt_image_layout
     return HIPT_OK;
 }
 
+// may the embedding read fp32 pixels itself (embed32.hip)?  `slot` bytes are available for its packed weight + tile queue
+static bool embed_fused_ok(const hipt_vit_weights* w, const void* images, const hipt_image_layout* lay, size_t slot) {
+    return lay->patch_w % 16 == 0 && lay->patch_h % 16 == 0 &&
+           hipt_embed32_supported(w->dtype, w->dim, w->embed_k, lay->patch_h / 16, lay->patch_w / 16) &&
+           w->ntok == (lay->patch_h / 16) * (lay->patch_w / 16) + 1 && slot >= hipt_embed32_packed_bytes() + 256 && ((uintptr_t)images % 16) == 0 &&
+           lay->row_stride % 4 == 0 && lay->chan_stride % 4 == 0 && lay->batch_stride % 4 == 0;
+}
+
+// the same from the fp32 image itself (embed32.hip): `wpk` = the packed Conv2d weight, `counter` = the kernel's tile queue
+int embed256_f32(const hipt_vit_weights* w, const float* img, const hipt_image_layout* lay, int seq0, int nseq, float* x, const void* wpk,
+                 int* counter, hipStream_t st) {
+    EmbedParams p;
+    memset(&p, 0, sizeof(p));
+    p.img = img;
+    p.im = *lay;
+    p.nty = lay->patch_h / 16;
+    p.ntx = lay->patch_w / 16;
+    p.seq0 = seq0;
+    p.nseq = nseq;
+    p.wpk = wpk;
+    p.bias = w->embed_b;
+    p.pos = w->pos;
+    p.x = x;
+    p.ntok = w->ntok;
+    p.counter = counter;
+    int rc;
+    PROF(PC_EMBED, hipt_embed32_launch(p, st));
+    PROF(PC_OTHER, hipt_cls_init_launch(x, w->cls, w->pos, nseq, w->ntok, w->dim, st));
+    return HIPT_OK;
+}
+
 int embed4k(const hipt_vit_weights* w, const void* tokens, int nseq, float* x, hipStream_t st) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
@@ -413,6 +444,10 @@ int hipt_vit256_prepare_tokens(const hipt_vit_weights* w, const float* images, c
         if (ws_bytes < al256((size_t)n * 2) || ((uintptr_t)workspace & 255)) {
             hipt_set_error("vit256_prepare_tokens: workspace %zu B too small / unaligned (need %zu)", ws_bytes, al256((size_t)n * 2));
             return HIPT_E_WORKSPACE;
+        }
+        if (embed_fused_ok(w, images, lay, ws_bytes)) {
+            if ((rc = hipt_embed32_pack_launch(w->embed_w, workspace, S(stream)))) return rc;
+            return embed256_f32(w, images, lay, seq0, nseq, x, workspace, (int*)((char*)workspace + hipt_embed32_packed_bytes()), S(stream));
         }
         if ((rc = hipt_f32_to_bf16_launch(images, workspace, n, S(stream)))) return rc;
         img = workspace;
@@ -556,8 +591,9 @@ static size_t image_extra_bytes(const hipt_vit_weights* w, const hipt_image_layo
 
 // ViT-256 over the sequences [seq0, seq0 + nseq) of an image tensor that is ALREADY in the compute dtype, chunk by chunk:
 // out[i] = [CLS] feature of sequence seq0 + i.  Scratch: the residual stream of one chunk + its block scratch.
+// (embed_pk != null: `img` is the fp32 image and the embedding reads it directly -- embed32.hip; the tile queue sits behind the image)
 static int vit256_range_impl(const hipt_vit_weights* w, const void* img, const hipt_image_layout* lay, int seq0, int nseq, int chunk, float* out,
-                             void* workspace, size_t ws_bytes, hipStream_t st) {
+                             void* workspace, size_t ws_bytes, hipStream_t st, const void* embed_pk = nullptr) {
     int rc;
     if (chunk <= 0) chunk = default_chunk(nseq);
     if (chunk > nseq) chunk = nseq;
@@ -570,7 +606,11 @@ static int vit256_range_impl(const hipt_vit_weights* w, const void* img, const h
     }
     for (int s0 = 0; s0 < nseq; s0 += chunk) {
         const int n = nseq - s0 < chunk ? nseq - s0 : chunk;
-        if ((rc = embed256(w, img, lay, seq0 + s0, n, x, st))) return rc;
+        if (embed_pk) {
+            if ((rc = embed256_f32(w, (const float*)img, lay, seq0 + s0, n, x, embed_pk, (int*)((char*)embed_pk + hipt_embed32_packed_bytes()), st))) return rc;
+        } else if ((rc = embed256(w, img, lay, seq0 + s0, n, x, st))) {
+            return rc;
+        }
         if (can_prune_last(w)) {
             float* xc = (float*)((char*)s.hid + 4096);  // (the hidden-tensor slot is free on this path; its head holds tile queues)
             bool have_xn = false, x_img = false;  // (x is this function's own buffer: it may come back as an activation image)
@@ -628,6 +668,13 @@ static int vit256_forward_impl(const hipt_vit_weights* w, const void* images, in
         return HIPT_E_WORKSPACE;
     }
     const void* img = images;
+    // fp32 pixels, bf16 model, 256 x 256 patches: the embedding kernel reads the image itself; the slot of the bf16 copy holds its
+    // packed weight (made here: 0.6 MB, a few microseconds) and its tile queue instead
+    if (kind == IMG_F32 && embed_fused_ok(w, images, lay, nimg)) {
+        void* pk = (char*)workspace + nrange;
+        if ((rc = hipt_embed32_pack_launch(w->embed_w, pk, st))) return rc;
+        return vit256_range_impl(w, images, lay, 0, nseq, chunk, out, workspace, nrange, st, pk);
+    }
     if ((rc = image_to_compute(w, images, kind, lay, nseq, (char*)workspace + nrange, &img, st))) return rc;
     return vit256_range_impl(w, img, lay, 0, nseq, chunk, out, workspace, nrange, st);
 }

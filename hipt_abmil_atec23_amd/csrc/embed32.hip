@@ -1,0 +1,299 @@
+// PATCH EMBEDDING of ViT-256 straight from the fp32 image:   x[s, 1 + t, :] = W . pixels(s, t) + b + pos[1 + t]
+//   (PatchEmbed.forward = Conv2d(3, 384, k = 16, s = 16) + flatten, HIPT_4K/vision_transformer.py:155-170, fused with the
+//   unfold / rearrange patchify of hipt_4k.py:64-65 through hipt_image_layout and with `x + pos` of prepare_tokens :235-246.)
+//
+// Round 1 made a bf16 copy of the image (f32_to_bf16: 2.4 GB read + written per 8 regions) and ran the generic LDS-tiled GEMM
+// over an im2col view of it, whose 16-pixel runs are 32-byte pieces: 6.2 ms per 24-region step, 7 % of it.  Here a workgroup owns
+// 128 tokens -- 8 token rows of one 256 x 256 patch, i.e. 128 image rows x 256 contiguous pixels per channel -- and works like the
+// fc2 half of mlp32.hip:
+//   * a wave's 32 tokens (2 token rows x 16) are ONE MFMA B operand: lane l = 32 h + 16 m + li is token (row m, column li) and holds,
+//     for k-step (channel c, pixel row r), the 8 pixels 8 h .. 8 h + 7 of that row -- two 16-byte fp32 loads, rounded to bf16 in
+//     registers.  A load instruction covers whole 64-byte lines; the image is read once, as fp32.
+//   * the weight [384, 768] streams through the 3 x 48 KiB LDS-DMA ring as A operand fragments (32 outputs x 16 k = 1 KiB,
+//     conflict-free by construction), 12 units per tile pass = 3 channels x 4; the [32 tokens x 384] accumulator (192 registers)
+//     takes all of them;
+//   * the pixels of a channel are fetched two channels ahead, a quarter (4 pixel rows) per phase, into one of three operand
+//     buffers (3 x 64 registers), across tile boundaries.  vmcnt is ONE in-order counter for these loads and the DMA pieces:
+//     a phase requests its quarter AFTER its last DMA piece (group 5) and waits with vmcnt(8) at its end -- the pieces have
+//     landed, the eight pixel loads may still be in flight; they are rounded to bf16 in the middle of the NEXT phase.
+//   * epilogue: + bias + pos, fp32 rows 1 + t of the sequence (row 0, the [CLS] slot, is written by cls_init).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "common.h"
+#include "kernels.h"
+#include "pipe_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int D = 384, NOT = 12, NCHN = 3, KPC = 256;  // KPC: k per channel = 16 pixel rows x 16 pixels
+constexpr int UNIT = 48 * 1024, UPT = 12;                          // ring unit = one phase = 48 fragments; units per tile pass
+
+__device__ __forceinline__ void mma32(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+// The packed image: unit pos = 4 c + u (channel c, u = 0..3), fragment f = 4 gg + t of group gg (0..11): output tile O = 3 u + gg / 4,
+// k-step r = 4 (gg % 4) + t (pixel row of the channel); lane (j = l & 31, h = l >> 5): W[32 O + j][256 c + 16 r + 8 h + (0..7)].
+__global__ void embed32_pack_kernel(const bf16_t* __restrict__ w, u32x4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte lane chunk
+    if (i >= UPT * (UNIT / 16)) return;
+    const int pos = i / (UNIT / 16), o = i % (UNIT / 16), frag = o >> 6, lane = o & 63, j = lane & 31, h = lane >> 5;
+    const int c = pos >> 2, u = pos & 3, gg = frag >> 2, t = frag & 3, O = 3 * u + (gg >> 2), r = 4 * (gg & 3) + t;
+    out[i] = *(const u32x4*)(w + (int64_t)(32 * O + j) * (NCHN * KPC) + KPC * c + 16 * r + 8 * h);
+}
+
+__global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bs = (float*)(smem + 3 * UNIT);  // bias [D]
+    int* tile_s = (int*)(bs + D);           // [2] tile handed to this workgroup, double-buffered by parity
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, h = lane >> 5, m = (lane >> 4) & 1;  // lane = 32 h + 16 m + li: token (row m, column li), k half h
+    const int tps = p.nty / 8;                                     // tiles per sequence
+
+    // ---- weight DMA: unit pos of the image = 48 pieces of 1 KiB; wave w issues pieces 12 w .. 12 w + 11, four per M0 value ----
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, UPT * UNIT, 0x00020000);
+    const uint32_t ilane = (uint32_t)(12 * wave * 1024 + lane * 16);
+    int ioff = 0, islot = 0, ipos = 0;
+    auto set_issue = [&](int pos, int slot) {
+        ioff = pos * UNIT;
+        islot = slot;
+    };
+    auto dma_piece = [&](auto T_) __attribute__((always_inline)) {
+        constexpr int t = decltype(T_)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(smem + islot * UNIT + (12 * wave + (t & ~3)) * 1024), 16, ilane, ioff + (t & ~3) * 1024, (t & 3) * 1024, 0);
+    };
+
+    for (int i = tid; i < D; i += 256) bs[i] = p.bias[i];
+    if (tid == 0) tile_s[0] = atomicAdd(p.counter, 1);
+    __syncthreads();
+    int tile = __builtin_amdgcn_readfirstlane(tile_s[0]);
+
+    const uint32_t lbase = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
+    const uint32_t fbase = lbase + lane * 16;                                       // + slot * UNIT + fragment * 1024
+    const uint32_t bbase = (uint32_t)(uintptr_t)(LDS_AS char*)bs + 16 * h;          // bias[32 O + 8 q + 4 h ..]: + (32 O + 8 q) * 4
+    const uint32_t tsbase = (uint32_t)(uintptr_t)(LDS_AS char*)tile_s;
+
+    // this lane's pixel row 0, columns 8 h .. of channel 0 for tile t (hipt_image_layout: include/hipt_abmil.h)
+    auto pix_base = [&](int t) __attribute__((always_inline)) {
+        const int b = p.seq0 + t / tps, ty = (t % tps) * 8 + 2 * wave + m;
+        const int gsz = p.im.grid_w * p.im.grid_h, bi = b / gsz, s = b % gsz, p1 = s / p.im.grid_h, p2 = s % p.im.grid_h;
+        return p.img + (int64_t)bi * p.im.batch_stride + (int64_t)(p1 * p.im.patch_h + ty * 16) * p.im.row_stride + p2 * p.im.patch_w + li * 16 + 8 * h;
+    };
+
+    u32x4 X[NCHN][16];  // operand fragments: channel c, k-step r (pixel row): the lane's 8 pixels as bf16
+    f32x4 raw[8];       // a quarter of a channel in flight: pixel rows 4 j .. 4 j + 3, two 16-byte pieces each
+    auto load_quarter = [&](const float* base, auto C_, auto J_) __attribute__((always_inline)) {
+        constexpr int c = decltype(C_)::value, j = decltype(J_)::value;
+        const float* q = base + (int64_t)c * p.im.chan_stride + (int64_t)(4 * j) * p.im.row_stride;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            raw[2 * t] = *(const f32x4*)(q + (int64_t)t * p.im.row_stride);
+            raw[2 * t + 1] = *(const f32x4*)(q + (int64_t)t * p.im.row_stride + 4);
+        }
+    };
+    auto cvt_quarter = [&](auto C_, auto J_) __attribute__((always_inline)) {
+        constexpr int c = decltype(C_)::value, j = decltype(J_)::value;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            u32x4 o;
+            o[0] = pack_bf16x2(raw[2 * t][0], raw[2 * t][1]);
+            o[1] = pack_bf16x2(raw[2 * t][2], raw[2 * t][3]);
+            o[2] = pack_bf16x2(raw[2 * t + 1][0], raw[2 * t + 1][1]);
+            o[3] = pack_bf16x2(raw[2 * t + 1][2], raw[2 * t + 1][3]);
+            X[c][4 * j + t] = o;
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 3> I3;
+
+    // ---- prime: ring units 0 and 1; channels 0 and 1 of the first tile (the only pixels this workgroup ever waits for) ----
+    int cons = 0;  // units consumed since kernel start (slot = cons % 3)
+    const float* base_cur = p.img;
+    if (tile < p.ntiles) {
+        set_issue(0, 0);
+        sfor<0, 12>(dma_piece);
+        set_issue(1, 1);
+        sfor<0, 2>(dma_piece);
+        ipos = 2;
+        base_cur = pix_base(tile);
+        sfor<0, 2>([&](auto C_) __attribute__((always_inline)) {
+            sfor<0, 4>([&](auto J_) __attribute__((always_inline)) {
+                load_quarter(base_cur, C_, J_);
+                cvt_quarter(C_, J_);
+            });
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    u32x4 wA[2][4];
+    auto rd_frag = [&](auto SET_, auto G_, uint32_t sa) __attribute__((always_inline)) {
+        constexpr int set = decltype(SET_)::value, gg = decltype(G_)::value;
+        const uint32_t a = sa;
+        u32x4 &d0 = wA[set][0], &d1 = wA[set][1], &d2 = wA[set][2], &d3 = wA[set][3];
+        DSR128(d0, a, (4 * gg + 0) * 1024);
+        DSR128(d1, a, (4 * gg + 1) * 1024);
+        DSR128(d2, a, (4 * gg + 2) * 1024);
+        DSR128(d3, a, (4 * gg + 3) * 1024);
+    };
+
+    for (int seq = 0; tile < p.ntiles; ++seq) {
+        if (tid == 0) {  // next tile: fetched now, read after the first ring barrier
+            const int nt = atomicAdd(p.counter, 1);
+            asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt) : "memory");
+        }
+        f32x16 acc[NOT];  // lane holds its token's output columns 32 O + 8 (reg >> 2) + 4 h + (reg & 3)
+#pragma unroll
+        for (int o = 0; o < NOT; ++o)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[o][e] = 0.f;
+        const float* base_next = base_cur;
+        int next = p.ntiles;
+
+        // ---- one phase: 12 groups of 4 MFMAs on the unit in slot cons % 3: channel C, unit U of it ----
+        // LAST: last phase of the tile, nothing is prefetched across the row phase (the compiler moves registers there)
+        auto phase = [&](auto C_, auto U_, auto LAST_, auto&& mid) __attribute__((always_inline)) {
+            constexpr int c = decltype(C_)::value, u = decltype(U_)::value, last = decltype(LAST_)::value;
+            const uint32_t sa = fbase + (cons % 3) * UNIT;
+            const uint32_t sn = fbase + ((cons + 1) % 3) * UNIT;
+            sfor<0, 12>([&](auto G_) __attribute__((always_inline)) {
+                constexpr int gg = decltype(G_)::value, set = gg & 1;
+                typedef std::integral_constant<int, set ^ 1> NS;
+                if constexpr (gg == 11) {
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // my pieces of the next unit have landed (the 8 pixel loads after them may not)
+                    __builtin_amdgcn_s_barrier();                     // ... everyone's; unit cons-1 is no longer read
+                    set_issue(ipos, (cons + 2) % 3);
+                    ipos = ipos + 1 == UPT ? 0 : ipos + 1;
+                    if constexpr (last) {
+                        LGKM(0);
+                    } else {
+                        rd_frag(NS{}, I0{}, sn);
+                        LGKM(4);
+                    }
+                } else {
+                    rd_frag(NS{}, std::integral_constant<int, gg + 1>{}, sa);
+                    LGKM(4);
+                }
+                constexpr int O = 3 * u + (gg >> 2), kq = gg & 3;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) mma32(acc[O], wA[set][t], X[c][4 * kq + t]);
+                if constexpr (gg == 11) {
+                    dma_piece(std::integral_constant<int, 0>{});
+                    dma_piece(std::integral_constant<int, 1>{});
+                } else if constexpr (gg <= 4) {
+                    dma_piece(std::integral_constant<int, 2 + 2 * gg>{});
+                    dma_piece(std::integral_constant<int, 3 + 2 * gg>{});
+                } else if constexpr (gg == 5) {
+                    mid();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            cons += 1;
+        };
+
+        rd_frag(I0{}, I0{}, fbase + (cons % 3) * UNIT);
+        // Phase (c, j), after its last DMA piece: round the quarter requested in the PREVIOUS phase, then request quarter j of the
+        // channel two ahead (tc: channel 2 of this tile for c = 0, channel 0 / 1 of the next tile for c = 1 / 2).
+        sfor<0, NCHN>([&](auto C_) __attribute__((always_inline)) {
+            constexpr int c = decltype(C_)::value, tc = (c + 2) % NCHN;
+            sfor<0, 4>([&](auto J_) __attribute__((always_inline)) {
+                constexpr int j = decltype(J_)::value;
+                if constexpr (c == 1 && j == 0) {
+                    int nt;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nt) : "v"(tsbase + 4 * ((seq + 1) & 1)) : "memory");
+                    next = __builtin_amdgcn_readfirstlane(nt);
+                    if (next < p.ntiles) base_next = pix_base(next);  // (no next tile: the current tile's pixels again, never used)
+                }
+                phase(C_, J_, std::integral_constant<int, (c == NCHN - 1 && j == 3) ? 1 : 0>{}, [&]() __attribute__((always_inline)) {
+                    if (seq > 0 || c > 0 || j > 0) {  // (the very first phase of a workgroup has no quarter in flight)
+                        if constexpr (j > 0)
+                            cvt_quarter(std::integral_constant<int, tc>{}, std::integral_constant<int, (j > 0 ? j - 1 : 0)>{});
+                        else
+                            cvt_quarter(std::integral_constant<int, (c + 1) % NCHN>{}, I3{});
+                    }
+                    load_quarter(c == 0 ? base_cur : base_next, std::integral_constant<int, tc>{}, J_);
+                });
+            });
+        });
+
+        // ---- epilogue: + bias + pos -> token rows of x.  acc[O][4 q + e] is output column 32 O + 8 q + 4 h + e of this lane's token ----
+        {
+            const int b = tile / tps, t = ((tile % tps) * 8 + 2 * wave + m) * p.ntx + li;
+            float* xr = p.x + ((int64_t)b * p.ntok + 1 + t) * D + 4 * h;
+            const float* pr = p.pos + (int64_t)(1 + t) * D + 4 * h;
+            sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
+                constexpr int O = decltype(O_)::value;
+                f32x4 pv[4], bb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pv[q] = *(const f32x4*)(pr + 32 * O + 8 * q);
+                const uint32_t ba = bbase;
+                f32x4 &r0_ = bb[0], &r1_ = bb[1], &r2_ = bb[2], &r3_ = bb[3];
+                DSR128X4_WAIT(r0_, r1_, r2_, r3_, ba, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (acc[O][4 * q + e] + bb[q][e]) + pv[q][e];
+                    *(f32x4*)(xr + 32 * O + 8 * q) = v;
+                }
+            });
+        }
+        tile = next;
+        base_cur = base_next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (continuous stream: pieces of a pass that never runs)
+}
+
+}  // namespace
+
+bool hipt_embed32_supported(int dtype, int D_, int K, int nty, int ntx) {
+    const bool off = getenv("HIPT_NO_EMBED32") != nullptr;  // (read per forward: the round-1 path = bf16 copy of the image + generic GEMM)
+    return !off && dtype == HIPT_BF16 && D_ == D && K == NCHN * KPC && ntx == 16 && nty > 0 && nty % 8 == 0;
+}
+
+size_t hipt_embed32_packed_bytes() { return (size_t)UPT * UNIT; }
+
+int hipt_embed32_pack_launch(const void* w, void* packed, hipStream_t st) {
+    const int chunks = UPT * (UNIT / 16);
+    hipLaunchKernelGGL(embed32_pack_kernel, dim3((chunks + 255) / 256), dim3(256), 0, st, (const bf16_t*)w, (u32x4*)packed);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}
+
+int hipt_embed32_launch(const EmbedParams& p_in, hipStream_t st) {
+    EmbedParams p = p_in;
+    HIPT_CHECK_ARG(p.img && p.wpk && p.bias && p.pos && p.x && p.counter && p.nseq > 0, "embed32: null/empty argument");
+    HIPT_CHECK_ARG(p.ntx == 16 && p.nty % 8 == 0 && p.ntok == p.nty * p.ntx + 1, "embed32: token grid %dx%d / %d tokens", p.nty, p.ntx, p.ntok);
+    HIPT_CHECK_ARG(((uintptr_t)p.img % 16) == 0 && p.im.row_stride % 4 == 0 && p.im.chan_stride % 4 == 0 && p.im.batch_stride % 4 == 0 && p.im.patch_w % 16 == 0,
+                   "embed32: 16-byte aligned pixel rows required");
+    const int lds = 3 * UNIT + D * 4 + 16;
+    static DevOnce once;
+    HIPT_CUR_DEVICE(dev);
+    if (!once.done[dev]) {
+        if (hipFuncSetAttribute((const void*)embed32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            hipt_set_error("hipFuncSetAttribute(embed32) failed");
+            return HIPT_E_LAUNCH;
+        }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            hipt_set_error("embed32: cannot query the device");
+            return HIPT_E_LAUNCH;
+        }
+        once.ncu[dev] = prop.multiProcessorCount;
+        once.done[dev] = true;
+    }
+    const int ncu = once.ncu[dev];
+    p.ntiles = p.nseq * (p.nty / 8);
+    const int grid = p.ntiles < ncu ? p.ntiles : ncu;
+    if (hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
+        hipt_set_error("embed32: hipMemsetAsync(counter) failed");
+        return HIPT_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(embed32_kernel, dim3(grid), dim3(256), lds, st, p);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}

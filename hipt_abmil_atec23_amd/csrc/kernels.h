@@ -29,6 +29,26 @@ struct GemmParams {
 
 int hipt_gemm_launch(const GemmParams& p, int dtype, int aload, int flags, hipStream_t st);
 
+// Patch embedding of ViT-256 straight from the fp32 image (embed32.hip): x[seq, 1 + t, :] = Conv2d_k16_s16(pixels) + bias + pos[1 + t]
+// for the 16 x 16 tokens of every 256 x 256 patch; bf16 MFMAs on pixels rounded to bf16 in registers (no bf16 copy of the image).
+struct EmbedParams {
+    const float* img;        // fp32 image tensor, addressed through `im` (include/hipt_abmil.h, hipt_image_layout)
+    hipt_image_layout im;
+    int nty, ntx;            // tokens per patch along dim2 / dim3 (ntx == 16, nty % 8 == 0)
+    int seq0, nseq;          // sequences (patches) [seq0, seq0 + nseq) of the tensor
+    const void* wpk;         // the Conv2d weight [D, 768] as the kernel's fragment image (hipt_embed32_pack_launch)
+    const float* bias;       // [D]
+    const float* pos;        // [ntok, D] (row 0 = [CLS])
+    float* x;                // [nseq, ntok, D] fp32; row 0 of every sequence is left alone
+    int ntok;
+    int* counter;            // device int the launcher zeroes on the stream: the kernel's tile queue
+    int ntiles;              // (set by the launcher)
+};
+bool hipt_embed32_supported(int dtype, int D, int K, int nty, int ntx);
+size_t hipt_embed32_packed_bytes();
+int hipt_embed32_pack_launch(const void* w, void* packed, hipStream_t st);
+int hipt_embed32_launch(const EmbedParams& p, hipStream_t st);
+
 // A-stationary GEMM (seqgemm.hip): one workgroup per sequence, activations in registers, optional fused LayerNorm
 // "Activation images" (pipelined D = 384 kernels, M % 16 == 0): a [M, 384] activation stored fragment by fragment in
 // the order the MFMA operand / accumulator layout wants it, so that every load / store instruction of a wave covers 1 KiB
@@ -44,7 +64,6 @@ struct SeqGemmParams {
     float ln_eps;
     const void* W;       // bf16 [N, K]
     const void* wpk;     // optional (pipelined kernel only): W pre-packed in ring order (hipt_seqgemm_pack_launch)
-    int wpk_fmt;         // format of wpk: 0 = mlp_pipe.hip's ring image, 1 = mlp32.hip's fragment image, 2 = mlp_ws.hip's step image
     int img;             // (pipelined kernel only) activation images: bit 0 = A (bf16, no LayerNorm), bit 1 = out (N = 384);
                          // bit 2 = out (N = 1152) head-major [sequence][q/k/v][head][token][64], out_ntok tokens per sequence
     int out_ntok;

@@ -403,6 +403,35 @@ def test_vit256_experimental_wave_specialised_mlp(vit256, monkeypatch):
     assert torch.equal(ws[1:4], ws_sub)
 
 
+def test_vit256_patch_embedding_from_fp32_pixels(vit256, monkeypatch):
+    """csrc/embed32.hip reads the fp32 image itself (pixels rounded to bf16 in registers, weights through the LDS-DMA ring); the
+    round-1 path (HIPT_NO_EMBED32=1) makes a bf16 copy of the image and runs the generic GEMM over an im2col view.  Same bf16
+    products, another summation order: the [CLS] features agree far inside the bf16 bar, also for a batch that is not a whole
+    region and for a sub-batch (bitwise: a token's result does not depend on its neighbours)."""
+    x = synth.hash_uniform_torch((7, 3, 256, 256), 31, device=DEV)
+    vit256.set_compute_dtype("bf16")
+    try:
+        fused = vit256(x)
+        fused_sub = vit256(x[2:5])
+        tok = vit256.prepare_tokens(x)
+        monkeypatch.setenv("HIPT_NO_EMBED32", "1")
+        plain = vit256(x)
+        tok_plain = vit256.prepare_tokens(x)
+    finally:
+        monkeypatch.delenv("HIPT_NO_EMBED32", raising=False)
+        vit256.set_compute_dtype("fp32")
+    rel = float((fused - plain).norm() / plain.norm())
+    # the tokens themselves against Conv2d on the bf16-rounded operands in fp64 (what both kernels compute, up to summation order)
+    w = vit256.patch_embed.proj.weight.detach().to(torch.bfloat16).double()
+    ref = torch.nn.functional.conv2d(x.to(torch.bfloat16).double(), w, vit256.patch_embed.proj.bias.detach().double(), stride=16)
+    ref = ref.flatten(2).transpose(1, 2) + vit256.interpolate_pos_encoding(tok, 256, 256)[:, 1:].double()
+    e_new, e_old = float((tok[:, 1:] - ref).abs().max()), float((tok_plain[:, 1:] - ref).abs().max())
+    print(f"fused patch embedding vs bf16-copy + GEMM: [CLS] features rel-L2 {rel:.2e}; tokens vs fp64 Conv2d: max |err| {e_new:.2e} (round-1 path {e_old:.2e})")
+    assert rel < 5e-3 and e_new < 1e-4 and e_old < 1e-4
+    assert torch.equal(tok[:, 0], tok_plain[:, 0])
+    assert torch.equal(fused[2:5], fused_sub)
+
+
 def test_vit256_activation_images_change_nothing(vit256, monkeypatch):
     """forward() keeps the residual stream, the attention-branch output and the pre-normalised QKV operands of blocks
     2..11 as fragment-blocked "activation images" (csrc/kernels.h) when the batch has whole 16-row fragments: a pure
