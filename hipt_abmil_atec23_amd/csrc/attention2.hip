@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const bf16_t* __restrict
     // this wave's tiles: wave, wave+4, ...; two at a time.  The first pair's Q rows are requested before the staging
     // wait; every later step's Q is requested right after the step before it has turned its Q into scores (the
     // registers are free then, and the softmax / PV that follow hide the latency).
-    int qt = wave;
+    // (257 tokens are 17 tiles: one wave of the four has five.  Which one rotates with the workgroup, so that the two workgroups
+    //  sharing a CU do not both load the same SIMD.)
+    int qt = (wave + blockIdx.x) & 3;
     u32x4 qf[2][2];
     if (qt < nqt) load_q(qbase, tokstride, ntok, qt, li, g, qf[0]);
     if (qt + 4 < nqt) load_q(qbase, tokstride, ntok, qt + 4, li, g, qf[1]);
