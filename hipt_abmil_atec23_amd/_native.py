@@ -92,6 +92,8 @@ SIGNATURES = {
     "hipt_image_to_compute": (_i, [_VW, _p, _i, _IL, _i, _p, _p]),
     "hipt_vit256_range_workspace_bytes": (_sz, [_VW, _i, _i]),
     "hipt_vit256_forward_range": (_i, [_VW, _p, _IL, _i, _i, _i, _p, _p, _sz, _p]),
+    "hipt_vit256_range_px_workspace_bytes": (_sz, [_VW, _IL, _i, _i]),
+    "hipt_vit256_forward_range_px": (_i, [_VW, _p, _IL, _i, _i, _i, _p, _p, _sz, _p]),
     "hipt_hipt4k_workspace_bytes": (_sz, [_VW, _VW, _i, _i, _i, _i]),
     "hipt_hipt4k_forward": (_i, [_VW, _VW, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "hipt_hipt4k_u8_workspace_bytes": (_sz, [_VW, _VW, _i, _i, _i, _i]),

@@ -710,6 +710,33 @@ int hipt_vit256_forward_range(const hipt_vit_weights* w, const void* images_cd, 
     return vit256_range_impl(w, images_cd, lay, seq0, nseq, chunk, out, workspace, ws_bytes, S(stream));
 }
 
+// the same over fp32 pixels where the embedding kernel reads them itself (embed32.hip): no image in the compute dtype is needed
+size_t hipt_vit256_range_px_workspace_bytes(const hipt_vit_weights* w, const hipt_image_layout* lay, int nseq, int chunk) {
+    if (!w || !lay || nseq <= 0 || lay->patch_h <= 0 || lay->patch_w <= 0) return 0;
+    const size_t slot = al256(hipt_embed32_packed_bytes() + 256);
+    // (the pointer's alignment is checked at the call; any non-null 16-byte aligned value stands in for it here)
+    return embed_fused_ok(w, (const void*)16, lay, slot) ? vit256_range_bytes(w, nseq, chunk) + slot : 0;
+}
+
+int hipt_vit256_forward_range_px(const hipt_vit_weights* w, const float* images, const hipt_image_layout* lay, int seq0, int nseq, int chunk,
+                                 float* out, void* workspace, size_t ws_bytes, void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(images && lay && out && nseq > 0 && seq0 >= 0, "vit256_forward_range_px: null/empty argument");
+    const size_t slot = al256(hipt_embed32_packed_bytes() + 256), nrange = vit256_range_bytes(w, nseq, chunk);
+    if (!embed_fused_ok(w, images, lay, slot)) {
+        hipt_set_error("vit256_forward_range_px: this model / layout has no pixel-reading embedding (hipt_vit256_range_px_workspace_bytes returns 0)");
+        return HIPT_E_UNSUPPORTED;
+    }
+    if (ws_bytes < nrange + slot || ((uintptr_t)workspace & 255)) {
+        hipt_set_error("vit256_forward_range_px: workspace %zu B too small / unaligned (need %zu)", ws_bytes, nrange + slot);
+        return HIPT_E_WORKSPACE;
+    }
+    void* pk = (char*)workspace + nrange;
+    if ((rc = hipt_embed32_pack_launch(w->embed_w, pk, S(stream)))) return rc;
+    return vit256_range_impl(w, images, lay, seq0, nseq, chunk, out, workspace, nrange, S(stream), pk);
+}
+
 int hipt_vit4k_forward(const hipt_vit_weights* w, const float* tokens_in, int nseq, float* out, void* workspace,
                        size_t ws_bytes, void* stream) {
     int rc = check_vit(w);

@@ -147,7 +147,9 @@ class HIPT_4K(torch.nn.Module):
         lay = N.ImageLayout(w_256, h_256, 256, 256, H, W * H, 3 * W * H)
         kind = (2 if hwc else 1) if u8 else 0
         cur = torch.cuda.current_stream(dev)
-        nb = N.lib().hipt_image_compute_bytes(pk256.ref, C.byref(lay), nseq, kind)
+        # fp32 pixels and a patch embedding that reads them itself (csrc/embed32.hip): no copy in the compute dtype
+        px = (not u8) and N.lib().hipt_vit256_range_px_workspace_bytes(pk256.ref, C.byref(lay), 16, self.chunk) > 0
+        nb = 0 if px else N.lib().hipt_image_compute_bytes(pk256.ref, C.byref(lay), nseq, kind)
         img = region
         if nb:
             img = Fn.workspace(dev, nb, ("img", cur.cuda_stream))
@@ -164,10 +166,13 @@ class HIPT_4K(torch.nn.Module):
                 continue
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                need = N.lib().hipt_vit256_range_workspace_bytes(pk256.ref, n, self.chunk)
+                if px:
+                    need = N.lib().hipt_vit256_range_px_workspace_bytes(pk256.ref, C.byref(lay), n, self.chunk)
+                else:
+                    need = N.lib().hipt_vit256_range_workspace_bytes(pk256.ref, n, self.chunk)
                 ws = Fn.workspace(dev, need, 1 + k)
-                N.call("hipt_vit256_forward_range", pk256.ref, N.ptr(img), C.byref(lay), lo, n, self.chunk, N.ptr(cls256[lo:lo + n]),
-                       N.ptr(ws), ws.numel(), N.stream_ptr(dev))
+                N.call("hipt_vit256_forward_range_px" if px else "hipt_vit256_forward_range", pk256.ref, N.ptr(img), C.byref(lay), lo, n,
+                       self.chunk, N.ptr(cls256[lo:lo + n]), N.ptr(ws), ws.numel(), N.stream_ptr(dev))
             for t in (region, cls256):
                 t.record_stream(st)
         for st in self._side_streams[key]:

@@ -218,6 +218,12 @@ int hipt_image_to_compute(const hipt_vit_weights* w, const void* images, int inp
 size_t hipt_vit256_range_workspace_bytes(const hipt_vit_weights* w, int nseq, int chunk);
 int hipt_vit256_forward_range(const hipt_vit_weights* w, const void* images_cd, const hipt_image_layout* lay,
                               int seq0, int nseq, int chunk, float* out, void* workspace, size_t ws_bytes, void* stream);
+/* The same straight from fp32 pixels, for models / layouts whose patch embedding reads them itself (bf16 ViT-256 on 256 x 256
+ * patches): no compute-dtype copy of the image.  hipt_vit256_range_px_workspace_bytes returns 0 where that is not available
+ * (then: hipt_image_to_compute + hipt_vit256_forward_range). */
+size_t hipt_vit256_range_px_workspace_bytes(const hipt_vit_weights* w, const hipt_image_layout* lay, int nseq, int chunk);
+int hipt_vit256_forward_range_px(const hipt_vit_weights* w, const float* images, const hipt_image_layout* lay, int seq0, int nseq,
+                                 int chunk, float* out, void* workspace, size_t ws_bytes, void* stream);
 
 /* Whole ViT-4K forward -> out[nseq, D] fp32. */
 int hipt_vit4k_forward(const hipt_vit_weights* w, const float* tokens_in, int nseq, float* out,
