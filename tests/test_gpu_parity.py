@@ -432,6 +432,23 @@ def test_vit256_patch_embedding_from_fp32_pixels(vit256, monkeypatch):
     assert torch.equal(fused[2:5], fused_sub)
 
 
+def test_hipt4k_patch_embedding_addresses_regions(hipt, monkeypatch):
+    """The pixel-reading patch embedding inside HIPT_4K: 256 x 256 patches addressed inside non-square regions (grid 2 x 3, batch of
+    two; one region per call takes the patch-range entry hipt_vit256_forward_range_px): the same bits as the round-1 path."""
+    x = synth.hash_uniform_torch((2, 3, 512, 768), 37, device=DEV)
+    hipt.set_compute_dtype("bf16")
+    try:
+        fused = hipt(x)
+        fused_one = hipt(x[1:2])
+        monkeypatch.setenv("HIPT_NO_EMBED32", "1")
+        plain = hipt(x)
+    finally:
+        monkeypatch.delenv("HIPT_NO_EMBED32", raising=False)
+        hipt.set_compute_dtype("fp32")
+    assert torch.equal(fused, plain)
+    assert torch.equal(fused[1:2], fused_one)
+
+
 def test_vit256_activation_images_change_nothing(vit256, monkeypatch):
     """forward() keeps the residual stream, the attention-branch output and the pre-normalised QKV operands of blocks
     2..11 as fragment-blocked "activation images" (csrc/kernels.h) when the batch has whole 16-row fragments: a pure
