@@ -180,13 +180,22 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             // (with activation images the attention output is one too: proj then reads its operands 1 KiB at a time)
             PROF(cATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st, img ? 1 : 0, hm ? 1 : 0));
             if (last_probs) break;
-            q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
-            q.counter = (int*)s.hid + 32;
-            q.img = img ? 3 : 0;  // A = the attention output image, out = y1 image
-            PROF(cPROJ, hipt_seqgemm_launch(q, false, 0, st));
+            // With activation images and the 32x32x16 MLP kernel's weight image (which carries the proj matrix too) the fused MLP can
+            // apply proj itself: no launch, no y1 round trip (HIPT_PROJ_FOLD=1).  Measured: break-even -- the six extra ring phases and
+            // the row phase that follows them cost a tile what the proj launch cost -- so it is not the default.
+            // (It reads the attention output from s.att and, with LayerNorm chaining, writes the next block's operands there: the
+            // same rows, read in a tile's first phase and written in its last.)
+            const bool fold = img && b.mlp_pk_fmt == 1 && hipt_mlp32_supported(dt, D, w->hidden) && getenv("HIPT_PROJ_FOLD") != nullptr;
+            if (!fold) {
+                q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
+                q.counter = (int*)s.hid + 32;
+                q.img = img ? 3 : 0;  // A = the attention output image, out = y1 image
+                PROF(cPROJ, hipt_seqgemm_launch(q, false, 0, st));
+            }
             MlpParams m;
             memset(&m, 0, sizeof(m));
-            m.x = x; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
+            m.x = x; m.y1 = fold ? s.att : s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
+            m.fold = fold ? 1 : 0; m.bproj = b.proj_b;
             m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.wpk_fmt = b.mlp_pk_fmt; m.M = M; m.D = D; m.hidden = w->hidden;
             m.counter = (int*)s.hid;
             have_xn = chain && (i + 1 < b1 || emit_last) && i + 1 < w->depth;
@@ -540,7 +549,8 @@ size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {
     switch (what) {
         case HIPT_PACK_QKV: return hipt_seqgemm_pipe_supported(w->dtype, D, 3 * D, false, 0) ? (size_t)3 * D * D * 2 : 0;
         case HIPT_PACK_PROJ: return hipt_seqgemm_pipe_supported(w->dtype, D, D, false, 0) ? (size_t)D * D * 2 : 0;
-        case HIPT_PACK_MLP: return hipt_mlp_pipe_supported(w->dtype, D, w->hidden) ? (size_t)2 * D * w->hidden * 2 : 0;
+        // (format 1 -- the 32x32x16 kernel -- carries the proj matrix behind fc1 / fc2: the kernel can apply it itself)
+        case HIPT_PACK_MLP: return hipt_mlp_pipe_supported(w->dtype, D, w->hidden) ? (size_t)2 * D * w->hidden * 2 + (hipt_vit_mlp_pack_format(w) == 1 ? (size_t)D * D * 2 : 0) : 0;
         default: return 0;
     }
 }
@@ -563,7 +573,7 @@ int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* 
         default:
             // the format the caller recorded beside the pointer (hipt_vit_mlp_pack_format): pack and launch read the same field
             if (b.mlp_pk_fmt == 2 && hipt_mlp_ws_supported(w->dtype, D, w->hidden)) return hipt_mlp_ws_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
-            if (b.mlp_pk_fmt == 1 && hipt_mlp32_supported(w->dtype, D, w->hidden)) return hipt_mlp32_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
+            if (b.mlp_pk_fmt == 1 && hipt_mlp32_supported(w->dtype, D, w->hidden)) return hipt_mlp32_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st, b.proj_w);
             if (b.mlp_pk_fmt != 0) {
                 hipt_set_error("hipt_vit_pack_weights: blocks[%d].mlp_pk_fmt = %d is not a format this model has", block, b.mlp_pk_fmt);
                 return HIPT_E_BADARG;

@@ -89,7 +89,9 @@ int hipt_seqgemm_pack_launch(const void* W, int N, int K, void* packed, hipStrea
 // Fused MLP sub-block (mlp.hip): x <- x + y1 + fc2(GELU(fc1(LN2(x + y1))))
 struct MlpParams {
     float* x;            // fp32 [M, D] residual stream, updated in place
-    const void* y1;      // bf16 [M, D] attention-branch output still to be added (or null)
+    const void* y1;      // bf16 [M, D] attention-branch output still to be added (or null); fold: the attention OUTPUT (before proj), as an image
+    const float* bproj;  // (fold) proj bias [D]
+    int fold;            // (mlp32.hip, image forms, wpk packed WITH the proj matrix) 1: the kernel applies proj itself: y1 = att . Wp^T + bproj
     const float* ln_w;
     const float* ln_b;
     float ln_eps;
@@ -123,7 +125,8 @@ int hipt_mlp_pack_launch(const void* w1, const void* w2, int D, int hidden, void
 // The 32x32x16-MFMA form of the pipelined kernel (mlp32.hip): packed weights only, its own image format (same size).
 bool hipt_mlp32_supported(int dtype, int D, int hidden);  // (shapes only: hipt_vit_mlp_pack_format chooses the kernel)
 int hipt_mlp32_launch(const MlpParams& p, hipStream_t st);
-int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);
+// (wproj != null: the proj matrix [D, D] as six more units behind the fc1 / fc2 units: D * D * 2 more bytes)
+int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st, const void* wproj = nullptr);
 // The wave-specialised form (mlp_ws.hip: 8 waves, fc1 + GELU waves and fc2 waves sharing rows): image format 2.
 bool hipt_mlp_ws_supported(int dtype, int D, int hidden);  // (shapes only; opt-in through hipt_vit_mlp_pack_format)
 int hipt_mlp_ws_launch(const MlpParams& p, hipStream_t st);

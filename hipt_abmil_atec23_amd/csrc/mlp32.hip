@@ -52,7 +52,7 @@ __device__ __forceinline__ void mma32(f32x16& acc, const u32x4& a, const u32x4& 
         if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
-enum { KA = 0, KB = 1 };  // phase kind: fc1 half / fc2 half
+enum { KA = 0, KB = 1, KP = 2 };  // phase kind: fc1 half / fc2 half / (FOLD) proj: output tiles 2 H, 2 H + 1 of the attention branch
 
 // Ring unit `pos` of a tile pass: positions A0(0) A1(0) B0(0) | A0(c) B1(c-1) A1(c) B0(c) ... | B1(n-1)
 __device__ __forceinline__ void unit_of(int pos, int nchunk, bool& is_a, int& c, int& h) {
@@ -75,8 +75,9 @@ __device__ __forceinline__ void unit_of(int pos, int nchunk, bool& is_a, int& c,
 }
 
 // The packed image: unit after unit in pass order, each 48 fragments x 1 KiB, lane-major (lane l = 32 h + r: 16 bytes at l * 16).
-//   fc1 unit (chunk c, half hh: hidden Hb = 128 c + 64 hh): fragment 4 gg + 2 p + U (gg 0..11, p 0/1, tile U 0/1) =
-//       W1[Hb + 32 U + r][32 gg + 16 h + 8 p + (0..7)]                       (k-step s = 2 gg + p of the activations' k order)
+//   fc1 unit (chunk c, half hh: hidden Hb = 128 c + 64 hh): fragment 4 gg + 2 p + U (gg 0..11, p 0/1, tile U 0/1): element j =
+//       W1[Hb + 32 U + r][32 gg + 16 p + 8 (j >> 2) + 4 h + (j & 3)]        (k-step s = 2 gg + p of the activations' k order: the
+//       column order of an ACCUMULATOR tile, so that an operand may also come straight from one -- the fc2 order, see below)
 //   fc2 unit: fragment 4 O + t (output tile O 0..11, t = 2 U + s'): element j of lane (r, h) =
 //       W2[32 O + r][Hb + 32 U + 16 s' + 8 (j >> 2) + 4 h + (j & 3)]         (the hidden order of a GELU'd fc1 accumulator tile)
 __global__ void mlp32_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2, int hidden, u32x4* __restrict__ out) {
@@ -90,7 +91,9 @@ __global__ void mlp32_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* _
     const int Hb = 128 * c + 64 * hh;
     if (is_a) {
         const int gg = frag >> 2, pp = (frag >> 1) & 1, U = frag & 1;
-        out[i] = *(const u32x4*)(w1 + (int64_t)(Hb + 32 * U + r) * D + 32 * gg + 16 * h + 8 * pp);
+        const bf16_t* row = w1 + (int64_t)(Hb + 32 * U + r) * D + 32 * gg + 16 * pp + 4 * h;
+        const u32x2 lo = *(const u32x2*)row, hi = *(const u32x2*)(row + 8);
+        out[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
     } else {
         const int O = frag >> 2, t = frag & 3, U = t >> 1, s2 = t & 1;
         const bf16_t* row = w2 + (int64_t)(32 * O + r) * hidden + Hb + 32 * U + 16 * s2 + 4 * h;
@@ -101,9 +104,23 @@ __global__ void mlp32_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* _
 
 // IMG / XIN: fragment-blocked activation images (kernels.h, "activation images") -- IMG: y1 is read and x / xn_out are written as
 // images; XIN: x is read as an image.  Row-major otherwise.  Weights always come from the packed image p.wpk (format 1).
+// The six proj units (FOLD), stored behind the fc1 / fc2 units: unit u = output tiles 2 u, 2 u + 1 of the attention branch, fragments as in
+// an fc1 unit: fragment 4 gg + 2 p + U: element j = Wp[32 (2 u + U) + r][32 gg + 16 p + 8 (j >> 2) + 4 h + (j & 3)].
+__global__ void mlp32_pack_proj_kernel(const bf16_t* __restrict__ wp, u32x4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte lane chunk
+    if (i >= 6 * (UNIT / 16)) return;
+    const int u = i / (UNIT / 16), o = i % (UNIT / 16), frag = o >> 6, lane = o & 63, r = lane & 31, h = lane >> 5;
+    const int gg = frag >> 2, pp = (frag >> 1) & 1, U = frag & 1;
+    const bf16_t* row = wp + (int64_t)(32 * (2 * u + U) + r) * D + 32 * gg + 16 * pp + 4 * h;
+    const u32x2 lo = *(const u32x2*)row, hi = *(const u32x2*)(row + 8);
+    out[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 // DBG (tools/mlp_probe.hip only): 1 = no weight DMA / ring syncs, 2 = GELU replaced by a plain pack, 4 = no MFMAs, 8 = no LDS
 // fragment reads.
-template <bool IMG = false, bool XIN = false, int DBG = 0>
+// FOLD: the attention branch's proj Linear runs here too (p.y1 = the attention output image [M, 384] bf16, six more weight units, p.bproj):
+// see the row phase below.
+template <bool IMG = false, bool XIN = false, int DBG = 0, bool FOLD = false>
 __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gam = (float*)(smem + 3 * UNIT);
@@ -112,23 +129,26 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     float* b1s = b2s + D;                  // [hidden]
     int* tile_s = (int*)(b1s + p.hidden);  // [2] tile handed to this workgroup, double-buffered by parity
     float* gam1 = (float*)(tile_s + 4);    // next block's LayerNorm-1 (gamma | beta), if p.xn_out
+    float* bps = gam1 + 2 * D;             // proj bias (FOLD)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;        // the row phases' 16-row fragment view: lane (li, g) owns chunks g + 4c
     const int h = lane >> 5, m = (lane >> 4) & 1;   // the MFMA view: lane = 32 h + 16 m + li holds row (fragment m, li), k half h
     const int nchunk = p.hidden / 128;
-    const int upt = 4 * nchunk;  // ring units (phases) per tile pass
+    const int upt_mlp = 4 * nchunk;               // fc1 / fc2 units of a tile pass
+    const int upt = upt_mlp + (FOLD ? 6 : 0);     // ring units (phases) per tile pass: FOLD: six proj units first
 
     // ---- weight DMA: unit pos of the image = 48 pieces of 1 KiB, byte for byte what its ring slot holds; wave w issues pieces
     // 12 w .. 12 w + 11.  An LDS-DMA instruction takes its LDS base from M0, and it is WRITING M0 that makes a piece expensive
     // (tools/issue_mix_probe.hip: +36 cycles per piece with a new M0, +2 with the same M0 and the piece selected by the instruction's
     // immediate offset, which is added to the LDS and to the global address alike): four consecutive pieces share one M0.
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, 2 * p.hidden * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, (2 * p.hidden * D + (FOLD ? D * D : 0)) * 2, 0x00020000);
     const uint32_t ilane = (uint32_t)(12 * wave * 1024 + lane * 16);
     int ioff = 0, islot = 0, ipos = 0;
     auto set_issue = [&](int pos, int slot) {
-        ioff = pos * UNIT;
+        // (the image: fc1 / fc2 units in pass order, then the six proj units -- kernels without FOLD never see those)
+        ioff = (FOLD ? (pos < 6 ? upt_mlp + pos : pos - 6) : pos) * UNIT;
         islot = slot;
     };
     auto dma_piece = [&](auto T_) __attribute__((always_inline)) {
@@ -145,6 +165,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
             gam1[i] = p.ln_next_w[i];
             gam1[D + i] = p.ln_next_b[i];
         }
+        if constexpr (FOLD) bps[i] = p.bproj[i];
     }
     for (int i = tid; i < p.hidden; i += 256) b1s[i] = p.b1[i];
     if (tid == 0) tile_s[0] = atomicAdd(p.counter, 1);
@@ -167,6 +188,8 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     const uint32_t gbase = (uint32_t)(uintptr_t)(LDS_AS char*)gam + 32 * g;           // (row phases: 16-row fragment view)
     const uint32_t b2base = (uint32_t)(uintptr_t)(LDS_AS char*)b2s + 16 * h;          // b2[32 O + 8 q + 4 h ..]: + (32 O + 8 q) * 4
     const uint32_t g1base = (uint32_t)(uintptr_t)(LDS_AS char*)gam1 + 16 * h;         // next LN-1 gamma (beta: + D * 4)
+    const uint32_t g2base = (uint32_t)(uintptr_t)(LDS_AS char*)gam + 16 * h;          // (FOLD) LN-2 gamma in accumulator column order (beta: + D * 4)
+    const uint32_t bpbase = (uint32_t)(uintptr_t)(LDS_AS char*)bps + 16 * h;          // (FOLD) proj bias
 
     // ---- prime the ring: units 0 and 1 of the pass ----
     int cons = 0;  // units consumed since kernel start (slot = cons % 3)
@@ -230,71 +253,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
             asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt) : "memory");
         }
 
-        // ---- activations: v = x + y1 -> LN2 -> operand fragments (16-row fragment view, as mlp_pipe.hip) ----
-        u32x4 X[NKS];
-        {
-            u32x4 af[2][NCH];
-#pragma unroll
-            for (int mf = 0; mf < 2; ++mf) {
-                int r = (wave * 2 + mf) * 16 + li;
-                r = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
-                // image forms: whole fragments only (the launcher guarantees M % 16 == 0); a fragment past the tile's end
-                // re-reads fragment 0 of the tile (never stored)
-                const int fr = (wave * 2 + mf) * 16 < nrows ? (wave * 2 + mf) * 16 : 0;
-                // x: row-major: row r, floats (g + 4c) * 8 + 4hh;  image: fragment base + c * 512 + hh * 256 + lane * 4
-                const float* xr = XIN ? p.x + (int64_t)(row0 + fr) * D + lane * 4 : p.x + (int64_t)(row0 + r) * D + g * 8;
-                constexpr int xc_ = XIN ? 512 : 32, xh_ = XIN ? 256 : 4;
-                f32x4 v[NCH][2];
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    v[c][0] = *(const f32x4*)(xr + c * xc_);
-                    v[c][1] = *(const f32x4*)(xr + c * xc_ + xh_);
-                }
-                if (p.y1) {
-                    // y1 (bf16): row-major: row r, elements (g + 4c) * 8;  image: fragment base + c * 512 + lane * 8
-                    const bf16_t* yr = IMG ? (const bf16_t*)p.y1 + (int64_t)(row0 + fr) * D + lane * 8 : (const bf16_t*)p.y1 + (int64_t)(row0 + r) * D + g * 8;
-                    constexpr int yc_ = IMG ? 512 : 32;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        const bf16x8 y = __builtin_bit_cast(bf16x8, *(const u32x4*)(yr + c * yc_));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[c][0][e] += (float)y[e];
-                            v[c][1][e] += (float)y[4 + e];
-                        }
-                    }
-                }
-                ln_rows_lds<D, NCH>(v, gbase, p.ln_eps, af[mf]);
-                if (mf == 0) {
-                    // park the finished fragment in the accumulator file (idle during the row phase) while the other one
-                    // is loaded and normalised: left alone, hipcc sends it to scratch and the reloads stall the first phase
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        u32x4& a2 = af[0][c];
-                        asm volatile("" : "+a"(a2));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            // 16-row fragments -> the 32-row B operand.  Lane (li, g = 2 h + m) holds chunks 2 h + m + 4 c of BOTH fragments; it needs
-            // fragment m only, chunks 2 h + 4 c (E) and 2 h + 1 + 4 c (O).  Lanes l and l ^ 16 (m = 0 / 1, same h) hold each other's
-            // missing chunks: one v_permlane16_swap per dword (odd 16-lane rows of the first operand <-> even rows of the second)
-            // leaves E in the first and O in the second for every lane.  k-step 2 c + p then carries k = 32 c + 16 h + 8 p + (0..7).
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                u32x4 e4, o4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const auto sw = __builtin_amdgcn_permlane16_swap(af[0][c][e], af[1][c][e], false, false);
-                    e4[e] = sw[0];
-                    o4[e] = sw[1];
-                }
-                X[2 * c] = e4;
-                X[2 * c + 1] = o4;
-            }
-        }
-        PSTAMP(2);
-        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
+        u32x4 X[NKS];  // the fc1 B operand: k-step s = 2 c + p, lane half h: columns 32 c + 16 p + 8 (j >> 2) + 4 h + (j & 3)
 
         f32x16 acc2[NOT];
 #pragma unroll
@@ -303,12 +262,6 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
             for (int e = 0; e < 16; ++e) acc2[o][e] = 0.f;
         f32x16 acc1[2][2];   // [half][tile U]: hidden (reg & 3) + 8 (reg >> 2) + 4 h of tile U for this lane's row
         u32x4 hf[2][2][2];   // [half][tile U][k-step s']: the GELU'd, bf16-packed registers 8 s' .. 8 s' + 7 of acc1[half][U]
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) hf[a][b][c] = u32x4{0u, 0u, 0u, 0u};
         // one 2-element GELU: unit u (0..15) of half GH -> one 32-bit word of the fc2 operand fragments
         auto gelu_unit = [&](auto GH_, auto U_) __attribute__((always_inline)) {
             constexpr int gh = decltype(GH_)::value, u = decltype(U_)::value;
@@ -384,9 +337,14 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                         mma32<DBG>(acc1[hh][0], wA[set][2], X[2 * gg + 1]);
                         mma32<DBG>(acc1[hh][1], wA[set][3], X[2 * gg + 1]);
                     }
-                } else {
+                } else if constexpr (kind == KB) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) mma32<DBG>(acc2[gg], wA[set][t], hf[hh][t >> 1][t & 1]);
+                } else {  // KP: as an fc1 group, into the (still idle) fc2 accumulators of output tiles 2 hh, 2 hh + 1
+                    mma32<DBG>(acc2[2 * hh], wA[set][0], X[2 * gg]);
+                    mma32<DBG>(acc2[2 * hh + 1], wA[set][1], X[2 * gg]);
+                    mma32<DBG>(acc2[2 * hh], wA[set][2], X[2 * gg + 1]);
+                    mma32<DBG>(acc2[2 * hh + 1], wA[set][3], X[2 * gg + 1]);
                 }
                 if constexpr (gg == 11) {
                     dma_piece(std::integral_constant<int, 0>{});
@@ -405,7 +363,231 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         typedef std::integral_constant<int, -1> IM1;
         typedef std::integral_constant<int, KA> TA;
         typedef std::integral_constant<int, KB> TB;
+        typedef std::integral_constant<int, KP> TP;
 
+        // 16-row fragments (chunk g + 4 c of fragments 0 / 1 per lane) -> the 32-row B operand X
+        auto to_operand = [&](u32x4 (&af)[2][NCH]) __attribute__((always_inline)) {
+            // 16-row fragments -> the 32-row B operand.  Lane (li, g = 2 h + m) holds chunks 2 h + m + 4 c of BOTH fragments; it needs
+        // fragment m only, chunks 2 h + 4 c (E) and 2 h + 1 + 4 c (O).  Lanes l and l ^ 16 (m = 0 / 1, same h) hold each other's
+        // missing chunks: one v_permlane16_swap per dword (odd 16-lane rows of the first operand <-> even rows of the second)
+        // leaves E in the first and O in the second for every lane.  k-step 2 c + p then carries k = 32 c + 16 h + 8 p + (0..7).
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            u32x4 e4, o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(af[0][c][e], af[1][c][e], false, false);
+                e4[e] = sw[0];
+                o4[e] = sw[1];
+            }
+            // ... and lanes l and l ^ 32 trade 4-column groups, so that the operand's k order is the column order of an accumulator
+            // tile (lane half h: columns 8 q + 4 h + (0..3) of every 32): after the 16-lane swap half h holds columns 16 h + (0..15)
+            // of the 32 as e4 = [G, G + 1], o4 = [G + 2, G + 3] (G = 4 h, groups of 4 columns); it keeps its even groups and
+            // takes the other half's: k-step 2 c = [G0 | G2] (h = 0) / [G1 | G3] (h = 1), k-step 2 c + 1 = [G4 | G6] / [G5 | G7].
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(e4[e], e4[2 + e], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(o4[e], o4[2 + e], false, false);
+                e4[e] = s0[0];
+                e4[2 + e] = s0[1];
+                o4[e] = s1[0];
+                o4[2 + e] = s1[1];
+            }
+            X[2 * c] = u32x4{e4[0], e4[1], o4[0], o4[1]};
+            X[2 * c + 1] = u32x4{e4[2], e4[3], o4[2], o4[3]};
+        }
+        };
+        if constexpr (!FOLD) {
+            // ---- activations: v = x + y1 -> LN2 -> operand fragments (16-row fragment view, as mlp_pipe.hip) ----
+            u32x4 af[2][NCH];
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                int r = (wave * 2 + mf) * 16 + li;
+                r = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
+                // image forms: whole fragments only (the launcher guarantees M % 16 == 0); a fragment past the tile's end
+                // re-reads fragment 0 of the tile (never stored)
+                const int fr = (wave * 2 + mf) * 16 < nrows ? (wave * 2 + mf) * 16 : 0;
+                // x: row-major: row r, floats (g + 4c) * 8 + 4hh;  image: fragment base + c * 512 + hh * 256 + lane * 4
+                const float* xr = XIN ? p.x + (int64_t)(row0 + fr) * D + lane * 4 : p.x + (int64_t)(row0 + r) * D + g * 8;
+                constexpr int xc_ = XIN ? 512 : 32, xh_ = XIN ? 256 : 4;
+                f32x4 v[NCH][2];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    v[c][0] = *(const f32x4*)(xr + c * xc_);
+                    v[c][1] = *(const f32x4*)(xr + c * xc_ + xh_);
+                }
+                if (p.y1) {
+                    // y1 (bf16): row-major: row r, elements (g + 4c) * 8;  image: fragment base + c * 512 + lane * 8
+                    const bf16_t* yr = IMG ? (const bf16_t*)p.y1 + (int64_t)(row0 + fr) * D + lane * 8 : (const bf16_t*)p.y1 + (int64_t)(row0 + r) * D + g * 8;
+                    constexpr int yc_ = IMG ? 512 : 32;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const bf16x8 y = __builtin_bit_cast(bf16x8, *(const u32x4*)(yr + c * yc_));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[c][0][e] += (float)y[e];
+                            v[c][1][e] += (float)y[4 + e];
+                        }
+                    }
+                }
+                ln_rows_lds<D, NCH>(v, gbase, p.ln_eps, af[mf]);
+                if (mf == 0) {
+                    // park the finished fragment in the accumulator file (idle during the row phase) while the other one
+                    // is loaded and normalised: left alone, hipcc sends it to scratch and the reloads stall the first phase
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        u32x4& a2 = af[0][c];
+                        asm volatile("" : "+a"(a2));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            to_operand(af);
+        } else {
+            // ---- FOLD: y1 = proj(att) is computed here instead of read.  (1) the attention output tile (bf16 image) is itself
+            // an operand: its 16-byte chunks are the fragment layout; (2) six phases on the proj units into acc2 (idle until the
+            // first fc2 phase): acc2[O][4 q + e] = column 32 O + 8 q + 4 h + e of this lane's row; (3) v = acc2 + b_proj + x becomes
+            // the residual stream (stored as its image: the epilogue re-reads it instead of x and y1) and, LayerNorm-2'd, the fc1
+            // operand -- whose k order IS the accumulator's column order.
+            {
+                u32x4 af[2][NCH];
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf) {
+                    const int fr = (wave * 2 + mf) * 16 < nrows ? (wave * 2 + mf) * 16 : 0;
+                    const bf16_t* yr = (const bf16_t*)p.y1 + (int64_t)(row0 + fr) * D + lane * 8;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) af[mf][c] = *(const u32x4*)(yr + c * 512);
+                }
+                to_operand(af);
+            }
+            // the residual rows of this tile, in the accumulator's layout: output tiles 0..5 are requested now and land under the proj
+            // phases (their 96 registers are free until the first fc1 phase), tiles 6..11 when those are being added
+            constexpr int xlo_ = XIN ? 512 : 32, xlq_ = XIN ? 64 : 8;
+            // (pointers are formed where they are used, from values that are live anyway: kept across the phases they would be spilled,
+            //  and a scratch reload inside a ring phase waits for the LDS-DMA in flight)
+            auto x_ptrs = [&](const float*& xl, float*& xs, bool& live) __attribute__((always_inline)) {
+                int li2 = li;
+                asm volatile("" : "+v"(li2));
+                const int r = wave * 32 + m * 16 + li2;
+                live = r < nrows;
+                const int frr = wave * 32 + m * 16;
+                const int64_t rb = (int64_t)(row0 + (live ? r : 0)) * D + 4 * h, fb = (int64_t)(row0 + (live ? frr : 0)) * D;
+                xl = XIN ? p.x + fb + 256 * h + 4 * li2 : p.x + rb;
+                xs = p.x + fb + 256 * h + 4 * li2;
+            };
+            f32x4 xa[6][4], xb[6][4];
+            {
+                const float* xl;
+                float* xs;
+                bool live;
+                x_ptrs(xl, xs, live);
+#pragma unroll
+                for (int O = 0; O < 6; ++O)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xa[O][q] = *(const f32x4*)(xl + xlo_ * O + xlq_ * q);
+            }
+            rd_frag(I0{}, I0{}, fbase + (cons % 3) * UNIT);
+            phase(TP{}, I0{}, IM1{}, I0{}, I0{}, 0);
+            phase(TP{}, I1{}, IM1{}, I0{}, I0{}, 0);
+            phase(TP{}, std::integral_constant<int, 2>{}, IM1{}, I0{}, I0{}, 0);
+            phase(TP{}, std::integral_constant<int, 3>{}, IM1{}, I0{}, I0{}, 0);
+            phase(TP{}, std::integral_constant<int, 4>{}, IM1{}, I0{}, I0{}, 0);
+            phase(TP{}, std::integral_constant<int, 5>{}, IM1{}, I0{}, IM1{}, 0);
+            {
+#pragma clang fp contract(off)
+                const float* xl;
+                float* xs;
+                bool live;
+                x_ptrs(xl, xs, live);
+                // every old value of the tile is loaded (and waited for) before the first store: converting in place (row-major in,
+                // image out: the first block of a forward) a lane's stores land where OTHER lanes' loads read
+#pragma unroll
+                for (int O = 0; O < 6; ++O)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xb[O][q] = *(const f32x4*)(xl + xlo_ * (6 + O) + xlq_ * q);
+                sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+                    constexpr int O = decltype(O_)::value;
+                    f32x4 bb[4];
+                    const uint32_t ba = bpbase;
+                    f32x4 &r0_ = bb[0], &r1_ = bb[1], &r2_ = bb[2], &r3_ = bb[3];
+                    DSR128X4_WAIT(r0_, r1_, r2_, r3_, ba, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
+                    f32x16 t = acc2[O];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[4 * q + e] = (t[4 * q + e] + bb[q][e]) + (O < 6 ? xa[O < 6 ? O : 0][q][e] : xb[O < 6 ? 0 : O - 6][q][e]);
+                    asm volatile("" : "+a"(t));  // back to the accumulator file at once (left to hipcc, the sums go to scratch)
+                    acc2[O] = t;
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (one output tile at a time from here on: the accumulators live in the accumulator file, arithmetic needs them in arch
+                //  VGPRs, and hipcc, left alone, fetches all 192 at once and spills)
+                float rs = 0.f;
+                sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+                    constexpr int O = decltype(O_)::value;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc2[O][4 * q], acc2[O][4 * q + 1], acc2[O][4 * q + 2], acc2[O][4 * q + 3]};
+                        if (live) *(f32x4*)(xs + 512 * O + 64 * q) = v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rs += v[e];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                rs += __shfl_xor(rs, 32, 64);
+                const float mean = rs * (1.0f / D);
+                float qs = 0.f;
+                sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+                    constexpr int O = decltype(O_)::value;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float a = acc2[O][e] - mean;
+                        qs = __builtin_fmaf(a, a, qs);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                qs += __shfl_xor(qs, 32, 64);
+                const float rstd = 1.0f / sqrtf(qs * (1.0f / D) + p.ln_eps);
+                sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+                    constexpr int O = decltype(O_)::value;
+                    f32x4 gq[4], bqv[4];
+                    const uint32_t ga = g2base;
+                    f32x4 &g0 = gq[0], &g1 = gq[1], &g2 = gq[2], &g3 = gq[3], &b0 = bqv[0], &b1_ = bqv[1], &b2_ = bqv[2], &b3 = bqv[3];
+                    DSR128X4_WAIT(g0, g1, g2, g3, ga, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
+                    DSR128X4_WAIT(b0, b1_, b2_, b3, ga, D * 4 + O * 128, D * 4 + O * 128 + 32, D * 4 + O * 128 + 64, D * 4 + O * 128 + 96);
+                    uint32_t w[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float y[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc2[O][4 * q + e] - mean) * rstd, gq[q][e], bqv[q][e]);
+                        w[2 * q] = pack_bf16x2(y[0], y[1]);
+                        w[2 * q + 1] = pack_bf16x2(y[2], y[3]);
+                    }
+                    X[2 * O] = u32x4{w[0], w[1], w[2], w[3]};      // k-step 2 O: columns 8 q + 4 h + e of the 32, q = 0, 1
+                    X[2 * O + 1] = u32x4{w[4], w[5], w[6], w[7]};  // k-step 2 O + 1: q = 2, 3
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+#pragma unroll
+                for (int o = 0; o < NOT; ++o)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc2[o][e] = 0.f;
+            }
+        }
+        PSTAMP(2);
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
+
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) hf[a][b][c] = u32x4{0u, 0u, 0u, 0u};
         // first fragments and bias of the pass (asm reads land asynchronously: nothing but the first phase may sit
         // between them and their counted wait -- in particular not the row phases, where the compiler moves registers)
         rd_frag(I0{}, I0{}, fbase + (cons % 3) * UNIT);
@@ -446,15 +628,17 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
             const int64_t rb = (int64_t)(row0 + (live ? r : 0)) * D + 4 * h, fb = (int64_t)(row0 + (live ? fr : 0)) * D;
             // float / element offsets of piece (O, q): row-major rb + 32 O + 8 q; fp32 image fb + 512 O + 256 h + 64 q + 4 li;
             // bf16 image fb + 512 O + 128 q + 8 li + 4 h
-            const float* xl = XIN ? p.x + fb + 256 * h + 4 * li : p.x + rb;
+            // (FOLD: the row phase left v = x + y1 where x was, as an image: that is what is re-read, and there is no y1)
+            constexpr bool XI = XIN || FOLD;
+            const float* xl = XI ? p.x + fb + 256 * h + 4 * li : p.x + rb;
             float* xs = IMG ? p.x + fb + 256 * h + 4 * li : p.x + rb;
             const bf16_t* yr = IMG ? (const bf16_t*)p.y1 + fb + 8 * li + 4 * h : (const bf16_t*)p.y1 + rb;
-            constexpr int xlo_ = XIN ? 512 : 32, xlq_ = XIN ? 64 : 8, xso_ = IMG ? 512 : 32, xsq_ = IMG ? 64 : 8, yo_ = IMG ? 512 : 32, yq_ = IMG ? 128 : 8;
+            constexpr int xlo_ = XI ? 512 : 32, xlq_ = XI ? 64 : 8, xso_ = IMG ? 512 : 32, xsq_ = IMG ? 64 : 8, yo_ = IMG ? 512 : 32, yq_ = IMG ? 128 : 8;
             float rs = 0.f;
             // three output tiles at a time: their old x (12 x 16 B) and y1 (12 x 8 B) pieces are requested one batch ahead.
             // Converting in place (row-major in, image out: the first block of a forward) a lane's stores land where OTHER lanes'
             // loads read: there every old value of the tile is loaded, and waited for, before the first store.
-            f32x4 xv[XIN != IMG ? NOT : 6][4];
+            f32x4 xv[XI != IMG ? NOT : 6][4];
             u32x2 yv[6][4];
             auto ld_batch = [&](auto B_) __attribute__((always_inline)) {
                 constexpr int b = decltype(B_)::value, s0 = (b & 1) * 3;
@@ -463,11 +647,11 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int O = 3 * b + i;
-                        if constexpr (XIN == IMG) xv[s0 + i][q] = *(const f32x4*)(xl + xlo_ * O + xlq_ * q);
-                        yv[s0 + i][q] = p.y1 ? *(const u32x2*)(yr + yo_ * O + yq_ * q) : u32x2{0u, 0u};
+                        if constexpr (XI == IMG) xv[s0 + i][q] = *(const f32x4*)(xl + xlo_ * O + xlq_ * q);
+                        yv[s0 + i][q] = (!FOLD && p.y1) ? *(const u32x2*)(yr + yo_ * O + yq_ * q) : u32x2{0u, 0u};
                     }
             };
-            if constexpr (XIN != IMG) {
+            if constexpr (XI != IMG) {
 #pragma unroll
                 for (int O = 0; O < NOT; ++O)
 #pragma unroll
@@ -481,7 +665,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                 if constexpr (b < 3) ld_batch(std::integral_constant<int, b + 1>{});
                 sfor<0, 3>([&](auto I_) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
-                    constexpr int i = decltype(I_)::value, O = 3 * b + i, xi = (XIN != IMG) ? O : s0 + i;
+                    constexpr int i = decltype(I_)::value, O = 3 * b + i, xi = (XI != IMG) ? O : s0 + i;
                     f32x4 bb[4];
                     const uint32_t ba = b2base;
                     f32x4 &r0_ = bb[0], &r1_ = bb[1], &r2_ = bb[2], &r3_ = bb[3];
@@ -552,7 +736,7 @@ bool hipt_mlp32_supported(int dtype, int D_, int hidden) {
     return dtype == HIPT_BF16 && D_ == 384 && hidden % 128 == 0 && hidden >= 256 && hidden <= 1536;
 }
 
-int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D_, int hidden, void* packed, hipStream_t st) {
+int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D_, int hidden, void* packed, hipStream_t st, const void* wproj) {
     if (!(D_ == 384 && hidden % 128 == 0 && hidden >= 256 && hidden <= 1536)) {
         hipt_set_error("mlp32 pack: unsupported D=%d hidden=%d", D_, hidden);
         return HIPT_E_UNSUPPORTED;
@@ -560,24 +744,34 @@ int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D_, int hidden, v
     const int64_t chunks = (int64_t)(hidden / 128) * 4 * (UNIT / 16);
     hipLaunchKernelGGL(mlp32_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const bf16_t*)w1, (const bf16_t*)w2, hidden, (u32x4*)packed);
     HIPT_CHECK_LAUNCH();
+    if (wproj) {
+        hipLaunchKernelGGL(mlp32_pack_proj_kernel, dim3((6 * (UNIT / 16) + 255) / 256), dim3(256), 0, st, (const bf16_t*)wproj, (u32x4*)packed + chunks);
+        HIPT_CHECK_LAUNCH();
+    }
     return HIPT_OK;
 }
 
 template <int DBG>
 int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     MlpParams p = p_in;
-    const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4;
-    if (!p.wpk || p.wpk_fmt != 1 || (p.img & 2 && !(p.img & 1)) || (p.img && p.M % 16 != 0)) {
-        hipt_set_error("mlp32: needs its packed weights; activation images need M %% 16 == 0 and img in {0, 1, 3} (img=%d, M=%d)", p.img, p.M);
+    const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4 + D * 4;
+    if (!p.wpk || p.wpk_fmt != 1 || (p.img & 2 && !(p.img & 1)) || (p.img && p.M % 16 != 0) || (p.fold && (!(p.img & 1) || !p.y1 || !p.bproj))) {
+        hipt_set_error("mlp32: needs its packed weights; activation images need M %% 16 == 0 and img in {0, 1, 3}; fold needs images (img=%d, M=%d, fold=%d)", p.img,
+                       p.M, p.fold);
         return HIPT_E_BADARG;
     }
-    auto k = p.img == 3 ? mlp32_kernel<true, true, DBG> : p.img == 1 ? mlp32_kernel<true, false, DBG> : mlp32_kernel<false, false, DBG>;
+    auto k = p.fold ? (p.img == 3 ? mlp32_kernel<true, true, DBG, true> : mlp32_kernel<true, false, DBG, true>)
+             : p.img == 3 ? mlp32_kernel<true, true, DBG>
+             : p.img == 1 ? mlp32_kernel<true, false, DBG>
+                          : mlp32_kernel<false, false, DBG>;
     static DevOnce once;
     HIPT_CUR_DEVICE(dev);
     if (!once.done[dev]) {
         if (hipFuncSetAttribute((const void*)mlp32_kernel<true, true, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)mlp32_kernel<true, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)mlp32_kernel<false, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            hipFuncSetAttribute((const void*)mlp32_kernel<false, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mlp32_kernel<true, true, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mlp32_kernel<true, false, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(mlp32) failed");
             return HIPT_E_LAUNCH;
         }

@@ -74,7 +74,8 @@ typedef struct hipt_block_weights {
      * are a cache of qkv_w / proj_w / fc1_w+fc2_w: re-pack after the weights change. */
     const void*  qkv_pk;  const void* proj_pk;  const void* mlp_pk;
     /* Which fused-MLP kernel mlp_pk was packed for: the value hipt_vit_mlp_pack_format returned when it was packed (the
-     * library has more than one fused-MLP kernel, each with its own image order; an image is only valid with its format). */
+     * library has more than one fused-MLP kernel, each with its own image order; an image is only valid with its format;
+     * format 1 also holds proj_w, which that kernel applies itself: re-pack after proj_w changes, too). */
     int32_t      mlp_pk_fmt;  int32_t reserved;
 } hipt_block_weights;
 

@@ -449,6 +449,32 @@ def test_hipt4k_patch_embedding_addresses_regions(hipt, monkeypatch):
     assert torch.equal(fused[1:2], fused_one)
 
 
+def test_vit256_proj_folded_into_the_mlp(vit256, monkeypatch):
+    """HIPT_PROJ_FOLD=1: the fused MLP kernel applies the attention branch's proj Linear itself (six more weight units in its image,
+    v = x + proj(att) + b kept in the fc2 accumulator's registers through LayerNorm-2; csrc/mlp32.hip, FOLD).  The attention
+    branch then stays fp32 instead of passing through a bf16 y1: held to the bf16 bar against the default path, bitwise against
+    itself under another batching."""
+    if os.environ.get("HIPT_NO_PREPACK"):
+        pytest.skip("HIPT_NO_PREPACK is set for the whole run")
+    x = synth.hash_uniform_torch((16, 3, 256, 256), 41, device=DEV)  # 16 x 257 rows: whole fragments, i.e. activation images
+    vit256.set_compute_dtype("bf16")
+    try:
+        plain = vit256(x)
+        inter = vit256.get_intermediate_layers(x, n=2)
+        monkeypatch.setenv("HIPT_PROJ_FOLD", "1")
+        fold = vit256(x)
+        fold_inter = vit256.get_intermediate_layers(x, n=2)
+        fold32 = vit256(torch.cat([x, x], dim=0))
+    finally:
+        monkeypatch.delenv("HIPT_PROJ_FOLD", raising=False)
+        vit256.set_compute_dtype("fp32")
+    rel = float((fold - plain).norm() / plain.norm())
+    rel_i = max(float((a - b).norm() / b.norm()) for a, b in zip(fold_inter, inter))
+    print(f"proj folded into the MLP vs separate proj: [CLS] features rel-L2 {rel:.2e}, last two blocks' tokens {rel_i:.2e}")
+    assert rel < 1.3e-2 and rel_i < 1.3e-2
+    assert torch.equal(fold32[:16], fold) and torch.equal(fold32[16:], fold)
+
+
 def test_vit256_activation_images_change_nothing(vit256, monkeypatch):
     """forward() keeps the residual stream, the attention-branch output and the pre-normalised QKV operands of blocks
     2..11 as fragment-blocked "activation images" (csrc/kernels.h) when the batch has whole 16-row fragments: a pure

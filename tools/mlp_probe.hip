@@ -71,7 +71,7 @@ static float bf2f(uint16_t b) {
 
 int main(int argc, char** argv) {
     // "check [M]": one launch on M rows (default 514), compared with an fp64 host evaluation of the same bf16 operands
-    const bool check = argc > 1 && strcmp(argv[1], "check") == 0;
+    const bool check = argc > 1 && (strcmp(argv[1], "check") == 0 || strcmp(argv[1], "checkfold") == 0);
     const int regions = (argc > 1 && !check) ? atoi(argv[1]) : 1;
     const int M = check ? (argc > 2 ? atoi(argv[2]) : 514) : regions * 65792, D = 384, H = 1536;
     std::vector<float> hx((size_t)M * D);
@@ -126,6 +126,72 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&xn, hy.size() * 2));
         p.img = 3; p.xn_out = xn; p.ln_next_w = (float*)g; p.ln_next_b = (float*)bt;
     }
+#ifdef PROBE_32
+    if (argc > 1 && strcmp(argv[1], "checkfold") == 0) {
+        // the proj Linear folded in: p.y1 = the attention output as a bf16 image, x row-major in / image out; the host evaluates
+        // v = x + att . Wp^T + bp, then the MLP on the bf16 operands, in fp64
+        const int Mf = argc > 2 ? atoi(argv[2]) : 2048;
+        if (Mf % 16 || Mf > M) { printf("checkfold: M must be a multiple of 16, <= %d\n", M); return 1; }
+        std::vector<uint16_t> hwp((size_t)D * D), hatt((size_t)Mf * D), himg((size_t)Mf * D);
+        std::vector<float> hbp(D);
+        for (auto& v : hwp) v = f2bf(frand() * 0.05f);
+        for (auto& v : hatt) v = f2bf(frand());
+        for (auto& v : hbp) v = frand() * 0.1f;
+        for (int r = 0; r < Mf; ++r)
+            for (int k = 0; k < D; ++k) {
+                const int F = r / 16, li = r % 16, ch = k / 8, e = k % 8, g = ch % 4, c = ch / 4;
+                himg[(size_t)F * 6144 + c * 512 + (16 * g + li) * 8 + e] = hatt[(size_t)r * D + k];
+            }
+        void *wp, *att, *bp, *pk;
+        CK(hipMalloc(&wp, hwp.size() * 2));
+        CK(hipMalloc(&att, himg.size() * 2));
+        CK(hipMalloc(&bp, D * 4));
+        CK(hipMalloc(&pk, (size_t)(2 * H * D + D * D) * 2));
+        CK(hipMemcpy(wp, hwp.data(), hwp.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(att, himg.data(), himg.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(bp, hbp.data(), D * 4, hipMemcpyHostToDevice));
+        if (hipt_mlp32_pack_launch(w1, w2, D, H, pk, 0, wp) != 0) { printf("pack failed\n"); return 1; }
+        MlpParams pf = p;
+        pf.M = Mf; pf.wpk = pk; pf.wpk_fmt = 1; pf.y1 = att; pf.bproj = (const float*)bp; pf.fold = 1; pf.img = 1;
+        if (LAUNCH(0, pf) != 0) { printf("launch failed\n"); return 1; }
+        CK(hipDeviceSynchronize());
+        std::vector<float> img((size_t)Mf * D);
+        CK(hipMemcpy(img.data(), x, img.size() * 4, hipMemcpyDeviceToHost));
+        double maxerr = 0;
+        long nbad = 0;
+        std::vector<double> v(D), a(D), hbuf(H);
+        for (int r = 0; r < Mf; ++r) {
+            double mean = 0, var = 0;
+            for (int n = 0; n < D; ++n) {
+                double acc = hbp[n];
+                for (int k = 0; k < D; ++k) acc += (double)bf2f(hatt[(size_t)r * D + k]) * bf2f(hwp[(size_t)n * D + k]);
+                v[n] = (double)hx[(size_t)r * D + n] + acc;
+                mean += v[n];
+            }
+            mean /= D;
+            for (int k = 0; k < D; ++k) var += (v[k] - mean) * (v[k] - mean);
+            const double rstd = 1.0 / sqrt(var / D + 1e-6);
+            for (int k = 0; k < D; ++k) a[k] = bf2f(f2bf((float)((v[k] - mean) * rstd * hg[k] + hbt[k])));
+            for (int n = 0; n < H; ++n) {
+                double acc = hb1[n];
+                for (int k = 0; k < D; ++k) acc += a[k] * bf2f(hw1[(size_t)n * D + k]);
+                hbuf[n] = bf2f(f2bf((float)(0.5 * acc * (1.0 + erf(acc * 0.70710678118654752)))));
+            }
+            for (int n = 0; n < D; ++n) {
+                double acc = hb2[n];
+                for (int k = 0; k < H; ++k) acc += hbuf[k] * bf2f(hw2[(size_t)n * H + k]);
+                const double ref = v[n] + acc;
+                const int F = r / 16, li = r % 16, ch = n / 8, e = n % 8, g = ch % 4, c = ch / 4, hh = e / 4;
+                const float got = img[(size_t)F * 6144 + c * 512 + hh * 256 + (16 * g + li) * 4 + (e % 4)];
+                const double err = fabs(got - ref);
+                if (!(err <= 2e-2)) ++nbad;
+                if (err > maxerr) maxerr = err;
+            }
+        }
+        printf("checkfold M=%d: max |err| %.3e, %ld elements off by > 2e-2\n", Mf, maxerr, nbad);
+        return nbad ? 1 : 0;
+    }
+#endif
     if (check) {
         LAUNCH(0, p);
         CK(hipDeviceSynchronize());
