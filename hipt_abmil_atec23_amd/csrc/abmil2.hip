@@ -823,9 +823,14 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
         }
         once.done[dev] = true;
     }
-    // contiguous row ranges per wave, multiples of 16 rows; at most 256 workgroups x 4 waves
+    // contiguous row ranges per wave; at most 256 workgroups x 4 waves
     int rows = (N + 1023) / 1024;
-    rows = (rows + 15) / 16 * 16;
+    // (rows per wave rounded to 2, not to a 16-row fragment: 100 000 rows are then 98 per wave on all 256 CUs instead of 112 on 224 --
+    //  the same time, measured both ways; rows are masked one by one, a buffer resource ends each wave's range.  HIPT_ABMIL_ROWS_ROUND=16:
+    //  round 1's partition)
+    static const char* rnd_env = getenv("HIPT_ABMIL_ROWS_ROUND");
+    const int rnd = rnd_env && atoi(rnd_env) > 0 ? atoi(rnd_env) : 2;
+    rows = (rows + rnd - 1) / rnd * rnd;
     const int waves = (N + rows - 1) / rows;
     const int grid = (waves + 3) / 4;
 #ifdef HIPT_DEBUG_STAMPS  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
