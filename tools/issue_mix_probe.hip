@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <stdlib.h>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -140,14 +141,20 @@ template <uint32_t G0, uint32_t G1, uint32_t G2, uint32_t G3, int NT = 256>
 __global__ __launch_bounds__(NT, 1) void k2(const char* src, int iters, unsigned long long* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < 96 * 1024 / 4; i += NT) ((uint32_t*)smem)[i] = 0x3c003c00u;
+    // (operands with random mantissas and small exponents: a constant pattern draws far less power than real data, and the
+    //  clock under load is part of what this probe reports)
+    for (int i = threadIdx.x; i < 96 * 1024 / 4; i += NT) {
+        const uint32_t hsh = (uint32_t)(i * 2654435761u) ^ (uint32_t)(blockIdx.x * 40503u);
+        ((uint32_t*)smem)[i] = (hsh & 0x807f807fu) | 0x3c003c00u;
+    }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 2359296, 0x00020000);
     const uint32_t fb = (uint32_t)(uintptr_t)(LDS_AS char*)smem + lane * 16;
     const uint32_t ilane = (wave & 3) * 1024 + lane * 16;
     f32x16 a0, a1;
     for (int e = 0; e < 16; ++e) a0[e] = a1[e] = 0.f;
-    u32x4 w0[4], w1[4], b = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    u32x4 w0[4], w1[4], b;
+    for (int i = 0; i < 4; ++i) b[i] = (((uint32_t)(threadIdx.x * 2246822519u + i * 3266489917u)) & 0x807f807fu) | 0x3c003c00u;
     for (int i = 0; i < 4; ++i) w0[i] = w1[i] = b;
     float f[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, c = 0.999f, d = 1e-3f;
     f32x2 p[4] = {{1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}}, pc = {0.999f, 0.999f}, pd = {1e-3f, 1e-3f};
@@ -191,7 +198,8 @@ __global__ __launch_bounds__(NT, 1) void k2(const char* src, int iters, unsigned
             for (int i = 0; i < nf; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i & 7]) : "v"(c), "v"(d));
         }
         if constexpr ((S & Dm) && (S & DL)) dma();
-        if constexpr (NRD) WAITL(3);
+        if constexpr (NRD == 4) WAITL(3);
+        if constexpr (NRD > 0 && NRD < 4) WAITL(NRD - 1);
         SB();
     };
     auto group = [&](u32x4(&cur)[4], u32x4(&nxt)[4], uint32_t ra) __attribute__((always_inline)) {
@@ -232,6 +240,7 @@ __global__ __launch_bounds__(NT, 1) void k2(const char* src, int iters, unsigned
 #define RUN2(name, g0, g1, g2, g3) run(name, k2<(g0), (g1), (g2), (g3)>, out)
 #define RUN2W(name, g0, g1, g2, g3) run(name, k2<(g0), (g1), (g2), (g3), 512>, out, 512)
 
+static int g_iters = 20000;
 template <typename K> void run(const char* name, K kern, unsigned long long* out, int nt = 256) {
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     static char* buf = nullptr;
@@ -239,11 +248,18 @@ template <typename K> void run(const char* name, K kern, unsigned long long* out
         CK(hipMalloc(&buf, 2359296));
         CK(hipMemset(buf, 0x3c, 2359296));
     }
-    const int iters = 20000, grid = 256;
+    const int iters = g_iters, grid = 256;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), LDS, 0, buf, 2000, out);
     CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), LDS, 0, buf, iters, out);
+    CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
     static unsigned long long h[256 * 8];
     const int nw = nt / 64;
     CK(hipMemcpy(h, out, (size_t)grid * nw * 8, hipMemcpyDeviceToHost));
@@ -254,10 +270,13 @@ template <typename K> void run(const char* name, K kern, unsigned long long* out
         t += (double)m;
     }
     // with 2 waves per SIMD each wave runs `iters` groups: per SIMD that is 2 groups per loop trip
-    printf("%-64s %.1f cycles / group (4 MFMAs = 128)%s\n", name, t / grid / iters / (nw / 4), nw == 8 ? "  [2 waves / SIMD]" : "");
+    // wall time per group and the clock it implies: long runs (ISSUE_MIX_ITERS=400000: 30 ms) sit at the power cap
+    printf("%-64s %.1f cycles / group (4 MFMAs = 128)%s  | %.1f ns / group, %.2f GHz\n", name, t / grid / iters / (nw / 4), nw == 8 ? "  [2 waves / SIMD]" : "",
+           ms * 1e6 / iters / (nw / 4), (t / grid / iters / (nw / 4)) / (ms * 1e6 / iters / (nw / 4)));
 }
 
 int main() {
+    if (getenv("ISSUE_MIX_ITERS")) g_iters = atoi(getenv("ISSUE_MIX_ITERS"));
     unsigned long long* out;
     CK(hipMalloc(&out, 256 * 8 * 8));
     run("MFMA only", k<RD_NONE, DMA_NONE, 0, 0>, out);
@@ -281,6 +300,8 @@ int main() {
 
     printf("---- per-gap specs (r = read, D = DMA piece first in its gap, Dl = DMA last, nF = n v_fma, nT = n transcendental, pk = packed fma)\n");
     RUN2("r | r | r | r", R, R, R, R);
+    RUN2("r | - | r | -   (one LDS fragment per two MFMAs; waits as for four)", R, 0, R, 0);
+    RUN2("r | - | - | -", R, 0, 0, 0);
     RUN2("r 2T | r 2T | r 2T | r 2T", R | T(2), R | T(2), R | T(2), R | T(2));
     RUN2("r 2T 3F | x4", R | T(2) | F(3), R | T(2) | F(3), R | T(2) | F(3), R | T(2) | F(3));
     RUN2("r 1T 4F | x4", R | T(1) | F(4), R | T(1) | F(4), R | T(1) | F(4), R | T(1) | F(4));
