@@ -127,6 +127,9 @@ bool hipt_mlp32_supported(int dtype, int D, int hidden);  // (shapes only: hipt_
 int hipt_mlp32_launch(const MlpParams& p, hipStream_t st);
 // (wproj != null: the proj matrix [D, D] as six more units behind the fc1 / fc2 units: D * D * 2 more bytes)
 int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st, const void* wproj = nullptr);
+// fc2 column-owned (mlp_co.hip): the same format-1 image; W2 goes L2 -> registers, the hidden tile through LDS.  Image forms (img == 3) only.
+bool hipt_mlp_co_supported(int dtype, int D, int hidden);
+int hipt_mlp_co_launch(const MlpParams& p, hipStream_t st);
 // The wave-specialised form (mlp_ws.hip: 8 waves, fc1 + GELU waves and fc2 waves sharing rows): image format 2.
 bool hipt_mlp_ws_supported(int dtype, int D, int hidden);  // (shapes only; opt-in through hipt_vit_mlp_pack_format)
 int hipt_mlp_ws_launch(const MlpParams& p, hipStream_t st);

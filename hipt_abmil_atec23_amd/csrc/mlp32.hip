@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     int* tile_s = (int*)(b1s + p.hidden);  // [2] tile handed to this workgroup, double-buffered by parity
     float* gam1 = (float*)(tile_s + 4);    // next block's LayerNorm-1 (gamma | beta), if p.xn_out
     float* bps = gam1 + 2 * D;             // proj bias (FOLD)
+    float* pfj = bps + D;                  // [64] where the L2-prefetch loads below drop their dwords (never read)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,9 +154,27 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     };
     auto dma_piece = [&](auto T_) __attribute__((always_inline)) {
         constexpr int t = decltype(T_)::value;
-        if constexpr ((DBG & 1) == 0)
+        if constexpr ((DBG & 1) == 0 && (DBG & 32) == 0)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(smem + islot * UNIT + (12 * wave + (t & ~3)) * 1024), 16, ilane, ioff + (t & ~3) * 1024, (t & 3) * 1024, 0);
     };
+
+    // ---- L2 prefetch of a tile's row-phase inputs.  The row phases are latency: one wave per SIMD waits 4-5 us for 36 KiB from HBM,
+    // twice before the first phase and again in the epilogue (13 + 13 us of a 97 us tile with the matrix pipes idle).  Touching one
+    // dword of every 128-byte line from inside a chunk phase a few microseconds earlier turns those waits into L2 hits.  The loads are
+    // LDS-DMA (no destination register to keep alive), all into one 256-byte scratch line; rows past the tile's end are out of the
+    // resource's range and dropped.  Nine instructions per wave: line (4 k + wave) * 64 + lane of x (k < 6) and of y1 (k < 3).
+    auto prefetch_rows = [&](int t_row0, int t_nrows) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)t_row0 * D), 0, t_nrows * D * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.y1 + (int64_t)t_row0 * D), 0, p.y1 ? t_nrows * D * 2 : 0, 0x00020000);
+        const uint32_t vo = (uint32_t)(wave * 8192 + lane * 128);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (LDS_AS void*)pfj, 4, vo, k * 32768, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (LDS_AS void*)pfj, 4, vo, k * 32768, 0, 0);
+    };
+    constexpr int NRD = (DBG & 16) ? 2 : 4;  // fragment reads per group
+    constexpr int NPF = 9;  // (the counted wait of a phase that prefetches)
 
     for (int i = tid; i < D; i += 256) {
         gam[i] = p.ln_w[i];
@@ -216,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         }
         DSR128(d0, a, (4 * gg + 0) * 1024);
         DSR128(d1, a, (4 * gg + 1) * 1024);
+        if constexpr (DBG & 16) return;  // (ablation: half the fragment reads, the other two MFMAs re-use stale registers)
         DSR128(d2, a, (4 * gg + 2) * 1024);
         DSR128(d3, a, (4 * gg + 3) * 1024);
     };
@@ -248,10 +268,11 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         }
         nrows = (p.M - row0) < nrows ? (p.M - row0) : nrows;
         PSTAMP(0);
-        if (tid == 0) {  // next tile: fetched now, read after this tile's ring barriers
-            const int nt = atomicAdd(p.counter, 1);
-            asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt) : "memory");
-        }
+        // next tile: requested now, handed to LDS behind the first row loads (the atomic's round trip is theirs too), read by every
+        // wave after the first ring barrier
+        int nt_req = 0;
+        if (tid == 0) nt_req = atomicAdd(p.counter, 1);
+        int tile_next = 0, row0_next = 0, nrows_next = 0;
 
         u32x4 X[NKS];  // the fc1 B operand: k-step s = 2 c + p, lane half h: columns 32 c + 16 p + 8 (j >> 2) + 4 h + (j & 3)
 
@@ -279,9 +300,11 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         // GH/GSEC: GELU units of half GH, first (0) or second (1) eight, one per group 4..11; GH = -1: none
         // NB/nb: the NEXT phase is an fc1 phase and starts from the bias at b1s offset nb (read with the cross-phase prefetch).
         //     NB = -1: last phase of the tile, nothing is prefetched (the row phases in between need the registers)
-        auto phase = [&](auto KIND_, auto H_, auto GH_, auto GSEC_, auto NB_, int nb) __attribute__((always_inline)) {
+        //     PF: 1 = this phase also prefetches this tile's rows for the epilogue, 2 = the next tile's rows (groups 5 / 6, behind
+        //     the phase's DMA pieces: the wait at group 11 leaves exactly the NPF prefetch loads in flight)
+        auto phase = [&](auto KIND_, auto H_, auto GH_, auto GSEC_, auto NB_, int nb, auto PF_) __attribute__((always_inline)) {
             constexpr int kind = decltype(KIND_)::value, hh = decltype(H_)::value, gh = decltype(GH_)::value;
-            constexpr int gsec = decltype(GSEC_)::value, needb = decltype(NB_)::value;
+            constexpr int gsec = decltype(GSEC_)::value, needb = decltype(NB_)::value, pf = decltype(PF_)::value;
             const uint32_t sa = fbase + (cons % 3) * UNIT;
             const uint32_t sn = fbase + ((cons + 1) % 3) * UNIT;
             sfor<0, 12>([&](auto G_) __attribute__((always_inline)) {
@@ -290,7 +313,10 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                 // (1) fragment reads one group ahead
                 if constexpr (gg == 11) {
                     if constexpr ((DBG & 1) == 0) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of the next unit have landed
+                        if constexpr (pf != 0)
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPF) : "memory");
+                        else
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of the next unit have landed
                         __builtin_amdgcn_s_barrier();                     // ... everyone's; unit cons-1 is no longer read
                     }
                     set_issue(ipos, (cons + 2) % 3);
@@ -301,14 +327,14 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                         rd_frag(NS{}, I0{}, sn);
                         if constexpr (needb > 0) {
                             bias_rd(nb);
-                            LGKM(12);
+                            LGKM(8 + NRD);
                         } else {
-                            LGKM(4);
+                            LGKM(NRD);
                         }
                     }
                 } else {
                     rd_frag(NS{}, std::integral_constant<int, gg + 1>{}, sa);
-                    LGKM(4);
+                    LGKM(NRD);
                 }
                 // (2) 4 MFMAs, with the vector work that hides under them
                 if constexpr (kind == KA) {
@@ -353,6 +379,8 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                     dma_piece(std::integral_constant<int, 2 + 2 * gg>{});
                     dma_piece(std::integral_constant<int, 3 + 2 * gg>{});
                 }
+                if constexpr (pf == 1 && gg == 5) prefetch_rows(row0, nrows);
+                if constexpr (pf == 2 && gg == 5) prefetch_rows(row0_next, nrows_next);
                 if constexpr (gh >= 0 && gg >= 4) {
                     gelu_unit(std::integral_constant<int, (gh >= 0 ? gh : 0)>{}, std::integral_constant<int, 8 * gsec + gg - 4>{});
                 }
@@ -364,6 +392,13 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         typedef std::integral_constant<int, KA> TA;
         typedef std::integral_constant<int, KB> TB;
         typedef std::integral_constant<int, KP> TP;
+#ifdef MLP32_PREFETCH  // (experiment, off: see prefetch_rows)
+        typedef std::integral_constant<int, 1> PFA;
+        typedef std::integral_constant<int, 2> PFB;
+#else
+        typedef I0 PFA;
+        typedef I0 PFB;
+#endif
 
         // 16-row fragments (chunk g + 4 c of fragments 0 / 1 per lane) -> the 32-row B operand X
         auto to_operand = [&](u32x4 (&af)[2][NCH]) __attribute__((always_inline)) {
@@ -430,7 +465,13 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                         }
                     }
                 }
+                if (HIPT_STAMPS_ON(p.stamps)) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (mf == 0) { PSTAMP(5); } else { PSTAMP(7); }
+                }
+                if (mf == 0 && tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
                 ln_rows_lds<D, NCH>(v, gbase, p.ln_eps, af[mf]);
+                if (mf == 0) PSTAMP(6);
                 if (mf == 0) {
                     // park the finished fragment in the accumulator file (idle during the row phase) while the other one
                     // is loaded and normalised: left alone, hipcc sends it to scratch and the reloads stall the first phase
@@ -442,8 +483,10 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            PSTAMP(12);
             to_operand(af);
         } else {
+            if (tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
             // ---- FOLD: y1 = proj(att) is computed here instead of read.  (1) the attention output tile (bf16 image) is itself
             // an operand: its 16-byte chunks are the fragment layout; (2) six phases on the proj units into acc2 (idle until the
             // first fc2 phase): acc2[O][4 q + e] = column 32 O + 8 q + 4 h + e of this lane's row; (3) v = acc2 + b_proj + x becomes
@@ -487,12 +530,12 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                     for (int q = 0; q < 4; ++q) xa[O][q] = *(const f32x4*)(xl + xlo_ * O + xlq_ * q);
             }
             rd_frag(I0{}, I0{}, fbase + (cons % 3) * UNIT);
-            phase(TP{}, I0{}, IM1{}, I0{}, I0{}, 0);
-            phase(TP{}, I1{}, IM1{}, I0{}, I0{}, 0);
-            phase(TP{}, std::integral_constant<int, 2>{}, IM1{}, I0{}, I0{}, 0);
-            phase(TP{}, std::integral_constant<int, 3>{}, IM1{}, I0{}, I0{}, 0);
-            phase(TP{}, std::integral_constant<int, 4>{}, IM1{}, I0{}, I0{}, 0);
-            phase(TP{}, std::integral_constant<int, 5>{}, IM1{}, I0{}, IM1{}, 0);
+            phase(TP{}, I0{}, IM1{}, I0{}, I0{}, 0, I0{});
+            phase(TP{}, I1{}, IM1{}, I0{}, I0{}, 0, I0{});
+            phase(TP{}, std::integral_constant<int, 2>{}, IM1{}, I0{}, I0{}, 0, I0{});
+            phase(TP{}, std::integral_constant<int, 3>{}, IM1{}, I0{}, I0{}, 0, I0{});
+            phase(TP{}, std::integral_constant<int, 4>{}, IM1{}, I0{}, I0{}, 0, I0{});
+            phase(TP{}, std::integral_constant<int, 5>{}, IM1{}, I0{}, IM1{}, 0, I0{});
             {
 #pragma clang fp contract(off)
                 const float* xl;
@@ -594,16 +637,40 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         bias_rd(0);
         // chunk 0 (peeled: no runtime branches around phases inside the steady-state loop).  Its half-0 GELUs have
         // only A1(0) to hide in: the second eight run bare.
-        phase(TA{}, I0{}, IM1{}, I0{}, I1{}, 64);
-        phase(TA{}, I1{}, I0{}, I0{}, I0{}, 0);
+        phase(TA{}, I0{}, IM1{}, I0{}, I1{}, 64, I0{});
+        phase(TA{}, I1{}, I0{}, I0{}, I0{}, 0, I0{});
         sfor<8, 16>([&](auto U_) __attribute__((always_inline)) { gelu_unit(I0{}, U_); });
         __builtin_amdgcn_sched_barrier(0);
-        phase(TB{}, I0{}, I1{}, I0{}, I1{}, 128);
-        for (int c = 1; c < nchunk; ++c) {
-            phase(TA{}, I0{}, I1{}, I1{}, I0{}, 0);             // A0(c)   + second eight GELUs of half 1 of chunk c-1
-            phase(TB{}, I1{}, I0{}, I0{}, I1{}, c * 128 + 64);  // B1(c-1) + first eight of half 0 of chunk c
-            phase(TA{}, I1{}, I0{}, I1{}, I0{}, 0);             // A1(c)   + second eight of half 0
-            phase(TB{}, I0{}, I1{}, I0{}, I1{}, c + 1 < nchunk ? (c + 1) * 128 : 0);  // B0(c) + first eight of half 1
+        {
+            // the tile after this one (handed over before the first ring barrier): which rows the prefetch below and the next pass
+            // of the loop work on.  The wait also covers the fragments the last phase requested ahead: a few hundred cycles, once a tile
+            int nt;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nt) : "v"(tsbase + 4 * ((seq + 1) & 1)) : "memory");
+            tile_next = __builtin_amdgcn_readfirstlane(nt);
+            if (tile_next < p.full_tiles) {
+                row0_next = tile_next * TMR;
+                nrows_next = TMR;
+            } else {
+                row0_next = p.full_tiles * TMR + (tile_next - p.full_tiles) * 16;
+                nrows_next = 16;
+            }
+            nrows_next = (p.M - row0_next) < nrows_next ? (p.M - row0_next) : nrows_next;
+            nrows_next = (tile_next < p.ntiles && nrows_next > 0) ? nrows_next : 0;  // (no next tile: an empty range, every load dropped)
+            row0_next = nrows_next > 0 ? row0_next : 0;
+        }
+        phase(TB{}, I0{}, I1{}, I0{}, I1{}, 128, I0{});
+        for (int c = 1; c < nchunk - 1; ++c) {
+            phase(TA{}, I0{}, I1{}, I1{}, I0{}, 0, I0{});             // A0(c)   + second eight GELUs of half 1 of chunk c-1
+            phase(TB{}, I1{}, I0{}, I0{}, I1{}, c * 128 + 64, I0{});  // B1(c-1) + first eight of half 0 of chunk c
+            phase(TA{}, I1{}, I0{}, I1{}, I0{}, 0, I0{});             // A1(c)   + second eight of half 0
+            phase(TB{}, I0{}, I1{}, I0{}, I1{}, (c + 1) * 128, I0{});  // B0(c) + first eight of half 1
+        }
+        {   // the last chunk (peeled): its first two phases also request the rows of the epilogue and of the next tile's row phase
+            const int c = nchunk - 1;
+            phase(TA{}, I0{}, I1{}, I1{}, I0{}, 0, PFA{});
+            phase(TB{}, I1{}, I0{}, I0{}, I1{}, c * 128 + 64, PFB{});
+            phase(TA{}, I1{}, I0{}, I1{}, I0{}, 0, I0{});
+            phase(TB{}, I0{}, I1{}, I0{}, I1{}, 0, I0{});
         }
         LGKM(0);  // (the last B0 read a bias nobody uses: let it land before its registers are re-used ...
         {         //  ... and keep those registers allocated up to here: a fake use AFTER the wait)
@@ -613,7 +680,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         // tail: second eight of the last half 1, then B1(last); its prefetch is the next tile's A0(0)
         sfor<8, 16>([&](auto U_) __attribute__((always_inline)) { gelu_unit(I1{}, U_); });
         __builtin_amdgcn_sched_barrier(0);
-        phase(TB{}, I1{}, IM1{}, I0{}, IM1{}, 0);
+        phase(TB{}, I1{}, IM1{}, I0{}, IM1{}, 0, I0{});
         PSTAMP(3);
         if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
 
@@ -722,9 +789,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
             }
         }
         PSTAMP(4);
-        int nt;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nt) : "v"(tsbase + 4 * ((seq + 1) & 1)) : "memory");
-        tile = __builtin_amdgcn_readfirstlane(nt);
+        tile = tile_next;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (continuous stream: pieces of a pass that never runs)
     if (HIPT_STAMPS_ON(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
@@ -754,7 +819,7 @@ int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D_, int hidden, v
 template <int DBG>
 int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     MlpParams p = p_in;
-    const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4 + D * 4;
+    const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4 + D * 4 + 256;
     if (!p.wpk || p.wpk_fmt != 1 || (p.img & 2 && !(p.img & 1)) || (p.img && p.M % 16 != 0) || (p.fold && (!(p.img & 1) || !p.y1 || !p.bproj))) {
         hipt_set_error("mlp32: needs its packed weights; activation images need M %% 16 == 0 and img in {0, 1, 3}; fold needs images (img=%d, M=%d, fold=%d)", p.img,
                        p.M, p.fold);
@@ -823,15 +888,18 @@ int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
             if (h[b * 16 + 11] < t0) t0 = h[b * 16 + 11];
             if (h[b * 16 + 10] > t4) t4 = h[b * 16 + 10];
         }
-        double pro = 0, chunks = 0, epi = 0, ghz = 0;
+        double pro = 0, chunks = 0, epi = 0, ghz = 0, pp[5] = {0, 0, 0, 0, 0};
         for (int b = 0; b < grid; ++b) {
             pro += (double)(h[b * 16 + 2] - h[b * 16 + 0]) * 0.01 / grid;
             chunks += (double)(h[b * 16 + 3] - h[b * 16 + 2]) * 0.01 / grid;
             epi += (double)(h[b * 16 + 4] - h[b * 16 + 3]) * 0.01 / grid;
+            const int ix[6] = {0, 5, 6, 7, 12, 2};
+            for (int i = 0; i < 5; ++i) pp[i] += (double)(h[b * 16 + ix[i + 1]] - h[b * 16 + ix[i]]) * 0.01 / grid;
             ghz += (double)(h[b * 16 + 9] - h[b * 16 + 8]) / (double)(h[b * 16 + 3] - h[b * 16 + 2]) * 0.1 / grid;
         }
         fprintf(stderr, "[mlp32 dbg=%d hidden=%d grid=%d tiles=%d(+%d)] total %.1f us | tile %d of each workgroup: rows+LN %.1f, chunks %.1f (%.2f GHz), epilogue %.1f\n",
                 DBG, p.hidden, grid, p.full_tiles, p.ntiles - p.full_tiles, (double)(t4 - t0) * 0.01, PSTAMP_SEQ, pro, chunks, ghz, epi);
+        if (!p.fold) fprintf(stderr, "    rows+LN: loads 0 %.1f, LN 0 %.1f, loads 1 %.1f, LN 1 %.1f, to operand %.1f\n", pp[0], pp[1], pp[2], pp[3], pp[4]);
     }
 #endif
     return HIPT_OK;

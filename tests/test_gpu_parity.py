@@ -403,6 +403,29 @@ def test_vit256_experimental_wave_specialised_mlp(vit256, monkeypatch):
     assert torch.equal(ws[1:4], ws_sub)
 
 
+def test_vit256_experimental_column_owned_mlp(vit256, monkeypatch):
+    """csrc/mlp_co.hip (HIPT_MLP_CO=1, read per launch; same format-1 weight image): fc2 column-owned -- W2 fragments go L2 ->
+    registers and feed four MFMAs each, the GELU'd hidden tile is exchanged through LDS.  Its x is the default kernel's bit for
+    bit (same products in the same order); the chained LayerNorm sums a row across four waves, so the features differ in the
+    last bits only.  Bitwise against itself under a different batching."""
+    if os.environ.get("HIPT_NO_PREPACK") or os.environ.get("HIPT_NO_MLP32") or os.environ.get("HIPT_MLP_WS"):
+        pytest.skip("needs the default (format 1) weight images")
+    x = synth.hash_uniform_torch((32, 3, 256, 256), 37, device=DEV)  # (activation images need rows % 16 == 0: 16 | patches)
+    vit256.set_compute_dtype("bf16")
+    try:
+        base = vit256(x)
+        monkeypatch.setenv("HIPT_MLP_CO", "1")
+        co = vit256(x)
+        co_sub = vit256(x[8:24])
+    finally:
+        monkeypatch.delenv("HIPT_MLP_CO", raising=False)
+        vit256.set_compute_dtype("fp32")
+    rel = float((co - base).norm() / base.norm())
+    print(f"column-owned fused MLP vs the default kernel: rel-L2 {rel:.2e}")
+    assert 0 < rel < 5e-3  # (0 would mean the switch did nothing)
+    assert torch.equal(co[8:24], co_sub)
+
+
 def test_vit256_patch_embedding_from_fp32_pixels(vit256, monkeypatch):
     """csrc/embed32.hip reads the fp32 image itself (pixels rounded to bf16 in registers, weights through the LDS-DMA ring); the
     round-1 path (HIPT_NO_EMBED32=1) makes a bf16 copy of the image and runs the generic GEMM over an im2col view.  Same bf16

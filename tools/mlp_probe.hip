@@ -16,6 +16,10 @@ int hipt_mlp_pipe_launch(const MlpParams&, hipStream_t) { return -1; }
 #include "../hipt_abmil_atec23_amd/csrc/mlp_ws.hip"
 #define LAUNCH(DBG, p) hipt_mlp_ws_launch_dbg<DBG>(p, 0)
 #define hipt_mlp_pack_launch hipt_mlp_ws_pack_launch
+#elif defined(PROBE_CO)  // fc2 column-owned (mlp_co.hip); -DPROBE_CO, link hipt_abmil_atec23_amd/csrc/build/mlp32.o for the pack kernel
+#include "../hipt_abmil_atec23_amd/csrc/mlp_co.hip"
+#define LAUNCH(DBG, p) hipt_mlp_co_launch(p, 0)
+#define hipt_mlp_pack_launch hipt_mlp32_pack_launch
 #elif defined(PROBE_32)  // the 32x32x16 form (mlp32.hip); -DPROBE_32
 #include "../hipt_abmil_atec23_amd/csrc/mlp32.hip"
 #define LAUNCH(DBG, p) hipt_mlp32_launch_dbg<DBG>(p, 0)
@@ -69,6 +73,11 @@ static float bf2f(uint16_t b) {
     return f;
 }
 
+#ifdef PROBE_CO
+// activation images (kernels.h): 16-row fragments; fp32: col 32 O + 8 q + 4 h + e of row li at 512 O + 256 h + 64 q + 4 li + e; bf16: 512 O + 128 q + 8 li + 4 h + e
+static size_t img_f32(int r, int c) { const int f = r / 16, li = r % 16, O = c / 32, q = (c / 8) & 3, h = (c / 4) & 1, e = c & 3; return (size_t)f * 16 * 384 + 512 * O + 256 * h + 64 * q + 4 * li + e; }
+static size_t img_bf16(int r, int c) { const int f = r / 16, li = r % 16, O = c / 32, q = (c / 8) & 3, h = (c / 4) & 1, e = c & 3; return (size_t)f * 16 * 384 + 512 * O + 128 * q + 8 * li + 4 * h + e; }
+#endif
 int main(int argc, char** argv) {
     // "check [M]": one launch on M rows (default 514), compared with an fp64 host evaluation of the same bf16 operands
     const bool check = argc > 1 && (strcmp(argv[1], "check") == 0 || strcmp(argv[1], "checkfold") == 0);
@@ -96,8 +105,20 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&b2, D * 4));
     CK(hipMalloc(&g, D * 4));
     CK(hipMalloc(&bt, D * 4));
+#ifdef PROBE_CO
+    std::vector<float> hxi(hx.size());
+    std::vector<uint16_t> hyi(hy.size());
+    for (int r = 0; r < M; ++r)
+        for (int c = 0; c < D; ++c) {
+            hxi[img_f32(r, c)] = hx[(size_t)r * D + c];
+            hyi[img_bf16(r, c)] = hy[(size_t)r * D + c];
+        }
+    CK(hipMemcpy(x, hxi.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(y, hyi.data(), hy.size() * 2, hipMemcpyHostToDevice));
+#else
     CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(y, hy.data(), hy.size() * 2, hipMemcpyHostToDevice));
+#endif
     CK(hipMemcpy(w1, hw1.data(), hw1.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(w2, hw2.data(), hw2.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(b1, hb1.data(), H * 4, hipMemcpyHostToDevice));
@@ -113,13 +134,18 @@ int main(int argc, char** argv) {
         if (hipt_mlp_pack_launch(w1, w2, D, H, pk, 0) != 0) { printf("pack failed\n"); return 1; }
         CK(hipDeviceSynchronize());
         p.wpk = pk;
-#ifdef PROBE_32
+#if defined(PROBE_32) || defined(PROBE_CO)
         p.wpk_fmt = 1;
 #endif
 #ifdef PROBE_WS
         p.wpk_fmt = 2;
 #endif
     }
+#endif
+#ifdef PROBE_CO
+    void* xn_co;
+    CK(hipMalloc(&xn_co, hy.size() * 2));
+    p.img = 3; p.xn_out = xn_co; p.ln_next_w = (float*)g; p.ln_next_b = (float*)bt;
 #endif
     if (getenv("PROBE_IMG") && !check) {  // as inside the pipeline: activation images + the next block's LayerNorm-1 output
         void* xn;
@@ -197,6 +223,16 @@ int main(int argc, char** argv) {
         CK(hipDeviceSynchronize());
         std::vector<float> out((size_t)M * D);
         CK(hipMemcpy(out.data(), x, out.size() * 4, hipMemcpyDeviceToHost));
+#ifdef PROBE_CO
+        std::vector<uint16_t> hxn((size_t)M * D);
+        CK(hipMemcpy(hxn.data(), xn_co, hxn.size() * 2, hipMemcpyDeviceToHost));
+        {
+            std::vector<float> t(out);
+            for (int r = 0; r < M; ++r)
+                for (int c = 0; c < D; ++c) out[(size_t)r * D + c] = t[img_f32(r, c)];
+        }
+        double maxerr_n = 0;
+#endif
         double maxerr = 0;
         long nbad = 0, nnan = 0;
         int first_bad_row = -1, first_bad_col = -1;
@@ -223,7 +259,27 @@ int main(int argc, char** argv) {
                 if (e > maxerr) maxerr = e;
                 if (e > 2e-2) { ++nbad; if (first_bad_row < 0) { first_bad_row = r; first_bad_col = n; } }
             }
+#ifdef PROBE_CO
+            {   // the chained LayerNorm of the next block, from the kernel's own fp32 output
+                double mu = 0, va = 0;
+                for (int n = 0; n < D; ++n) mu += out[(size_t)r * D + n];
+                mu /= D;
+                for (int n = 0; n < D; ++n) va += (out[(size_t)r * D + n] - mu) * (out[(size_t)r * D + n] - mu);
+                const double rs = 1.0 / sqrt(va / D + 1e-6);
+                for (int n = 0; n < D; ++n) {
+                    const double ref = (out[(size_t)r * D + n] - mu) * rs * hg[n] + hbt[n];
+                    const double e = fabs(bf2f(hxn[img_bf16(r, n)]) - ref);
+                    if (e > maxerr_n) maxerr_n = e;
+                    if (!(e <= 4e-2)) { ++nbad; if (first_bad_row < 0) { first_bad_row = r; first_bad_col = 1000 + n; } }
+                }
+            }
+#endif
         }
+#ifdef PROBE_CO
+        printf("chained LayerNorm: max |err| %.3e\n", maxerr_n);
+        return (nbad || nnan) ? (printf("check M=%d: max |err| %.3e, %ld bad, %ld NaN, first (row %d, col %d)\n", M, maxerr, nbad, nnan, first_bad_row, first_bad_col), 1)
+                              : (printf("check M=%d: max |err| %.3e OK\n", M, maxerr), 0);
+#endif
         {   // batch invariance: the same rows at a different position inside the tiles must give the same bits
             const int sh = argc > 3 ? atoi(argv[3]) : 12;
             CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
@@ -254,6 +310,9 @@ int main(int argc, char** argv) {
     std::vector<int> masks;
     for (int i = 2; i < argc; ++i) masks.push_back(atoi(argv[i]));
     if (masks.empty()) masks = {0, 1, 2, 3, 4, 5, 6, 7};
+#if defined(PROBE_CO)
+    masks = {0};
+#endif
 #if defined(PROBE_32) || defined(PROBE_WS)
     masks.push_back(8);
     masks.push_back(12);
@@ -272,6 +331,12 @@ int main(int argc, char** argv) {
             case 8: run<8>(p, iters); break;
             case 12: run<12>(p, iters); break;
             case 15: run<15>(p, iters); break;
+#endif
+#ifdef PROBE_32
+            case 16: run<16>(p, iters); break;
+            case 32: run<32>(p, iters); break;
+            case 48: run<48>(p, iters); break;
+            case 18: run<18>(p, iters); break;
 #endif
 #ifdef PROBE_WS
             case 16: run<16>(p, iters); break;
