@@ -153,6 +153,9 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     // with them, q | k | v leave the QKV GEMM head-major (the attention kernel's K / V staging reads consecutive bytes)
     const bool hm = img && (int64_t)M * 3 * D * 2 < ((int64_t)1 << 32) - 65536 && getenv("HIPT_NO_QKV_HM") == nullptr;
     bool x_img = false;
+    // the tile queues of the pipelined kernels (three ints in the unused hidden slot) reset themselves at the end of a launch:
+    // zeroed once here instead of before each of the ~44 launches (5 us each on the stream: 3 % of a one-region forward)
+    const bool qz = seq && chain && getenv("HIPT_QUEUE_MEMSET") == nullptr && hipMemsetAsync(s.hid, 0, 48 * sizeof(int), st) == hipSuccess;
     for (int i = b0; i < b1; ++i) {
         const hipt_block_weights& b = w->blocks[i];
         const bool last_probs = probs != nullptr && i == b1 - 1;
@@ -167,6 +170,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             q.out = s.qkv; q.ldc = 3 * D;
             // (the hidden tensor is never materialised on this path: its slot holds the kernels' tile queues)
             q.counter = (int*)s.hid + 16;
+            q.counter_zeroed = qz ? 1 : 0;
             q.out_ntok = w->ntok;
             if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue
                 q.A = s.att; q.ln_w = q.ln_b = nullptr;
@@ -198,6 +202,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             m.fold = fold ? 1 : 0; m.bproj = b.proj_b;
             m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.wpk_fmt = b.mlp_pk_fmt; m.M = M; m.D = D; m.hidden = w->hidden;
             m.counter = (int*)s.hid;
+            m.counter_zeroed = qz ? 1 : 0;
             have_xn = chain && (i + 1 < b1 || emit_last) && i + 1 < w->depth;
             if (have_xn) {
                 m.ln_next_w = w->blocks[i + 1].ln1_w;

@@ -76,6 +76,7 @@ struct SeqGemmParams {
     void* out;           // bf16 [M, ldc]
     int64_t ldc;
     int* counter;        // (pipelined kernel) device int the launcher zeroes on the stream: the tile queue
+    int counter_zeroed;  // 1: the caller guarantees *counter == 0 at launch (seqgemm_pipe.hip skips its memset); the kernel leaves it 0 again
     int ntiles;          // (set by the launcher)
 };
 bool hipt_seqgemm_supported(int dtype, int K);
@@ -104,6 +105,7 @@ struct MlpParams {
     int wpk_fmt;         // format of wpk: 0 = mlp_pipe.hip's ring image, 1 = mlp32.hip's fragment image, 2 = mlp_ws.hip's step image
     int img;             // (pipelined kernel only) activation images: bit 0 = y1, xn_out and the updated x, bit 1 = x on entry
     int* counter;        // device int the launcher zeroes on the stream: the kernel's tile queue
+    int counter_zeroed;  // 1: the caller guarantees *counter == 0 at launch (mlp32.hip / mlp_co.hip skip their memset); these kernels leave it 0 again
     // optional (pipelined kernel only): LayerNorm-1 of the NEXT block applied to the updated rows, written as bf16
     // [M, D] -- the next block's QKV GEMM then loads operands directly instead of fp32 rows + LayerNorm
     const float* ln_next_w;

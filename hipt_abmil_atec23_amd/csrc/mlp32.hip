@@ -187,7 +187,14 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         if constexpr (FOLD) bps[i] = p.bproj[i];
     }
     for (int i = tid; i < p.hidden; i += 256) b1s[i] = p.b1[i];
-    if (tid == 0) tile_s[0] = atomicAdd(p.counter, 1);
+    // (the tile queue resets itself: a launch makes grid + ntiles fetches, the one that draws the last number stores 0 -- nobody
+    //  fetches after it -- so that a caller running a chain of these kernels zeroes the counter once, not once per launch)
+    const int last_fetch = p.ntiles + (int)gridDim.x - 1;
+    if (tid == 0) {
+        const int t0 = atomicAdd(p.counter, 1);
+        if (t0 == last_fetch) *p.counter = 0;
+        tile_s[0] = t0;
+    }
     __syncthreads();
     int tile = __builtin_amdgcn_readfirstlane(tile_s[0]);
     if (HIPT_STAMPS_ON(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
@@ -268,6 +275,10 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         }
         nrows = (p.M - row0) < nrows ? (p.M - row0) : nrows;
         PSTAMP(0);
+        if (p.stagger < 0) {  // (experiment, HIPT_MLP_IDLE_US: every tile starts with an idle wait -- is the kernel's time additive, or does the power cap give it back?)
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(-p.stagger)) __builtin_amdgcn_s_sleep(64);
+        }
         // next tile: requested now, handed to LDS behind the first row loads (the atomic's round trip is theirs too), read by every
         // wave after the first ring barrier
         int nt_req = 0;
@@ -469,7 +480,10 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (mf == 0) { PSTAMP(5); } else { PSTAMP(7); }
                 }
-                if (mf == 0 && tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
+                if (mf == 0 && tid == 0) {
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
+                    if (nt_req == last_fetch) *p.counter = 0;
+                }
                 ln_rows_lds<D, NCH>(v, gbase, p.ln_eps, af[mf]);
                 if (mf == 0) PSTAMP(6);
                 if (mf == 0) {
@@ -486,7 +500,10 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
             PSTAMP(12);
             to_operand(af);
         } else {
-            if (tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
+            if (tid == 0) {
+                asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
+                if (nt_req == last_fetch) *p.counter = 0;
+            }
             // ---- FOLD: y1 = proj(att) is computed here instead of read.  (1) the attention output tile (bf16 image) is itself
             // an operand: its 16-byte chunks are the fragment layout; (2) six phases on the proj units into acc2 (idle until the
             // first fc2 phase): acc2[O][4 q + e] = column 32 O + 8 q + 4 h + e of this lane's row; (3) v = acc2 + b_proj + x becomes
@@ -863,7 +880,9 @@ int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     static const char* stag_env = getenv("HIPT_MLP_STAGGER_US");
     const int stag_us = stag_env ? atoi(stag_env) : 0;
     p.stagger = (p.full_tiles >= 6 * ncu) ? stag_us * 100 : 0;
-    if (hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
+    static const char* idle_env = getenv("HIPT_MLP_IDLE_US");
+    if (idle_env) p.stagger = -atoi(idle_env) * 100;
+    if (!p.counter_zeroed && hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
         hipt_set_error("mlp32: hipMemsetAsync(counter) failed");
         return HIPT_E_LAUNCH;
     }

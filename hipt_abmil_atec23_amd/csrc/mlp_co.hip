@@ -94,7 +94,14 @@ __global__ __launch_bounds__(256, 1) void mlp_co_kernel(const MlpParams p) {
         }
     }
     for (int i = tid; i < p.hidden; i += 256) b1s[i] = p.b1[i];
-    if (tid == 0) tile_s[0] = atomicAdd(p.counter, 1);
+    // (the tile queue resets itself: a launch makes grid + ntiles fetches, the one that draws the last number stores 0 -- nobody
+    //  fetches after it -- so that a caller running a chain of these kernels zeroes the counter once, not once per launch)
+    const int last_fetch = p.ntiles + (int)gridDim.x - 1;
+    if (tid == 0) {
+        const int t0 = atomicAdd(p.counter, 1);
+        if (t0 == last_fetch) *p.counter = 0;
+        tile_s[0] = t0;
+    }
     __syncthreads();
     int tile = __builtin_amdgcn_readfirstlane(tile_s[0]);
     if (HIPT_STAMPS_ON(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
@@ -311,7 +318,10 @@ __global__ __launch_bounds__(256, 1) void mlp_co_kernel(const MlpParams p) {
                         }
                     }
                 }
-                if (mf == 0 && tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
+                if (mf == 0 && tid == 0) {
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
+                    if (nt_req == last_fetch) *p.counter = 0;
+                }
                 ln_rows_lds<D, NCH>(v, gbase, p.ln_eps, af[mf]);
                 if (mf == 0) {
 #pragma unroll
@@ -568,7 +578,7 @@ int hipt_mlp_co_launch(const MlpParams& p_in, hipStream_t st) {
     p.ntiles = p.full_tiles + (tail_rows > 0 ? (tail_rows + 15) / 16 : 0);
     const int grid = p.ntiles < ncu ? p.ntiles : ncu;
     p.stagger = 0;
-    if (hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
+    if (!p.counter_zeroed && hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
         hipt_set_error("mlp_co: hipMemsetAsync(counter) failed");
         return HIPT_E_LAUNCH;
     }

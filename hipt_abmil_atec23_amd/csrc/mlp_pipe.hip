@@ -667,6 +667,8 @@ int hipt_mlp_pipe_launch_dbg(const MlpParams& p_in, hipStream_t st) {
 #endif
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
     HIPT_CHECK_LAUNCH();
+    // (a caller that zeroes the queue once for a chain of launches -- MlpParams::counter_zeroed -- gets it back zero: this kernel's queue does not reset itself)
+    if (p.counter_zeroed) (void)hipMemsetAsync(p.counter, 0, sizeof(int), st);
 #ifdef HIPT_DEBUG_STAMPS
     if (want_stamps && grid <= 4096) {
         static unsigned long long h[4096 * 16];

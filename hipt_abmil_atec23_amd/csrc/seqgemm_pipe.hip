@@ -102,7 +102,14 @@ __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParam
             bet[i] = p.ln_b[i];
         }
     }
-    if (tid == 0) tile_s[0] = atomicAdd(p.counter, 1);
+    // (the tile queue resets itself: a launch makes grid + ntiles fetches, the one that draws the last number stores 0 -- nobody
+    //  fetches after it -- so that a caller running a chain of these kernels zeroes the counter once, not once per launch)
+    const int last_fetch = p.ntiles + (int)gridDim.x - 1;
+    if (tid == 0) {
+        const int t0 = atomicAdd(p.counter, 1);
+        if (t0 == last_fetch) *p.counter = 0;
+        tile_s[0] = t0;
+    }
     __syncthreads();
     int tile = __builtin_amdgcn_readfirstlane(tile_s[0]);
     if (HIPT_STAMPS_ON(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
@@ -166,6 +173,7 @@ __global__ __launch_bounds__(256, 1) void seqgemm_pipe_kernel(const SeqGemmParam
         if (tid == 0) {  // next tile: fetched now, read after this tile's ring barriers
             const int nt = atomicAdd(p.counter, 1);
             asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt) : "memory");
+            if (nt == last_fetch) *p.counter = 0;
         }
         // this tile's output window: rows beyond nrows are outside the buffer -> their stores are dropped
         const __amdgpu_buffer_rsrc_t orsrc =
@@ -455,7 +463,7 @@ int hipt_seqgemm_pipe_launch_dbg(const SeqGemmParams& p_in, hipStream_t st) {
     const int ncu = once.ncu[dev];
     p.ntiles = (p.M + TMR - 1) / TMR;
     const int grid = p.ntiles < ncu ? p.ntiles : ncu;
-    if (hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
+    if (!p.counter_zeroed && hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
         hipt_set_error("seqgemm_pipe: hipMemsetAsync(counter) failed");
         return HIPT_E_LAUNCH;
     }
