@@ -312,7 +312,10 @@ int embed256(const hipt_vit_weights* w, const void* img, const hipt_image_layout
 }
 
 // may the embedding read fp32 pixels itself (embed32.hip)?  `slot` bytes are available for its packed weight + tile queue
-static bool embed_fused_ok(const hipt_vit_weights* w, const void* images, const hipt_image_layout* lay, size_t slot) {
+static bool embed_fused_ok(const hipt_vit_weights* w, const void* images, const hipt_image_layout* lay, size_t slot, int kind = 0) {
+    // (uint8: 8-byte pixel runs; interleaved tensors are whole [n, W, H, 3] images: batch_stride = 3 * chan_stride)
+    if (kind != 0 && (lay->row_stride % 8 != 0 || lay->chan_stride % 8 != 0 || lay->batch_stride != 3 * lay->chan_stride || getenv("HIPT_NO_EMBED32_U8") != nullptr))
+        return false;
     return lay->patch_w % 16 == 0 && lay->patch_h % 16 == 0 &&
            hipt_embed32_supported(w->dtype, w->dim, w->embed_k, lay->patch_h / 16, lay->patch_w / 16) &&
            w->ntok == (lay->patch_h / 16) * (lay->patch_w / 16) + 1 && slot >= hipt_embed32_packed_bytes() + 256 && ((uintptr_t)images % 16) == 0 &&
@@ -320,11 +323,12 @@ static bool embed_fused_ok(const hipt_vit_weights* w, const void* images, const 
 }
 
 // the same from the fp32 image itself (embed32.hip): `wpk` = the packed Conv2d weight, `counter` = the kernel's tile queue
-int embed256_f32(const hipt_vit_weights* w, const float* img, const hipt_image_layout* lay, int seq0, int nseq, float* x, const void* wpk,
-                 int* counter, hipStream_t st) {
+int embed256_f32(const hipt_vit_weights* w, const void* img, const hipt_image_layout* lay, int seq0, int nseq, float* x, const void* wpk,
+                 int* counter, hipStream_t st, int kind = 0) {
     EmbedParams p;
     memset(&p, 0, sizeof(p));
     p.img = img;
+    p.kind = kind;
     p.im = *lay;
     p.nty = lay->patch_h / 16;
     p.ntx = lay->patch_w / 16;
@@ -608,7 +612,7 @@ static size_t image_extra_bytes(const hipt_vit_weights* w, const hipt_image_layo
 // out[i] = [CLS] feature of sequence seq0 + i.  Scratch: the residual stream of one chunk + its block scratch.
 // (embed_pk != null: `img` is the fp32 image and the embedding reads it directly -- embed32.hip; the tile queue sits behind the image)
 static int vit256_range_impl(const hipt_vit_weights* w, const void* img, const hipt_image_layout* lay, int seq0, int nseq, int chunk, float* out,
-                             void* workspace, size_t ws_bytes, hipStream_t st, const void* embed_pk = nullptr) {
+                             void* workspace, size_t ws_bytes, hipStream_t st, const void* embed_pk = nullptr, int embed_kind = 0) {
     int rc;
     if (chunk <= 0) chunk = default_chunk(nseq);
     if (chunk > nseq) chunk = nseq;
@@ -622,7 +626,7 @@ static int vit256_range_impl(const hipt_vit_weights* w, const void* img, const h
     for (int s0 = 0; s0 < nseq; s0 += chunk) {
         const int n = nseq - s0 < chunk ? nseq - s0 : chunk;
         if (embed_pk) {
-            if ((rc = embed256_f32(w, (const float*)img, lay, seq0 + s0, n, x, embed_pk, (int*)((char*)embed_pk + hipt_embed32_packed_bytes()), st))) return rc;
+            if ((rc = embed256_f32(w, img, lay, seq0 + s0, n, x, embed_pk, (int*)((char*)embed_pk + hipt_embed32_packed_bytes()), st, embed_kind))) return rc;
         } else if ((rc = embed256(w, img, lay, seq0 + s0, n, x, st))) {
             return rc;
         }
@@ -685,10 +689,11 @@ static int vit256_forward_impl(const hipt_vit_weights* w, const void* images, in
     const void* img = images;
     // fp32 pixels, bf16 model, 256 x 256 patches: the embedding kernel reads the image itself; the slot of the bf16 copy holds its
     // packed weight (made here: 0.6 MB, a few microseconds) and its tile queue instead
-    if (kind == IMG_F32 && embed_fused_ok(w, images, lay, nimg)) {
+    // (uint8 RGB, planar or interleaved: the same kernel normalises in registers -- no device copy of the image at all)
+    if (embed_fused_ok(w, images, lay, nimg, kind)) {
         void* pk = (char*)workspace + nrange;
         if ((rc = hipt_embed32_pack_launch(w->embed_w, pk, st))) return rc;
-        return vit256_range_impl(w, images, lay, 0, nseq, chunk, out, workspace, nrange, st, pk);
+        return vit256_range_impl(w, images, lay, 0, nseq, chunk, out, workspace, nrange, st, pk, kind);
     }
     if ((rc = image_to_compute(w, images, kind, lay, nseq, (char*)workspace + nrange, &img, st))) return rc;
     return vit256_range_impl(w, img, lay, 0, nseq, chunk, out, workspace, nrange, st);

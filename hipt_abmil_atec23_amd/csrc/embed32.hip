@@ -17,6 +17,12 @@
 //     a phase requests its quarter AFTER its last DMA piece (group 5) and waits with vmcnt(8) at its end -- the pieces have
 //     landed, the eight pixel loads may still be in flight; they are rounded to bf16 in the middle of the NEXT phase.
 //   * epilogue: + bias + pos, fp32 rows 1 + t of the sequence (row 0, the [CLS] slot, is written by cls_init).
+//   * KIND 1 / 2: the image is uint8 RGB, planar or interleaved (what a decoded slide tile is: a quarter of the bytes over PCIe
+//     and HBM).  ToTensor + Normalize(0.5, 0.5) happen in registers: a lane's 8 pixels of a row are 8 consecutive bytes (planar) or,
+//     with all three channels, 24 (interleaved: every channel's phase re-reads the run and keeps its own bytes);
+//     bf16((b / 255 - 0.5) / 0.5) -- the reference's arithmetic, hipt_model_utils.py:113-118 -- equals bf16(fma(b, 2/255, -1)) for every one of
+//     the 256 byte values with 2/255 rounded to 0x3c008081 (tests/test_host_and_abi.py checks all of them), so the two divisions
+//     become one v_cvt_f32_ubyte + one v_fma_f32 per pixel and the tokens are the bits of the float path.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -44,6 +50,7 @@ __global__ void embed32_pack_kernel(const bf16_t* __restrict__ w, u32x4* __restr
     out[i] = *(const u32x4*)(w + (int64_t)(32 * O + j) * (NCHN * KPC) + KPC * c + 16 * r + 8 * h);
 }
 
+template <int KIND>
 __global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bs = (float*)(smem + 3 * UNIT);  // bias [D]
@@ -77,33 +84,79 @@ __global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
     const uint32_t bbase = (uint32_t)(uintptr_t)(LDS_AS char*)bs + 16 * h;          // bias[32 O + 8 q + 4 h ..]: + (32 O + 8 q) * 4
     const uint32_t tsbase = (uint32_t)(uintptr_t)(LDS_AS char*)tile_s;
 
-    // this lane's pixel row 0, columns 8 h .. of channel 0 for tile t (hipt_image_layout: include/hipt_abmil.h)
+    // this lane's pixel row 0, columns 8 h .. of channel 0 for tile t (hipt_image_layout: include/hipt_abmil.h), as an ELEMENT offset
+    // (fp32 / planar uint8: elements of the tensor; interleaved: pixels -- 3 bytes each)
+    typedef typename std::conditional<KIND == 0, float, uint8_t>::type pix_t;
+    const pix_t* img = (const pix_t*)p.img;
+    const int64_t plane = p.im.batch_stride / 3;  // (interleaved: pixels per image)
     auto pix_base = [&](int t) __attribute__((always_inline)) {
         const int b = p.seq0 + t / tps, ty = (t % tps) * 8 + 2 * wave + m;
         const int gsz = p.im.grid_w * p.im.grid_h, bi = b / gsz, s = b % gsz, p1 = s / p.im.grid_h, p2 = s % p.im.grid_h;
-        return p.img + (int64_t)bi * p.im.batch_stride + (int64_t)(p1 * p.im.patch_h + ty * 16) * p.im.row_stride + p2 * p.im.patch_w + li * 16 + 8 * h;
+        const int64_t inimg = (int64_t)(p1 * p.im.patch_h + ty * 16) * p.im.row_stride + p2 * p.im.patch_w + li * 16 + 8 * h;
+        if constexpr (KIND == 2) return img + ((int64_t)bi * plane + inimg) * 3;
+        else return img + (int64_t)bi * p.im.batch_stride + inimg;
     };
 
     u32x4 X[NCHN][16];  // operand fragments: channel c, k-step r (pixel row): the lane's 8 pixels as bf16
-    f32x4 raw[8];       // a quarter of a channel in flight: pixel rows 4 j .. 4 j + 3, two 16-byte pieces each
-    auto load_quarter = [&](const float* base, auto C_, auto J_) __attribute__((always_inline)) {
+    // a quarter of a channel in flight: pixel rows 4 j .. 4 j + 3.  fp32: two 16-byte pieces per row; uint8 planar: one 8-byte piece;
+    // interleaved: the 24 bytes of the 8 pixels' three channels
+    constexpr int RAWN = KIND == 0 ? 8 : (KIND == 1 ? 2 : 6);  // 16-byte registers
+    constexpr int NLD = KIND == 0 ? 8 : (KIND == 1 ? 4 : 12);  // load instructions per quarter (the counted wait of a phase)
+    u32x4 raw[RAWN];
+    auto load_quarter = [&](const pix_t* base, auto C_, auto J_) __attribute__((always_inline)) {
         constexpr int c = decltype(C_)::value, j = decltype(J_)::value;
-        const float* q = base + (int64_t)c * p.im.chan_stride + (int64_t)(4 * j) * p.im.row_stride;
+        if constexpr (KIND == 0) {
+            const float* q = (const float*)base + (int64_t)c * p.im.chan_stride + (int64_t)(4 * j) * p.im.row_stride;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            raw[2 * t] = *(const f32x4*)(q + (int64_t)t * p.im.row_stride);
-            raw[2 * t + 1] = *(const f32x4*)(q + (int64_t)t * p.im.row_stride + 4);
+            for (int t = 0; t < 4; ++t) {
+                raw[2 * t] = *(const u32x4*)(q + (int64_t)t * p.im.row_stride);
+                raw[2 * t + 1] = *(const u32x4*)(q + (int64_t)t * p.im.row_stride + 4);
+            }
+        } else if constexpr (KIND == 1) {
+            const uint8_t* q = (const uint8_t*)base + (int64_t)c * p.im.chan_stride + (int64_t)(4 * j) * p.im.row_stride;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const u32x2 w = *(const u32x2*)(q + (int64_t)t * p.im.row_stride);
+                raw[t >> 1][2 * (t & 1)] = w[0];
+                raw[t >> 1][2 * (t & 1) + 1] = w[1];
+            }
+        } else {
+            const uint8_t* q = (const uint8_t*)base + (int64_t)(4 * j) * p.im.row_stride * 3;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const u32x2 w = *(const u32x2*)(q + (int64_t)t * p.im.row_stride * 3 + 8 * k);
+                    const int d = 6 * t + 2 * k;  // dword index of the quarter's 24 dwords
+                    raw[d >> 2][d & 3] = w[0];
+                    raw[(d + 1) >> 2][(d + 1) & 3] = w[1];
+                }
         }
     };
     auto cvt_quarter = [&](auto C_, auto J_) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
         constexpr int c = decltype(C_)::value, j = decltype(J_)::value;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             u32x4 o;
-            o[0] = pack_bf16x2(raw[2 * t][0], raw[2 * t][1]);
-            o[1] = pack_bf16x2(raw[2 * t][2], raw[2 * t][3]);
-            o[2] = pack_bf16x2(raw[2 * t + 1][0], raw[2 * t + 1][1]);
-            o[3] = pack_bf16x2(raw[2 * t + 1][2], raw[2 * t + 1][3]);
+            if constexpr (KIND == 0) {
+                const f32x4 r0 = __builtin_bit_cast(f32x4, raw[2 * t]), r1 = __builtin_bit_cast(f32x4, raw[2 * t + 1]);
+                o[0] = pack_bf16x2(r0[0], r0[1]);
+                o[1] = pack_bf16x2(r0[2], r0[3]);
+                o[2] = pack_bf16x2(r1[0], r1[1]);
+                o[3] = pack_bf16x2(r1[2], r1[3]);
+            } else {
+                // pixel i of row t: byte i of its 8 (planar) / byte 3 i + c of its 24 (interleaved)
+                float f[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int byte = KIND == 1 ? 8 * t + i : 24 * t + 3 * i + c;  // within the quarter's bytes
+                    const uint32_t w = raw[byte >> 4][(byte >> 2) & 3];
+                    f[i] = __builtin_fmaf((float)((w >> (8 * (byte & 3))) & 0xffu), __builtin_bit_cast(float, 0x3c008081u), -1.0f);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
+            }
             X[c][4 * j + t] = o;
         }
     };
@@ -112,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
 
     // ---- prime: ring units 0 and 1; channels 0 and 1 of the first tile (the only pixels this workgroup ever waits for) ----
     int cons = 0;  // units consumed since kernel start (slot = cons % 3)
-    const float* base_cur = p.img;
+    const pix_t* base_cur = img;
     if (tile < p.ntiles) {
         set_issue(0, 0);
         sfor<0, 12>(dma_piece);
@@ -151,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
         for (int o = 0; o < NOT; ++o)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[o][e] = 0.f;
-        const float* base_next = base_cur;
+        const pix_t* base_next = base_cur;
         int next = p.ntiles;
 
         // ---- one phase: 12 groups of 4 MFMAs on the unit in slot cons % 3: channel C, unit U of it ----
@@ -164,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
                 constexpr int gg = decltype(G_)::value, set = gg & 1;
                 typedef std::integral_constant<int, set ^ 1> NS;
                 if constexpr (gg == 11) {
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // my pieces of the next unit have landed (the 8 pixel loads after them may not)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");  // my pieces of the next unit have landed (the pixel loads after them may not)
                     __builtin_amdgcn_s_barrier();                     // ... everyone's; unit cons-1 is no longer read
                     set_issue(ipos, (cons + 2) % 3);
                     ipos = ipos + 1 == UPT ? 0 : ipos + 1;
@@ -274,7 +327,9 @@ int hipt_embed32_launch(const EmbedParams& p_in, hipStream_t st) {
     static DevOnce once;
     HIPT_CUR_DEVICE(dev);
     if (!once.done[dev]) {
-        if (hipFuncSetAttribute((const void*)embed32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)embed32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)embed32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)embed32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(embed32) failed");
             return HIPT_E_LAUNCH;
         }
@@ -293,7 +348,7 @@ int hipt_embed32_launch(const EmbedParams& p_in, hipStream_t st) {
         hipt_set_error("embed32: hipMemsetAsync(counter) failed");
         return HIPT_E_LAUNCH;
     }
-    hipLaunchKernelGGL(embed32_kernel, dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(p.kind == 2 ? embed32_kernel<2> : (p.kind == 1 ? embed32_kernel<1> : embed32_kernel<0>), dim3(grid), dim3(256), lds, st, p);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }

@@ -32,7 +32,8 @@ int hipt_gemm_launch(const GemmParams& p, int dtype, int aload, int flags, hipSt
 // Patch embedding of ViT-256 straight from the fp32 image (embed32.hip): x[seq, 1 + t, :] = Conv2d_k16_s16(pixels) + bias + pos[1 + t]
 // for the 16 x 16 tokens of every 256 x 256 patch; bf16 MFMAs on pixels rounded to bf16 in registers (no bf16 copy of the image).
 struct EmbedParams {
-    const float* img;        // fp32 image tensor, addressed through `im` (include/hipt_abmil.h, hipt_image_layout)
+    const void* img;         // image tensor, addressed through `im` (include/hipt_abmil.h, hipt_image_layout)
+    int kind;                // 0: fp32 [.., 3, W, H]; 1: uint8 in the same layout; 2: uint8 interleaved [.., W, H, 3] (`im` still gives W, H as strides)
     hipt_image_layout im;
     int nty, ntx;            // tokens per patch along dim2 / dim3 (ntx == 16, nty % 8 == 0)
     int seq0, nseq;          // sequences (patches) [seq0, seq0 + nseq) of the tensor

@@ -278,3 +278,19 @@ def test_stream_argument_carries_its_device():
     with pytest.raises(RuntimeError, match="expected all tensors on"):
         N.same_device("x", torch.device("cuda", 0), t_cpu)
     N.same_device("x", torch.device("cpu"), t_cpu, None)
+
+
+def test_uint8_normalisation_constant_reproduces_every_byte_value():
+    """csrc/embed32.hip normalises uint8 pixels in registers as bf16(fma(b, 2/255, -1)) with 2/255 = 0x3c008081 instead of the
+    reference's ((b / 255) - 0.5) / 0.5 (ToTensor + Normalize, hipt_model_utils.py:113-118) rounded to bf16: the same bits for every
+    one of the 256 inputs (a fused multiply-add is exact in float64 here: 8 x 24 significant bits, then one rounding to float32)."""
+    import numpy as np
+    import torch
+
+    b = torch.arange(256, dtype=torch.float32)
+    ref = ((b / 255) - 0.5) / 0.5
+    s = np.array([0x3C008081], dtype=np.uint32).view(np.float32)[0]
+    fused = (np.arange(256, dtype=np.float64) * np.float64(s) - 1.0).astype(np.float32)
+    assert torch.equal(torch.from_numpy(fused).to(torch.bfloat16), ref.to(torch.bfloat16))
+    # (and it is NOT the same float32: the kernel may only use it where the next step rounds to bf16)
+    assert int((torch.from_numpy(fused) != ref).sum()) > 0
