@@ -44,8 +44,10 @@ REGION = 4096
 # 3 146 029 797 888 FLOP per region when every block runs on all 257 tokens.  The build runs the LAST
 # ViT-256 block for the [CLS] query only (nothing else of it is consumed, vision_transformer.py:253); §8d requires the
 # pruned figure then: per patch, block 12 keeps QKV (K and V of all tokens) and does QK^T / PV / proj / MLP for 1 of 257 rows.
+# (round 2: Q of block 12 is computed for the [CLS] row only as well -- 256 of 257 rows of a [257, 384] x [384, 384] product less)
 _BLOCK_TAIL = 50_725_632 + 50_725_632 + 75_792_384 + 606_339_072          # QK^T + PV + proj + MLP of one patch, one block
-FLOP_PER_REGION = 3_146_029_797_888 - 256 * (_BLOCK_TAIL - _BLOCK_TAIL // 257)
+_Q_LAST = 2 * 257 * 384 * 384                                              # the Q third of block 12's QKV Linear, one patch
+FLOP_PER_REGION = 3_146_029_797_888 - 256 * (_BLOCK_TAIL - _BLOCK_TAIL // 257) - 256 * (_Q_LAST - _Q_LAST // 257)
 FLOP_PER_REGION_FULL = 3_146_029_797_888
 LIB_CHUNK = 2048  # patches per ViT-256 pass when --chunk is 0 (capi.hip default_chunk)
 

@@ -254,7 +254,24 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
     if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue (bf16 operands in s.att)
         q.A = s.att; q.ln_w = q.ln_b = nullptr;
         q.img = x_img ? 1 : 0;  // (x and the operands s.att change layout together)
-        PROF(PC_QKV, hipt_seqgemm_launch(q, false, 0, st));
+        if (getenv("HIPT_NO_Q_PRUNE") == nullptr) {
+            // Only token 0 of a sequence asks a question in this block: K and V for every row (columns 384.. of the QKV Linear: the
+            // weight image of an N tile is the 98 304 bytes of its rows, so the tail of the image IS the [K; V] matrix), Q for the
+            // [CLS] rows alone -- their operands gathered into the free hidden slot, a [nseq, 384] GEMM scattered to rows s * ntok
+            bf16_t* qa = (bf16_t*)((char*)s.hid + 4096 + al256((size_t)nseq * D * 4));
+            PROF(PC_LASTCLS, hipt_gather_cls_bf16_launch(s.att, qa, nseq, w->ntok, D, st, x_img ? 1 : 0));
+            const size_t wq = (size_t)D * D * 2;
+            q.W = (const char*)b.qkv_w + wq; q.wpk = b.qkv_pk ? (const char*)b.qkv_pk + wq : nullptr; q.N = 2 * D; q.bias = b.qkv_b + D;
+            q.out = (bf16_t*)s.qkv + D;
+            PROF(PC_LASTCLS, hipt_seqgemm_launch(q, false, 0, st));  // (booked apart: the QKV category holds full-size launches only)
+            q.img = 0;
+            q.M = nseq; q.A = qa; q.W = b.qkv_w; q.wpk = b.qkv_pk; q.N = D; q.bias = b.qkv_b; q.out = s.qkv; q.ldc = w->ntok * 3 * D;
+            q.counter = (int*)s.hid + 32;
+            PROF(PC_LASTCLS, hipt_seqgemm_launch(q, false, 0, st));
+            q.M = M; q.ldc = 3 * D;
+        } else {
+            PROF(PC_QKV, hipt_seqgemm_launch(q, false, 0, st));
+        }
         q.img = 0;
     } else {
         PROF(PC_QKV, hipt_seqgemm_launch(q, true, 0, st));

@@ -152,6 +152,7 @@ int hipt_attn_cls_launch(const void* qkv, void* out, float* probs, int B, int nt
 int hipt_attn_cls_probs_launch(const void* qkv, float* probs, int B, int ntok, int heads, int dh, float scale, int dtype, hipStream_t st);
 // dst[s, :] = src[s * seq_stride ...] : the first row of every sequence (fp32)
 int hipt_gather_cls_launch(const float* src, float* dst, int nseq, int64_t seq_stride, int D, hipStream_t st, int img = 0);
+int hipt_gather_cls_bf16_launch(const void* src, void* dst, int nseq, int ntok, int D, hipStream_t st, int img = 0);  // bf16 rows s * ntok of [.., 384]
 // x[s, 0, :] = cls + pos[0]  for s in [0, nseq)
 int hipt_cls_init_launch(float* x, const float* cls, const float* pos, int nseq, int ntok, int D, hipStream_t st);
 // out[i] = src[i] (+ (float)y[i] if y)  (fp32, bf16 branch, n % 8 == 0): lands the residual stream in the caller's buffer

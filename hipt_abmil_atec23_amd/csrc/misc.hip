@@ -323,6 +323,17 @@ __global__ void gather_cls_kernel(const float* __restrict__ src, float* __restri
     }
 }
 
+// the same for bf16 rows of 384 (the LayerNorm'd operands): dst[s, :] = src[s * ntok, :]; img: src is a bf16 activation image
+// (row r in fragment r / 16 as li = r % 16; its 8 elements at column 8k are chunk k = g + 4 c: F * 6144 + c * 512 + (16 g + li) * 8)
+__global__ void gather_cls_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int nseq, int ntok, int img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk
+    if (i >= nseq * 48) return;
+    const int s = i / 48, k = i % 48;
+    const int64_t r = (int64_t)s * ntok;
+    const int64_t off = img ? (r >> 4) * 6144 + (k >> 2) * 512 + (16 * (k & 3) + (int)(r & 15)) * 8 : r * 384 + 8 * k;
+    *(u32x4*)(dst + (int64_t)s * 384 + 8 * k) = *(const u32x4*)(src + off);
+}
+
 }  // namespace
 
 int hipt_attn_cls_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale, hipStream_t st) {
@@ -427,6 +438,14 @@ int hipt_f32_to_bf16_launch(const float* in, void* out, int64_t n, hipStream_t s
     int64_t blocks = (n8 + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, (bf16_t*)out, n8);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}
+
+int hipt_gather_cls_bf16_launch(const void* src, void* dst, int nseq, int ntok, int D, hipStream_t st, int img) {
+    HIPT_CHECK_ARG(D == 384, "gather_cls_bf16: D = 384 only");
+    const int n = nseq * 48;
+    hipLaunchKernelGGL(gather_cls_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, nseq, ntok, img);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }
