@@ -337,14 +337,16 @@ def test_vit256_prepacked_weight_images_change_nothing(vit256, monkeypatch):
     run from either (QKV, proj, and the 16x16x32 fused MLP, HIPT_NO_MLP32=1).  The default fused MLP (32x32x16 MFMAs, its own
     image, mlp_pk_fmt = 1) exists only in packed form: it sums in another order and uses the 3-coefficient GELU, so against the
     row-major path it is held to the bf16 bar instead."""
-    if os.environ.get("HIPT_NO_PREPACK"):
-        pytest.skip("HIPT_NO_PREPACK is set for the whole run")
+    if os.environ.get("HIPT_NO_PREPACK") or os.environ.get("HIPT_MLP_WS"):
+        pytest.skip("HIPT_NO_PREPACK / HIPT_MLP_WS is set for the whole run (the latter overrides the formats this test switches between)")
     x = synth.hash_uniform_torch((4, 3, 256, 256), 19, device=DEV)
     vit256.set_compute_dtype("bf16")
     try:
         pk = vit256._tokens(x)[0]
         assert all(pk.blocks[i].mlp_pk and pk.blocks[i].qkv_pk and pk.blocks[i].proj_pk for i in range(pk.w.depth))
-        assert all(pk.blocks[i].mlp_pk_fmt == 1 for i in range(pk.w.depth))
+        # (a whole run under HIPT_NO_MLP32 starts from that kernel's format instead of the default's)
+        exp_fmt = 0 if os.environ.get("HIPT_NO_MLP32") else 1
+        assert all(pk.blocks[i].mlp_pk_fmt == exp_fmt for i in range(pk.w.depth))
         default = vit256(x), vit256.get_intermediate_layers(x, n=2)
         monkeypatch.setenv("HIPT_NO_MLP32", "1")  # read when the images are made: the format travels with the image
         vit256._packed.clear()
@@ -408,8 +410,8 @@ def test_vit256_experimental_column_owned_mlp(vit256, monkeypatch):
     registers and feed four MFMAs each, the GELU'd hidden tile is exchanged through LDS.  Its x is the default kernel's bit for
     bit (same products in the same order); the chained LayerNorm sums a row across four waves, so the features differ in the
     last bits only.  Bitwise against itself under a different batching."""
-    if os.environ.get("HIPT_NO_PREPACK") or os.environ.get("HIPT_NO_MLP32") or os.environ.get("HIPT_MLP_WS"):
-        pytest.skip("needs the default (format 1) weight images")
+    if os.environ.get("HIPT_NO_PREPACK") or os.environ.get("HIPT_NO_MLP32") or os.environ.get("HIPT_MLP_WS") or os.environ.get("HIPT_MLP_CO"):
+        pytest.skip("needs the default kernel and its (format 1) weight images as the other side of the comparison")
     x = synth.hash_uniform_torch((32, 3, 256, 256), 37, device=DEV)  # (activation images need rows % 16 == 0: 16 | patches)
     vit256.set_compute_dtype("bf16")
     try:
@@ -503,6 +505,8 @@ def test_vit256_activation_images_change_nothing(vit256, monkeypatch):
     2..11 as fragment-blocked "activation images" (csrc/kernels.h) when the batch has whole 16-row fragments: a pure
     re-ordering of bytes in private buffers -- identical bits to the row-major path (HIPT_NO_IMG=1), also for a batch
     whose row count is not a multiple of 16 (which never uses them)."""
+    if os.environ.get("HIPT_MLP_WS") or os.environ.get("HIPT_MLP_CO"):
+        pytest.skip("the experimental fused-MLP kernels exist in image form only: with and without images are different kernels")
     vit256.set_compute_dtype("bf16")
     try:
         for nseq in (16, 48, 5):  # 16 * 257 and 48 * 257 rows: whole fragments; 5 * 257: not
