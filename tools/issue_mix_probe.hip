@@ -237,6 +237,91 @@ __global__ __launch_bounds__(NT, 1) void k2(const char* src, int iters, unsigned
     if (lane == 0) out[blockIdx.x * (NT / 64) + wave] = t1 - t0;
     if (s == 123.456f) out[0] = 0;
 }
+// ---- two TEAMS of four waves (wave w and w + 4 share a SIMD), the shape of a wave-specialised kernel: team A runs the heavy stream
+// (a fragment read + 5 v_fma per MFMA gap: fc1 + GELU), team B the light one (a read per gap: fc2).  Every STEP groups they synchronise:
+//   SYNC 0: not at all;  1: s_barrier (all eight waves);  2: each team among itself, spinning on an LDS counter (ds_add + poll);
+//   3: as 2, plus the producer / consumer coupling of a two-slot hand-over: B starts step s when A has finished it, A starts step
+//      s + 2 when B has finished step s.
+// Reports cycles per group for the slower team (what a tile would take) -- the price of each kind of synchronisation.
+template <int SYNC, int STEP = 6>
+__global__ __launch_bounds__(512, 1) void k3(const char* src, int iters, unsigned long long* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int team = wave >> 2;
+    for (int i = threadIdx.x; i < 96 * 1024 / 4; i += 512) {
+        const uint32_t hsh = (uint32_t)(i * 2654435761u) ^ (uint32_t)(blockIdx.x * 40503u);
+        ((uint32_t*)smem)[i] = (hsh & 0x807f807fu) | 0x3c003c00u;
+    }
+    volatile int* cnt = (volatile int*)(smem + 100 * 1024);  // [2] arrivals per team
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t fb = (uint32_t)(uintptr_t)(LDS_AS char*)smem + lane * 16;
+    f32x16 a0, a1;
+    for (int e = 0; e < 16; ++e) a0[e] = a1[e] = 0.f;
+    u32x4 w0[4], w1[4], b;
+    for (int i = 0; i < 4; ++i) b[i] = (((uint32_t)(threadIdx.x * 2246822519u + i * 3266489917u)) & 0x807f807fu) | 0x3c003c00u;
+    for (int i = 0; i < 4; ++i) w0[i] = w1[i] = b;
+    float f[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, c = 0.999f, d = 1e-3f;
+    auto mma = [&](f32x16& acc, const u32x4& a) __attribute__((always_inline)) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    };
+    auto gap = [&](auto NF_, u32x4& dst, uint32_t ra, auto OFF_) __attribute__((always_inline)) {
+        constexpr int nf = decltype(NF_)::value, off = decltype(OFF_)::value;
+        DSR(dst, ra, off);
+#pragma unroll
+        for (int i = 0; i < nf; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i & 7]) : "v"(c), "v"(d));
+        WAITL(3);
+        SB();
+    };
+    auto group = [&](auto NF_, u32x4(&cur)[4], u32x4(&nxt)[4], uint32_t ra) __attribute__((always_inline)) {
+        mma(a0, cur[0]); SB(); gap(NF_, nxt[0], ra, std::integral_constant<int, 0>{});
+        mma(a1, cur[1]); SB(); gap(NF_, nxt[1], ra, std::integral_constant<int, 1024>{});
+        mma(a0, cur[2]); SB(); gap(NF_, nxt[2], ra, std::integral_constant<int, 2048>{});
+        mma(a1, cur[3]); SB(); gap(NF_, nxt[3], ra, std::integral_constant<int, 3072>{});
+    };
+    auto arrive = [&]() __attribute__((always_inline)) {
+        if (lane == 0) __hip_atomic_fetch_add((int*)&cnt[team], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto wait_for = [&](int t, int target) __attribute__((always_inline)) {
+        while (__hip_atomic_load((int*)&cnt[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    };
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    uint32_t ra = fb;
+    int step = 0;
+    for (int it = 0; it < iters; it += STEP) {
+        if constexpr (SYNC == 3) {
+            if (team == 1) wait_for(0, 4 * (step + 1));            // B: A has produced step `step`
+            else if (step >= 2) wait_for(1, 4 * (step - 1));       // A: B has consumed step `step - 2` (two hand-over slots)
+        }
+#pragma unroll
+        for (int g = 0; g < STEP; g += 2) {
+            if (team == 0) {
+                group(std::integral_constant<int, 5>{}, w0, w1, ra);
+                group(std::integral_constant<int, 5>{}, w1, w0, ra + 4096);
+            } else {
+                group(std::integral_constant<int, 0>{}, w0, w1, ra);
+                group(std::integral_constant<int, 0>{}, w1, w0, ra + 4096);
+            }
+            ra = ra + 8192 >= fb + 96 * 1024 ? fb : ra + 8192;
+        }
+        WAITL(0);
+        step += 1;
+        if constexpr (SYNC == 1) __builtin_amdgcn_s_barrier();
+        if constexpr (SYNC >= 2) {
+            arrive();
+            if constexpr (SYNC == 2) wait_for(team, 4 * step);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += f[i];
+    for (int e = 0; e < 16; ++e) s += a0[e] + a1[e];
+    for (int i = 0; i < 4; ++i) s += __builtin_bit_cast(float, w0[i][0] ^ w1[i][1]);
+    if (lane == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
+    if (s == 123.456f) out[0] = 0;
+}
+
 #define RUN2(name, g0, g1, g2, g3) run(name, k2<(g0), (g1), (g2), (g3)>, out)
 #define RUN2W(name, g0, g1, g2, g3) run(name, k2<(g0), (g1), (g2), (g3), 512>, out, 512)
 
@@ -340,5 +425,12 @@ int main() {
     RUN2W("r D 2T 4pk | r 2T 4pk | r D 2T 4pk | r 2T 4pk", R | Dm | T(2) | F(4) | PK, R | T(2) | F(4) | PK, R | Dm | T(2) | F(4) | PK, R | T(2) | F(4) | PK);
     RUN2W("r D | r D | r | r", R | Dm, R | Dm, R, R);
     RUN2W("r D(imm) | r D(imm) | r | r", R | Dm | IMM, R | Dm | IMM, R, R);
+    printf("---- two teams of four waves (A: read + 5 v_fma per gap, B: read per gap), synchronised every 6 groups (24 MFMAs)\n");
+    run("teams, no synchronisation", k3<0>, out, 512);
+    run("teams, s_barrier (all 8 waves) per step", k3<1>, out, 512);
+    run("teams, LDS-counter spin barrier inside each team per step", k3<2>, out, 512);
+    run("teams, two-slot producer / consumer coupling only (LDS counters)", k3<3>, out, 512);
+    run("teams, s_barrier per 12 groups", k3<1, 12>, out, 512);
+    run("teams, producer / consumer coupling per 12 groups", k3<3, 12>, out, 512);
     return 0;
 }
