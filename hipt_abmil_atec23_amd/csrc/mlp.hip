@@ -415,7 +415,9 @@ int launch(const MlpParams& p_in, hipStream_t st) {
     // eighth full is cut into 16-row tiles (one active wave each: such a tile costs about half a full one)
     const int tiles = (p.M + TMR - 1) / TMR;
     const int rem = tiles % ncu;
-    const int tail_tiles = (tiles > ncu && rem > 0 && rem <= ncu / 8) ? rem : 0;
+    // (a launch of at most four tiles -- the second-level ViT on one region, the [CLS] rows of the pruned block -- is all 16-row tiles:
+    //  the same weight pass per workgroup, a fraction of the row work, 8x the CUs of an otherwise idle GPU)
+    const int tail_tiles = tiles <= 4 ? tiles : ((tiles > ncu && rem > 0 && rem <= ncu / 8) ? rem : 0);
     p.full_tiles = tiles - tail_tiles;
     const int tail_rows = p.M - p.full_tiles * TMR;
     p.ntiles = p.full_tiles + (tail_rows > 0 ? (tail_rows + 15) / 16 : 0);
