@@ -142,8 +142,9 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     const int cQKV = big ? PC_QKV : PC_VIT4K, cATTN = big ? PC_ATTN : PC_VIT4K, cPROJ = big ? PC_PROJ : PC_VIT4K, cMLP = big ? PC_MLP : PC_VIT4K;
     // pipelined path: the MLP of block i applies LayerNorm-1 of block i+1 to the rows it finishes and leaves them in
     // s.att as bf16 operands; block i+1's QKV GEMM then skips the fp32 row load + LayerNorm
+    // (HIPT_NO_MLP_PIPE: the generic fused-MLP kernel that switch selects has no chained-LayerNorm epilogue)
     const bool chain = seq && hipt_mlp_pipe_supported(dt, D, w->hidden) && hipt_seqgemm_pipe_supported(dt, D, 3 * D, false, 0) &&
-                       getenv("HIPT_NO_LN_CHAIN") == nullptr;
+                       getenv("HIPT_NO_LN_CHAIN") == nullptr && getenv("HIPT_NO_MLP_PIPE") == nullptr;
     bool have_xn = false;
     // activation images: chained pipelined blocks with packed weights, whole 16-row fragments, no probability output
     bool img = img_ok && chain && probs == nullptr && M % 16 == 0 && getenv("HIPT_NO_IMG") == nullptr &&

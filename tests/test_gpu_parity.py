@@ -410,8 +410,9 @@ def test_vit256_experimental_column_owned_mlp(vit256, monkeypatch):
     registers and feed four MFMAs each, the GELU'd hidden tile is exchanged through LDS.  Its x is the default kernel's bit for
     bit (same products in the same order); the chained LayerNorm sums a row across four waves, so the features differ in the
     last bits only.  Bitwise against itself under a different batching."""
-    if os.environ.get("HIPT_NO_PREPACK") or os.environ.get("HIPT_NO_MLP32") or os.environ.get("HIPT_MLP_WS") or os.environ.get("HIPT_MLP_CO"):
-        pytest.skip("needs the default kernel and its (format 1) weight images as the other side of the comparison")
+    if any(os.environ.get(k) for k in ("HIPT_NO_PREPACK", "HIPT_NO_MLP32", "HIPT_MLP_WS", "HIPT_MLP_CO", "HIPT_NO_IMG", "HIPT_NO_SEQGEMM_PIPE",
+                                       "HIPT_NO_MLP_PIPE", "HIPT_NO_LN_CHAIN", "HIPT_PROJ_FOLD")):
+        pytest.skip("needs the default kernel, its (format 1) weight images and activation images as the other side of the comparison")
     x = synth.hash_uniform_torch((32, 3, 256, 256), 37, device=DEV)  # (activation images need rows % 16 == 0: 16 | patches)
     vit256.set_compute_dtype("bf16")
     try:
@@ -505,8 +506,8 @@ def test_vit256_activation_images_change_nothing(vit256, monkeypatch):
     2..11 as fragment-blocked "activation images" (csrc/kernels.h) when the batch has whole 16-row fragments: a pure
     re-ordering of bytes in private buffers -- identical bits to the row-major path (HIPT_NO_IMG=1), also for a batch
     whose row count is not a multiple of 16 (which never uses them)."""
-    if os.environ.get("HIPT_MLP_WS") or os.environ.get("HIPT_MLP_CO"):
-        pytest.skip("the experimental fused-MLP kernels exist in image form only: with and without images are different kernels")
+    if os.environ.get("HIPT_MLP_WS") or os.environ.get("HIPT_MLP_CO") or os.environ.get("HIPT_PROJ_FOLD"):
+        pytest.skip("the experimental fused-MLP forms exist with images only: with and without images are different kernels")
     vit256.set_compute_dtype("bf16")
     try:
         for nseq in (16, 48, 5):  # 16 * 257 and 48 * 257 rows: whole fragments; 5 * 257: not
