@@ -411,7 +411,7 @@ def test_vit256_experimental_column_owned_mlp(vit256, monkeypatch):
     bit (same products in the same order); the chained LayerNorm sums a row across four waves, so the features differ in the
     last bits only.  Bitwise against itself under a different batching."""
     if any(os.environ.get(k) for k in ("HIPT_NO_PREPACK", "HIPT_NO_MLP32", "HIPT_MLP_WS", "HIPT_MLP_CO", "HIPT_NO_IMG", "HIPT_NO_SEQGEMM_PIPE",
-                                       "HIPT_NO_MLP_PIPE", "HIPT_NO_LN_CHAIN", "HIPT_PROJ_FOLD")):
+                                       "HIPT_NO_MLP_PIPE", "HIPT_NO_LN_CHAIN", "HIPT_PROJ_FOLD", "HIPT_NO_SEQGEMM", "HIPT_ATTN_V1", "HIPT_NO_PRUNE")):
         pytest.skip("needs the default kernel, its (format 1) weight images and activation images as the other side of the comparison")
     x = synth.hash_uniform_torch((32, 3, 256, 256), 37, device=DEV)  # (activation images need rows % 16 == 0: 16 | patches)
     vit256.set_compute_dtype("bf16")
