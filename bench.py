@@ -429,6 +429,14 @@ def main():
             ex["config2_vit256_one_patch_fp32_ms"] = timed(lambda: model.model256(patch), 20) * 1e3  # BASELINE configs[1]
             model.set_compute_dtype(args.dtype)
             ex["config2_vit256_one_patch_bf16_ms"] = timed(lambda: model.model256(patch), 20) * 1e3
+        if not args.u8 and args.dtype == "bf16":
+            # the same regions as decoded 8-bit RGB tiles (interleaved [R, W, H, 3]: a quarter of the bytes over the host link;
+            # normalised inside the patch-embedding kernel, bit-identical features): the production input format
+            model.streams = args.streams
+            reg8 = ((region * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+            ex["uint8_input_regions_per_s"] = R / timed(lambda: model(reg8), 5)
+            del reg8
+            model.streams = 1
         bag2k = synth.hash_uniform_torch((2000, BAG_S0), 1, device=dev)
         clam.set_compute_dtype("fp32")
         with torch.no_grad():
