@@ -18,8 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 
 HIPT_F32, HIPT_BF16 = 0, 1
 EPI_GELU, EPI_RESID, EPI_OUT_F32, EPI_RELU = 1, 2, 4, 16
-ABI_VERSION = 3
-PACK_QKV, PACK_PROJ, PACK_MLP = 0, 1, 2
+ABI_VERSION = 4
+PACK_QKV, PACK_PROJ, PACK_MLP, PACK_QKV_ATT = 0, 1, 2, 3
 
 c_f32p = C.c_void_p  # device pointers travel as integers
 
@@ -28,7 +28,7 @@ class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
         "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "qkv_pk", "proj_pk", "mlp_pk")] + [
-        ("mlp_pk_fmt", C.c_int32), ("reserved", C.c_int32)]
+        ("mlp_pk_fmt", C.c_int32), ("reserved", C.c_int32), ("qkv_att_pk", C.c_void_p)]
 
 
 class VitWeights(C.Structure):
@@ -48,7 +48,8 @@ class ClamWeights(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("s0", C.c_int32), ("s1", C.c_int32), ("s2", C.c_int32),
                 ("n_classes", C.c_int32), ("reserved", C.c_int32),
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("wab", C.c_void_p), ("bab", C.c_void_p),
-                ("wc", C.c_void_p), ("bc", C.c_void_p), ("wcls", C.c_void_p), ("bcls", C.c_void_p), ("ring_pk", C.c_void_p)]
+                ("wc", C.c_void_p), ("bc", C.c_void_p), ("wcls", C.c_void_p), ("bcls", C.c_void_p),
+                ("logit_bound", C.c_float), ("reserved2", C.c_int32)]
 
 
 class ClamTrainWeights(C.Structure):
@@ -101,12 +102,11 @@ SIGNATURES = {
     "hipt_u8_normalize": (_i, [_p, _i, C.c_int64, C.c_int64, _p, _i, _p]),
     "hipt_clam_workspace_bytes": (_sz, [_CW, _i]),
     "hipt_clam_ticket_offset": (_sz, [_CW, _i]),
-    "hipt_clam_ring_packed_bytes": (_sz, [_CW]),
-    "hipt_clam_pack_ring": (_i, [_CW, _p, _p]),
     "hipt_clam_sb_forward": (_i, [_CW, _p, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "hipt_attn_net_gated": (_i, [_CW, _p, _i, _p, _p, _sz, _p]),
     "hipt_clam_gather_h1": (_i, [_CW, _p, _p, _i, _p, _p]),
     "hipt_clam_train_workspace_bytes": (_sz, [_TW, _i]),
+    "hipt_clam_train_shape_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "hipt_clam_train_forward": (_i, [_TW, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "hipt_clam_train_backward": (_i, [_TW, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _TG, _p, _sz, _p]),
     "hipt_topk_rows": (_i, [_p, _i, _i, _i, _p, _p]),

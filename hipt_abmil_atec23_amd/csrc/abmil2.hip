@@ -813,24 +813,13 @@ template <int KS>
 int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, float* partials,
            int* n_partials, unsigned* ticket, float* M, float* logits, float* Y_prob, int64_t* Y_hat, hipStream_t st) {
     constexpr int lds = (KS + 2) * SLAB + (S1 + 3 * S2) * 4;
-    auto k = abmil_stream_kernel<KS>;
-    static DevOnce once;
+    constexpr bool piped = KS == 6;  // S0 = 384: the software-pipelined form; S0 = 192: the plain streaming form
     HIPT_CUR_DEVICE(dev);
-    if (!once.done[dev]) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            hipt_set_error("hipFuncSetAttribute(abmil stream) failed");
-            return HIPT_E_LAUNCH;
-        }
-        once.done[dev] = true;
-    }
     // contiguous row ranges per wave; at most 256 workgroups x 4 waves
     int rows = (N + 1023) / 1024;
     // (rows per wave rounded to 2, not to a 16-row fragment: 100 000 rows are then 98 per wave on all 256 CUs instead of 112 on 224 --
-    //  the same time, measured both ways; rows are masked one by one, a buffer resource ends each wave's range.  HIPT_ABMIL_ROWS_ROUND=16:
-    //  round 1's partition)
-    static const char* rnd_env = getenv("HIPT_ABMIL_ROWS_ROUND");
-    const int rnd = rnd_env && atoi(rnd_env) > 0 ? atoi(rnd_env) : 2;
-    rows = (rows + rnd - 1) / rnd * rnd;
+    //  the same time, measured both ways; rows are masked one by one, a buffer resource ends each wave's range)
+    rows = (rows + 1) / 2 * 2;
     const int waves = (N + rows - 1) / rows;
     const int grid = (waves + 3) / 4;
 #ifdef HIPT_DEBUG_STAMPS  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
@@ -842,9 +831,7 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
     constexpr unsigned long long* dbuf = nullptr;
 #endif
     const bool fuse = !attention_only && ticket && M && w->n_classes <= 64 && grid <= 256;
-    static const bool no_pipe = getenv("HIPT_NO_ABMIL_PIPE") != nullptr;
-    const bool piped = KS == 6 && !no_pipe;
-    if (piped) {
+    if constexpr (piped) {
         auto kp = abmil_pipe_kernel;
         static DevOnce once_p;
         if (!once_p.done[dev]) {
@@ -857,10 +844,20 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
         hipLaunchKernelGGL(kp, dim3(grid), dim3(256), lds, st, (const bf16_t*)bag, N, rows, (const bf16_t*)w->w1, w->b1,
                            (const bf16_t*)w->wab, w->bab, w->wc, w->bc, A_raw, partials, attention_only,
                            want_stamps ? dbuf : nullptr, fuse ? ticket : nullptr, w->wcls, w->bcls, w->n_classes, M, logits, Y_prob, Y_hat);
-    } else
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (const bf16_t*)bag, N, rows, (const bf16_t*)w->w1, w->b1,
-                       (const bf16_t*)w->wab, w->bab, w->wc, w->bc, A_raw, partials, attention_only, want_stamps ? dbuf : nullptr,
-                       fuse ? ticket : nullptr, w->wcls, w->bcls, w->n_classes, M, logits, Y_prob, Y_hat);
+    } else {
+        auto k = abmil_stream_kernel<KS>;
+        static DevOnce once;
+        if (!once.done[dev]) {
+            if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+                hipt_set_error("hipFuncSetAttribute(abmil stream) failed");
+                return HIPT_E_LAUNCH;
+            }
+            once.done[dev] = true;
+        }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (const bf16_t*)bag, N, rows, (const bf16_t*)w->w1, w->b1,
+                           (const bf16_t*)w->wab, w->bab, w->wc, w->bc, A_raw, partials, attention_only, want_stamps ? dbuf : nullptr,
+                           fuse ? ticket : nullptr, w->wcls, w->bcls, w->n_classes, M, logits, Y_prob, Y_hat);
+    }
     HIPT_CHECK_LAUNCH();
 #ifdef HIPT_DEBUG_STAMPS
     if (want_stamps && grid <= 512) {
@@ -891,8 +888,7 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
 }  // namespace
 
 bool hipt_clam_stream_supported(const hipt_clam_weights* w) {
-    return w->dtype == HIPT_BF16 && w->s1 == S1 && w->s2 == S2 && (w->s0 == 384 || w->s0 == 192) &&
-           getenv("HIPT_NO_ABMIL2") == nullptr;
+    return w->dtype == HIPT_BF16 && w->s1 == S1 && w->s2 == S2 && (w->s0 == 384 || w->s0 == 192) && !hipt_generic_only();
 }
 
 int hipt_clam_stream_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw,

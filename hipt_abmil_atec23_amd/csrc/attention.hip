@@ -232,8 +232,7 @@ int hipt_attention_launch(const void* qkv, void* out, float* probs, int B, int n
         return HIPT_E_UNSUPPORTED;
     }
     HIPT_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "attention: 16-byte alignment required");
-    static const bool v1_only = getenv("HIPT_ATTN_V1") != nullptr;
-    if (!v1_only && hipt_attention64_supported(dtype, dh, ntok, probs != nullptr)) return hipt_attention64_launch(qkv, out, B, ntok, heads, scale, st, out_img, qkv_hm);
+    if (!hipt_generic_only() && hipt_attention64_supported(dtype, dh, ntok, probs != nullptr)) return hipt_attention64_launch(qkv, out, B, ntok, heads, scale, st, out_img, qkv_hm);
     HIPT_CHECK_ARG(!out_img && !qkv_hm, "attention: only the 64-wide-head bf16 kernel handles activation images / head-major qkv");
     if (dtype == HIPT_F32) return dispatch<float>(qkv, out, probs, B, ntok, heads, dh, scale, st);
     if (dtype == HIPT_BF16) return dispatch<bf16_t>(qkv, out, probs, B, ntok, heads, dh, scale, st);

@@ -135,28 +135,25 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     const int D = w->dim, M = nseq * w->ntok, dt = w->dtype, dh = D / w->heads;
     const float scale = attn_scale(w);
     int rc;
-    const bool seq = hipt_seqgemm_supported(dt, D) && hipt_mlp_supported(dt, D, w->hidden) && getenv("HIPT_NO_SEQGEMM") == nullptr;
+    const bool seq = hipt_seqgemm_supported(dt, D) && hipt_mlp_supported(dt, D, w->hidden);
     // timing categories: the kernels of the small second-level ViT (D = 192, a few hundred rows) are booked together,
     // so that the per-kernel categories hold only the ViT-256 launches the roofline is computed on
     const bool big = D >= 384;
     const int cQKV = big ? PC_QKV : PC_VIT4K, cATTN = big ? PC_ATTN : PC_VIT4K, cPROJ = big ? PC_PROJ : PC_VIT4K, cMLP = big ? PC_MLP : PC_VIT4K;
     // pipelined path: the MLP of block i applies LayerNorm-1 of block i+1 to the rows it finishes and leaves them in
     // s.att as bf16 operands; block i+1's QKV GEMM then skips the fp32 row load + LayerNorm
-    // (HIPT_NO_MLP_PIPE: the generic fused-MLP kernel that switch selects has no chained-LayerNorm epilogue)
-    const bool chain = seq && hipt_mlp_pipe_supported(dt, D, w->hidden) && hipt_seqgemm_pipe_supported(dt, D, 3 * D, false, 0) &&
-                       getenv("HIPT_NO_LN_CHAIN") == nullptr && getenv("HIPT_NO_MLP_PIPE") == nullptr;
+    // (only the streaming kernels have that epilogue / prologue: every block of the range needs its packed weight images)
+    bool chain = seq && !hipt_generic_only() && hipt_mlp32_supported(dt, D, w->hidden) && hipt_seqgemm_pipe_supported(dt, D, 3 * D, false, 0);
+    for (int i = b0; i < b1 && chain; ++i) chain = w->blocks[i].qkv_pk && w->blocks[i].proj_pk && w->blocks[i].mlp_pk && w->blocks[i].mlp_pk_fmt == 1;
     bool have_xn = false;
-    // activation images: chained pipelined blocks with packed weights, whole 16-row fragments, no probability output
-    bool img = img_ok && chain && probs == nullptr && M % 16 == 0 && getenv("HIPT_NO_IMG") == nullptr &&
-               getenv("HIPT_NO_SEQGEMM_PIPE") == nullptr && getenv("HIPT_NO_MLP_PIPE") == nullptr;
-    for (int i = b0; i < b1 && img; ++i) img = w->blocks[i].qkv_pk && w->blocks[i].proj_pk && w->blocks[i].mlp_pk;
-    img = img && hipt_attention64_supported(dt, dh, w->ntok, false) && getenv("HIPT_ATTN_V1") == nullptr;
+    // activation images: chained streaming blocks, whole 16-row fragments, no probability output
+    const bool img = img_ok && chain && probs == nullptr && M % 16 == 0 && !hipt_env_on("HIPT_NO_IMG") && hipt_attention64_supported(dt, dh, w->ntok, false);
     // with them, q | k | v leave the QKV GEMM head-major (the attention kernel's K / V staging reads consecutive bytes)
-    const bool hm = img && (int64_t)M * 3 * D * 2 < ((int64_t)1 << 32) - 65536 && getenv("HIPT_NO_QKV_HM") == nullptr;
+    const bool hm = img && (int64_t)M * 3 * D * 2 < ((int64_t)1 << 32) - 65536;
     bool x_img = false;
-    // the tile queues of the pipelined kernels (three ints in the unused hidden slot) reset themselves at the end of a launch:
+    // the tile queues of the streaming kernels (three ints in the unused hidden slot) reset themselves at the end of a launch:
     // zeroed once here instead of before each of the ~44 launches (5 us each on the stream: 3 % of a one-region forward)
-    const bool qz = seq && chain && getenv("HIPT_QUEUE_MEMSET") == nullptr && hipMemsetAsync(s.hid, 0, 48 * sizeof(int), st) == hipSuccess;
+    const bool qz = chain && hipMemsetAsync(s.hid, 0, 48 * sizeof(int), st) == hipSuccess;
     for (int i = b0; i < b1; ++i) {
         const hipt_block_weights& b = w->blocks[i];
         const bool last_probs = probs != nullptr && i == b1 - 1;
@@ -185,22 +182,14 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             // (with activation images the attention output is one too: proj then reads its operands 1 KiB at a time)
             PROF(cATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st, img ? 1 : 0, hm ? 1 : 0));
             if (last_probs) break;
-            // With activation images and the 32x32x16 MLP kernel's weight image (which carries the proj matrix too) the fused MLP can
-            // apply proj itself: no launch, no y1 round trip (HIPT_PROJ_FOLD=1).  Measured: break-even -- the six extra ring phases and
-            // the row phase that follows them cost a tile what the proj launch cost -- so it is not the default.
-            // (It reads the attention output from s.att and, with LayerNorm chaining, writes the next block's operands there: the
-            // same rows, read in a tile's first phase and written in its last.)
-            const bool fold = img && b.mlp_pk_fmt == 1 && hipt_mlp32_supported(dt, D, w->hidden) && getenv("HIPT_PROJ_FOLD") != nullptr;
-            if (!fold) {
-                q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
-                q.counter = (int*)s.hid + 32;
-                q.img = img ? 3 : 0;  // A = the attention output image, out = y1 image
-                PROF(cPROJ, hipt_seqgemm_launch(q, false, 0, st));
-            }
+            // (proj folded into the fused MLP was measured break-even -- DESIGN.md -- and lives on as an experiment build only)
+            q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
+            q.counter = (int*)s.hid + 32;
+            q.img = img ? 3 : 0;  // A = the attention output image, out = y1 image
+            PROF(cPROJ, hipt_seqgemm_launch(q, false, 0, st));
             MlpParams m;
             memset(&m, 0, sizeof(m));
-            m.x = x; m.y1 = fold ? s.att : s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
-            m.fold = fold ? 1 : 0; m.bproj = b.proj_b;
+            m.x = x; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
             m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.wpk_fmt = b.mlp_pk_fmt; m.M = M; m.D = D; m.hidden = w->hidden;
             m.counter = (int*)s.hid;
             m.counter_zeroed = qz ? 1 : 0;
@@ -239,7 +228,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
 // the pruned FLOP figure is the one the roofline uses).  Leaves the final residual rows compact in xc [nseq, D].
 static bool can_prune_last(const hipt_vit_weights* w) {
     return w->dtype == HIPT_BF16 && w->dim == 384 && w->dim / w->heads == 64 && w->ntok <= 320 && hipt_seqgemm_supported(w->dtype, w->dim) &&
-           hipt_mlp_supported(w->dtype, w->dim, w->hidden) && getenv("HIPT_NO_SEQGEMM") == nullptr && getenv("HIPT_NO_PRUNE") == nullptr;
+           hipt_mlp_supported(w->dtype, w->dim, w->hidden) && !hipt_env_on("HIPT_NO_PRUNE");
 }
 
 static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, const BlockScratch& s, float* xc, bool have_xn, bool x_img, hipStream_t st) {
@@ -255,7 +244,7 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
     if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue (bf16 operands in s.att)
         q.A = s.att; q.ln_w = q.ln_b = nullptr;
         q.img = x_img ? 1 : 0;  // (x and the operands s.att change layout together)
-        if (getenv("HIPT_NO_Q_PRUNE") == nullptr) {
+        {
             // Only token 0 of a sequence asks a question in this block: K and V for every row (columns 384.. of the QKV Linear: the
             // weight image of an N tile is the 98 304 bytes of its rows, so the tail of the image IS the [K; V] matrix), Q for the
             // [CLS] rows alone -- their operands gathered into the free hidden slot, a [nseq, 384] GEMM scattered to rows s * ntok
@@ -270,8 +259,6 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
             q.counter = (int*)s.hid + 32;
             PROF(PC_LASTCLS, hipt_seqgemm_launch(q, false, 0, st));
             q.M = M; q.ldc = 3 * D;
-        } else {
-            PROF(PC_QKV, hipt_seqgemm_launch(q, false, 0, st));
         }
         q.img = 0;
     } else {
@@ -332,7 +319,7 @@ int embed256(const hipt_vit_weights* w, const void* img, const hipt_image_layout
 // may the embedding read fp32 pixels itself (embed32.hip)?  `slot` bytes are available for its packed weight + tile queue
 static bool embed_fused_ok(const hipt_vit_weights* w, const void* images, const hipt_image_layout* lay, size_t slot, int kind = 0) {
     // (uint8: 8-byte pixel runs; interleaved tensors are whole [n, W, H, 3] images: batch_stride = 3 * chan_stride)
-    if (kind != 0 && (lay->row_stride % 8 != 0 || lay->chan_stride % 8 != 0 || lay->batch_stride != 3 * lay->chan_stride || getenv("HIPT_NO_EMBED32_U8") != nullptr))
+    if (kind != 0 && (lay->row_stride % 8 != 0 || lay->chan_stride % 8 != 0 || lay->batch_stride != 3 * lay->chan_stride))
         return false;
     return lay->patch_w % 16 == 0 && lay->patch_h % 16 == 0 &&
            hipt_embed32_supported(w->dtype, w->dim, w->embed_k, lay->patch_h / 16, lay->patch_w / 16) &&
@@ -563,12 +550,7 @@ int hipt_vit_cls_attention(const hipt_vit_weights* w, float* x, int nseq, float*
     return hipt_attn_cls_probs_launch(s.qkv, probs_cls, nseq, w->ntok, w->heads, dh, attn_scale(w), w->dtype, st);
 }
 
-int hipt_vit_mlp_pack_format(const hipt_vit_weights* w) {
-    if (!w) return 0;
-    if (getenv("HIPT_MLP_WS") && hipt_mlp_ws_supported(w->dtype, w->dim, w->hidden)) return 2;
-    if (!getenv("HIPT_NO_MLP32") && hipt_mlp32_supported(w->dtype, w->dim, w->hidden)) return 1;
-    return 0;
-}
+int hipt_vit_mlp_pack_format(const hipt_vit_weights* w) { return (w && hipt_mlp32_supported(w->dtype, w->dim, w->hidden)) ? 1 : 0; }
 
 size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {
     if (!w || w->dtype != HIPT_BF16) return 0;
@@ -576,8 +558,7 @@ size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {
     switch (what) {
         case HIPT_PACK_QKV: return hipt_seqgemm_pipe_supported(w->dtype, D, 3 * D, false, 0) ? (size_t)3 * D * D * 2 : 0;
         case HIPT_PACK_PROJ: return hipt_seqgemm_pipe_supported(w->dtype, D, D, false, 0) ? (size_t)D * D * 2 : 0;
-        // (format 1 -- the 32x32x16 kernel -- carries the proj matrix behind fc1 / fc2: the kernel can apply it itself)
-        case HIPT_PACK_MLP: return hipt_mlp_pipe_supported(w->dtype, D, w->hidden) ? (size_t)2 * D * w->hidden * 2 + (hipt_vit_mlp_pack_format(w) == 1 ? (size_t)D * D * 2 : 0) : 0;
+        case HIPT_PACK_MLP: return hipt_vit_mlp_pack_format(w) == 1 ? (size_t)2 * D * w->hidden * 2 : 0;
         default: return 0;
     }
 }
@@ -599,13 +580,9 @@ int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* 
         case HIPT_PACK_PROJ: return hipt_seqgemm_pack_launch(b.proj_w, D, D, out, st);
         default:
             // the format the caller recorded beside the pointer (hipt_vit_mlp_pack_format): pack and launch read the same field
-            if (b.mlp_pk_fmt == 2 && hipt_mlp_ws_supported(w->dtype, D, w->hidden)) return hipt_mlp_ws_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
-            if (b.mlp_pk_fmt == 1 && hipt_mlp32_supported(w->dtype, D, w->hidden)) return hipt_mlp32_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st, b.proj_w);
-            if (b.mlp_pk_fmt != 0) {
-                hipt_set_error("hipt_vit_pack_weights: blocks[%d].mlp_pk_fmt = %d is not a format this model has", block, b.mlp_pk_fmt);
-                return HIPT_E_BADARG;
-            }
-            return hipt_mlp_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
+            if (b.mlp_pk_fmt == 1 && hipt_mlp32_supported(w->dtype, D, w->hidden)) return hipt_mlp32_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
+            hipt_set_error("hipt_vit_pack_weights: blocks[%d].mlp_pk_fmt = %d is not a format this model has", block, b.mlp_pk_fmt);
+            return HIPT_E_BADARG;
     }
 }
 
@@ -879,11 +856,14 @@ static size_t clam_partials_bytes(const hipt_clam_weights* w, int N) {
     return al256(g * (2 + w->s1) * 4);
 }
 
-size_t hipt_clam_ticket_offset(const hipt_clam_weights* w, int N) { return clam_partials_bytes(w, N); }
+// The ticket block is the FIRST 256 bytes of the workspace, whatever the model's widths, and nothing else ever writes there
+// (one workspace may serve several CLAM modules of different widths / paths on a stream: the generic path's scratch must not
+// run over the streaming kernels' arrival counter).
+size_t hipt_clam_ticket_offset(const hipt_clam_weights* w, int N) { return 0; }
 
 size_t hipt_clam_workspace_bytes(const hipt_clam_weights* w, int N) {
-    // partials | gmax | h1 fp32 | ab fp32 | h1 in dtype (generic path)
-    return clam_partials_bytes(w, N) + 256 + al256((size_t)N * w->s1 * 4) + al256((size_t)N * 2 * w->s2 * 4) +
+    // ticket | partials | gmax | h1 fp32 | ab fp32 | h1 in dtype (generic path)
+    return 256 + clam_partials_bytes(w, N) + 256 + al256((size_t)N * w->s1 * 4) + al256((size_t)N * 2 * w->s2 * 4) +
            al256((size_t)N * w->s1 * 2);
 }
 
@@ -906,17 +886,6 @@ static int gated_scores(const hipt_clam_weights* w, const void* x, int xdtype, i
     return hipt_gate_launch(ab, n2, N, w->s2, w->wc, w->bc, A, st);
 }
 
-int hipt_clam_pack_ring(const hipt_clam_weights* w, void* out, void* stream) {
-    int rc = check_clam(w);
-    if (rc) return rc;
-    HIPT_CHECK_ARG(out && w->w1 && w->wab, "clam_pack_ring: null pointer");
-    if (hipt_clam_ring_packed_bytes(w) == 0) {
-        hipt_set_error("clam_pack_ring: widths [%d,%d,%d] / dtype %d have no packed form", w->s0, w->s1, w->s2, w->dtype);
-        return HIPT_E_UNSUPPORTED;
-    }
-    return hipt_clam_ring_pack_launch(w, out, S(stream));
-}
-
 int hipt_clam_sb_forward(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, float* M,
                          float* logits, float* Y_prob, int64_t* Y_hat, void* workspace, size_t ws_bytes, void* stream) {
     int rc = check_clam(w);
@@ -935,15 +904,12 @@ int hipt_clam_sb_forward(const hipt_clam_weights* w, const void* bag, int N, int
     }
     hipStream_t st = S(stream);
     Carver c(workspace, ws_bytes);
+    unsigned* ticket = (unsigned*)c.take(256);  // (hipt_clam_ticket_offset() = 0: zero before the first use, zero after every call)
     float* partials = (float*)c.take(clam_partials_bytes(w, N));
     float* gmax = (float*)c.take(256);
     int G = 0;
-    if (hipt_clam_ring_supported(w)) {  // bf16 [384,128,64]: weights in registers, the bag through an LDS-DMA ring
-        PROF(PC_ABMIL, hipt_clam_ring_launch(w, bag, N, attention_only, A_raw, partials, &G, (unsigned*)gmax, M, logits, Y_prob, Y_hat, st));
-        if (!attention_only && G == 0) return HIPT_OK;
-    } else if (hipt_clam_stream_supported(w)) {  // bf16 [S0,128,64]: weight-stationary streaming kernel
-        // (the gmax slot is unused on this path: it holds the finish ticket of the fused combine)
-        PROF(PC_ABMIL, hipt_clam_stream_launch(w, bag, N, attention_only, A_raw, partials, &G, (unsigned*)gmax, M, logits, Y_prob, Y_hat, st));
+    if (hipt_clam_stream_supported(w)) {  // bf16 [S0,128,64]: weight-stationary streaming kernel
+        PROF(PC_ABMIL, hipt_clam_stream_launch(w, bag, N, attention_only, A_raw, partials, &G, ticket, M, logits, Y_prob, Y_hat, st));
         if (!attention_only && G == 0) return HIPT_OK;
     } else if (hipt_clam_fused_supported(w)) {
         PROF(PC_ABMIL, hipt_clam_fused_launch(w, bag, N, attention_only, A_raw, partials, &G, st));

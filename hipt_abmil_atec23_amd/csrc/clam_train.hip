@@ -19,6 +19,8 @@
 // passes the scaled masks (0 or 1/(1-p)) it drew with torch's generator, so the RNG stream is the framework's own.
 // Everything is deterministic (no float atomics) unless the bag is so long that the weight-gradient reduction is split
 // over workgroups (N > 4096 rows), which uses fp32 atomic adds.
+#include <string.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -571,6 +573,14 @@ size_t bwd_lds(const hipt_clam_train_weights* w, bool dbag) {
 }  // namespace
 
 extern "C" {
+
+int hipt_clam_train_shape_supported(int s0, int s1, int s2, int n_att, int n_classes, int need_dbag) {
+    if (s0 <= 0 || s1 <= 0 || s2 <= 0 || (s0 | s1 | s2) % 4 != 0 || n_att < 1 || n_att > KMAX || n_classes < 1 || n_classes > KMAX) return 0;
+    hipt_clam_train_weights w;
+    memset(&w, 0, sizeof(w));
+    w.s0 = s0; w.s1 = s1; w.s2 = s2; w.n_att = n_att; w.n_classes = n_classes;
+    return fwd_lds(&w) <= 160 * 1024 && bwd_lds(&w, need_dbag != 0) <= 160 * 1024;
+}
 
 size_t hipt_clam_train_workspace_bytes(const hipt_clam_train_weights* w, int N) {
     if (!w || N <= 0) return 0;

@@ -127,6 +127,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // host side -------------------------------------------------------------------------------
 void hipt_set_error(const char* fmt, ...);
 
+// The library reads FOUR environment switches, all for debugging / A-B runs (README.md):
+//   HIPT_GENERIC=1        every operator takes its generic kernel (no streaming / packed-weight kernels)
+//   HIPT_NO_IMG=1         no activation images / head-major qkv between the streaming kernels
+//   HIPT_NO_PRUNE=1       the last ViT-256 block runs in full instead of for the [CLS] rows only
+//   HIPT_NO_FUSED_ATTN=1  LayerNorm-chained blocks run QKV GEMM + attention as two kernels instead of the fused one
+// read per call (cheap: host side, a handful of calls per forward), so a test may flip them inside one process.
+#include <stdlib.h>
+inline bool hipt_env_on(const char* name) {
+    const char* v = getenv(name);
+    return v != nullptr && v[0] != '\0' && v[0] != '0';
+}
+inline bool hipt_generic_only() { return hipt_env_on("HIPT_GENERIC"); }
+
 // hipFuncSetAttribute (the > 64 KiB dynamic-LDS opt-in) is a PER-DEVICE setting and a process may drive several GPUs
 // (HIPT_4K's device256 != device4k placement, a module on cuda:1 while cuda:0 is current): launchers cache it per
 // (kernel family, device).  hipt_cur_device(): ordinal of the calling thread's current device, -1 on failure.

@@ -304,8 +304,8 @@ __global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
 }  // namespace
 
 bool hipt_embed32_supported(int dtype, int D_, int K, int nty, int ntx) {
-    const bool off = getenv("HIPT_NO_EMBED32") != nullptr;  // (read per forward: the round-1 path = bf16 copy of the image + generic GEMM)
-    return !off && dtype == HIPT_BF16 && D_ == D && K == NCHN * KPC && ntx == 16 && nty > 0 && nty % 8 == 0;
+    // (HIPT_GENERIC: the generic path = a bf16 copy of the image + the im2col GEMM)
+    return !hipt_generic_only() && dtype == HIPT_BF16 && D_ == D && K == NCHN * KPC && ntx == 16 && nty > 0 && nty % 8 == 0;
 }
 
 size_t hipt_embed32_packed_bytes() { return (size_t)UPT * UNIT; }

@@ -64,13 +64,12 @@ struct SeqGemmParams {
     const float* ln_b;
     float ln_eps;
     const void* W;       // bf16 [N, K]
-    const void* wpk;     // optional (pipelined kernel only): W pre-packed in ring order (hipt_seqgemm_pack_launch)
+    const void* wpk;     // W pre-packed in ring order (hipt_seqgemm_pack_launch): what selects the pipelined kernel (null: the generic one)
     int img;             // (pipelined kernel only) activation images: bit 0 = A (bf16, no LayerNorm), bit 1 = out (N = 384);
                          // bit 2 = out (N = 1152) head-major [sequence][q/k/v][head][token][64], out_ntok tokens per sequence
     int out_ntok;
     int M, N, K;
     unsigned long long* stamps;  // debug: per-workgroup phase timestamps (100 MHz), or null
-    int debug;           // HIPT_SEQGEMM_DEBUG bits: 1 = skip epilogue stores, 2 = skip A load (zeros)
     int full_tiles;      // (set by the launcher) row tiles run whole; the rest are split nsplit ways over N
     int nsplit;
     const float* bias;
@@ -102,8 +101,8 @@ struct MlpParams {
     const void* w2;      // bf16 [D, hidden]
     const float* b2;
     int M, D, hidden;
-    const void* wpk;     // optional (pipelined kernel only): both weights pre-packed in ring order (hipt_mlp_pack_launch)
-    int wpk_fmt;         // format of wpk: 0 = mlp_pipe.hip's ring image, 1 = mlp32.hip's fragment image, 2 = mlp_ws.hip's step image
+    const void* wpk;     // optional (streaming kernel only): both weights pre-packed in ring order (hipt_mlp32_pack_launch)
+    int wpk_fmt;         // format of wpk: 1 = mlp32.hip's fragment image (the only one)
     int img;             // (pipelined kernel only) activation images: bit 0 = y1, xn_out and the updated x, bit 1 = x on entry
     int* counter;        // device int the launcher zeroes on the stream: the kernel's tile queue
     int counter_zeroed;  // 1: the caller guarantees *counter == 0 at launch (mlp32.hip / mlp_co.hip skip their memset); these kernels leave it 0 again
@@ -118,32 +117,22 @@ struct MlpParams {
     unsigned long long* stamps;
 };
 bool hipt_mlp_supported(int dtype, int D, int hidden);
-int hipt_mlp_launch(const MlpParams& p, hipStream_t st);  // dispatches to the pipelined D = 384 kernel when it applies
-bool hipt_mlp_pipe_supported(int dtype, int D, int hidden);
-int hipt_mlp_pipe_launch(const MlpParams& p, hipStream_t st);
-// The pipelined kernel's weight stream as ONE contiguous image (2 * hidden * D bf16 = the two matrices, re-ordered):
-// unit after unit in the order a tile pass consumes them, each unit byte for byte what its LDS ring slot holds.
-// A DMA piece then reads 1 KiB of consecutive bytes instead of 8 row segments of 128 B (2.4x the L2 -> LDS rate).
-int hipt_mlp_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);
-// The 32x32x16-MFMA form of the pipelined kernel (mlp32.hip): packed weights only, its own image format (same size).
-bool hipt_mlp32_supported(int dtype, int D, int hidden);  // (shapes only: hipt_vit_mlp_pack_format chooses the kernel)
+int hipt_mlp_launch(const MlpParams& p, hipStream_t st);  // dispatches to the packed-weight D = 384 kernel (mlp32.hip) when it applies
+// The streaming kernel (mlp32.hip, 32x32x16 MFMAs): its weight stream is ONE contiguous image (2 * hidden * D bf16 = the two
+// matrices, re-ordered): unit after unit in the order a tile pass consumes them, each unit byte for byte what its LDS ring slot
+// holds, so that a DMA piece reads 1 KiB of consecutive bytes instead of 8 row segments of 128 B (2.4x the L2 -> LDS rate).
+bool hipt_mlp32_supported(int dtype, int D, int hidden);
 int hipt_mlp32_launch(const MlpParams& p, hipStream_t st);
-// (wproj != null: the proj matrix [D, D] as six more units behind the fc1 / fc2 units: D * D * 2 more bytes)
+// (wproj != null: the proj matrix [D, D] as six more units behind the fc1 / fc2 units: D * D * 2 more bytes; only the
+//  experiment builds -- HIPT_EXPERIMENTS -- have a kernel that reads them)
 int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st, const void* wproj = nullptr);
-// fc2 column-owned (mlp_co.hip): the same format-1 image; W2 goes L2 -> registers, the hidden tile through LDS.  Image forms (img == 3) only.
-bool hipt_mlp_co_supported(int dtype, int D, int hidden);
-int hipt_mlp_co_launch(const MlpParams& p, hipStream_t st);
-// The wave-specialised form (mlp_ws.hip: 8 waves, fc1 + GELU waves and fc2 waves sharing rows): image format 2.
-bool hipt_mlp_ws_supported(int dtype, int D, int hidden);  // (shapes only; opt-in through hipt_vit_mlp_pack_format)
-int hipt_mlp_ws_launch(const MlpParams& p, hipStream_t st);
-int hipt_mlp_ws_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);
 
 int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, const float* b, void* out, int out_dtype,
                           int64_t out_stride, int rows, int D, float eps, hipStream_t st);
 
 int hipt_attention_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale,
                           int dtype, hipStream_t st, int out_img = 0, int qkv_hm = 0);  // dispatches to the bf16 / head-dim-64 kernel when it applies
-bool hipt_attention64_supported(int dtype, int dh, int ntok, bool want_probs);  // (false too when HIPT_ATTN_V1 is set)
+bool hipt_attention64_supported(int dtype, int dh, int ntok, bool want_probs);
 int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st, int out_img = 0, int qkv_hm = 0);
 
 // attention of the [CLS] query only (bf16, head dim 64): out[B, heads*64] bf16 and/or probs[B, heads, ntok] fp32 (either may be null)
@@ -170,10 +159,6 @@ bool hipt_clam_stream_supported(const hipt_clam_weights* w);
 int hipt_clam_stream_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw,
                             float* partials, int* n_partials, unsigned* ticket, float* M, float* logits, float* Y_prob,
                             int64_t* Y_hat, hipStream_t st);  // n_partials = 0: combine already done in the kernel
-int hipt_clam_ring_pack_launch(const hipt_clam_weights* w, void* out, hipStream_t st);
-bool hipt_clam_ring_supported(const hipt_clam_weights* w);  // bf16 [384,128,64]: weights in registers, bag through an LDS-DMA ring
-int hipt_clam_ring_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, float* partials,
-                          int* n_partials, unsigned* ticket, float* M, float* logits, float* Y_prob, int64_t* Y_hat, hipStream_t st);
 int hipt_clam_combine_launch(const float* partials, int G, const hipt_clam_weights* w, float* M, float* logits,
                              float* Y_prob, int64_t* Y_hat, hipStream_t st);
 int hipt_gate_launch(const float* ab, int64_t ld, int N, int S2, const float* wc, const float* bc, float* A,

@@ -423,8 +423,7 @@ int launch(const MlpParams& p_in, hipStream_t st) {
     p.ntiles = p.full_tiles + (tail_rows > 0 ? (tail_rows + 15) / 16 : 0);
     const int grid = p.ntiles < ncu ? p.ntiles : ncu;
     // long launches (>= 6 tiles per workgroup) start their 4 workgroup groups a quarter of a tile time apart
-    static const char* stag_env = getenv("HIPT_MLP_STAGGER_US");
-    const int stag_us = stag_env ? atoi(stag_env) : 20;
+    const int stag_us = 20;
     p.stagger = (p.full_tiles >= 6 * ncu) ? stag_us * 100 : 0;
     if (hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
         hipt_set_error("mlp: hipMemsetAsync(counter) failed");
@@ -482,14 +481,9 @@ int hipt_mlp_launch(const MlpParams& p, hipStream_t st) {
     HIPT_CHECK_ARG(((uintptr_t)p.x % 16) == 0 && ((uintptr_t)p.w1 % 16) == 0 && ((uintptr_t)p.w2 % 16) == 0 &&
                        ((uintptr_t)p.y1 % 16) == 0,
                    "mlp: 16-byte alignment required");
-    static const bool no_pipe = getenv("HIPT_NO_MLP_PIPE") != nullptr;
-    if (!no_pipe && p.wpk && p.wpk_fmt == 2 && hipt_mlp_ws_supported(HIPT_BF16, p.D, p.hidden)) return hipt_mlp_ws_launch(p, st);
-    // (opt-in experiment, HIPT_MLP_CO=1: fc2 column-owned -- a third fewer LDS fragment reads, half the weight DMA, the same time)
-    if (!no_pipe && p.wpk && p.wpk_fmt == 1 && p.img == 3 && !p.fold && p.M % 16 == 0 && hipt_mlp_co_supported(HIPT_BF16, p.D, p.hidden) && getenv("HIPT_MLP_CO"))
-        return hipt_mlp_co_launch(p, st);
-    if (!no_pipe && p.wpk && p.wpk_fmt == 1 && hipt_mlp32_supported(HIPT_BF16, p.D, p.hidden)) return hipt_mlp32_launch(p, st);
-    if (!no_pipe && hipt_mlp_pipe_supported(HIPT_BF16, p.D, p.hidden)) return hipt_mlp_pipe_launch(p, st);
-    HIPT_CHECK_ARG(p.img == 0, "mlp: activation images exist only in the pipelined kernel (img=%d)", p.img);
+    // the streaming kernel (mlp32.hip) runs from its packed weight image: callers without one get the generic kernel below
+    if (!hipt_generic_only() && p.wpk && p.wpk_fmt == 1 && hipt_mlp32_supported(HIPT_BF16, p.D, p.hidden)) return hipt_mlp32_launch(p, st);
+    HIPT_CHECK_ARG(p.img == 0 && !p.xn_out && !p.fold, "mlp: activation images / the chained LayerNorm exist only in the streaming kernel (img=%d)", p.img);
     if (p.D == 384) return launch<6>(p, st);
     if (p.D == 192) return launch<3>(p, st);
     hipt_set_error("mlp: D=%d not in {192, 384}", p.D);

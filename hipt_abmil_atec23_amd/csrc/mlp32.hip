@@ -199,14 +199,6 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     int tile = __builtin_amdgcn_readfirstlane(tile_s[0]);
     if (HIPT_STAMPS_ON(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
 
-    if (p.stagger > 0) {
-        // Start the workgroups in four groups a quarter of a tile time apart ((block / 8) & 3 mixes the groups inside every XCD):
-        // the row phases of a tile move 0.9 MB per CU and run at 24 GB/s per CU when all 256 CUs are in theirs, at 50-60 when a
-        // quarter of them is.  The tile queue evens the late starters out.
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long wait = (unsigned long long)(((blockIdx.x >> 3) & 3) * p.stagger);
-        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
-    }
     const uint32_t lbase = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
     const uint32_t fbase = lbase + lane * 16;                                         // + slot * UNIT + fragment * 1024
     const uint32_t b1base = (uint32_t)(uintptr_t)(LDS_AS char*)b1s + 16 * h;          // b1[Hb + 32 U + 8 q + 4 h ..]: + (Hb + 32 U + 8 q) * 4
@@ -275,10 +267,6 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         }
         nrows = (p.M - row0) < nrows ? (p.M - row0) : nrows;
         PSTAMP(0);
-        if (p.stagger < 0) {  // (experiment, HIPT_MLP_IDLE_US: every tile starts with an idle wait -- is the kernel's time additive, or does the power cap give it back?)
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(-p.stagger)) __builtin_amdgcn_s_sleep(64);
-        }
         // next tile: requested now, handed to LDS behind the first row loads (the atomic's round trip is theirs too), read by every
         // wave after the first ring barrier
         int nt_req = 0;
@@ -842,18 +830,29 @@ int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
                        p.M, p.fold);
         return HIPT_E_BADARG;
     }
+#ifdef HIPT_EXPERIMENTS  // proj folded into the MLP (break-even): tools/mlp_probe.hip builds it, the library does not
     auto k = p.fold ? (p.img == 3 ? mlp32_kernel<true, true, DBG, true> : mlp32_kernel<true, false, DBG, true>)
              : p.img == 3 ? mlp32_kernel<true, true, DBG>
              : p.img == 1 ? mlp32_kernel<true, false, DBG>
                           : mlp32_kernel<false, false, DBG>;
+#else
+    if (p.fold) {
+        hipt_set_error("mlp32: the proj-folding kernel exists only in experiment builds (HIPT_EXPERIMENTS)");
+        return HIPT_E_UNSUPPORTED;
+    }
+    auto k = p.img == 3 ? mlp32_kernel<true, true, DBG> : p.img == 1 ? mlp32_kernel<true, false, DBG> : mlp32_kernel<false, false, DBG>;
+#endif
     static DevOnce once;
     HIPT_CUR_DEVICE(dev);
     if (!once.done[dev]) {
         if (hipFuncSetAttribute((const void*)mlp32_kernel<true, true, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)mlp32_kernel<true, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)mlp32_kernel<false, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)mlp32_kernel<true, true, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)mlp32_kernel<true, false, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            hipFuncSetAttribute((const void*)mlp32_kernel<false, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess
+#ifdef HIPT_EXPERIMENTS
+            || hipFuncSetAttribute((const void*)mlp32_kernel<true, true, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mlp32_kernel<true, false, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess
+#endif
+        ) {
             hipt_set_error("hipFuncSetAttribute(mlp32) failed");
             return HIPT_E_LAUNCH;
         }
@@ -878,11 +877,7 @@ int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     const int tail_rows = p.M - p.full_tiles * TMR;
     p.ntiles = p.full_tiles + (tail_rows > 0 ? (tail_rows + 15) / 16 : 0);
     const int grid = p.ntiles < ncu ? p.ntiles : ncu;
-    static const char* stag_env = getenv("HIPT_MLP_STAGGER_US");
-    const int stag_us = stag_env ? atoi(stag_env) : 0;
-    p.stagger = (p.full_tiles >= 6 * ncu) ? stag_us * 100 : 0;
-    static const char* idle_env = getenv("HIPT_MLP_IDLE_US");
-    if (idle_env) p.stagger = -atoi(idle_env) * 100;
+    p.stagger = 0;
     if (!p.counter_zeroed && hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
         hipt_set_error("mlp32: hipMemsetAsync(counter) failed");
         return HIPT_E_LAUNCH;

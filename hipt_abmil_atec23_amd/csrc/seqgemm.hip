@@ -54,7 +54,7 @@ template <int FLAGS>
 __device__ __forceinline__ void seq_epilogue(const SeqGemmParams& p, uint32_t bias_lds, int64_t row, int n, f32x4 v) {
     v += lds_ld128(bias_lds + n * 4);  // asm LDS read: a visible one would cost a vmcnt(0) ring drain (common.h)
     if constexpr (FLAGS & HIPT_EPI_GELU) {
-        if (!(p.debug & 4)) {
+        {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
         }
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void seqgemm_kernel(const SeqGemmParams p) 
             const int i = t * KS + kt;
             // slab i has landed when at most the later slabs already issued remain in flight
             const int issued_after = (i + NSLOT - 2 < nslab ? i + NSLOT - 2 : nslab - 1) - i;
-            if (!(p.debug & 2)) wait_slabs(issued_after);
+            wait_slabs(issued_after);
             __builtin_amdgcn_s_barrier();  // slab i visible to all; all waves are done reading slab i-1
             if (i + NSLOT - 1 < nslab) issue(i + NSLOT - 1);  // reuses the slot of slab i-1
             // 8 groups per slab: (ks, column-fragment pair), 8 MFMAs each.  Two explicit W register sets:
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void seqgemm_kernel(const SeqGemmParams p) 
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) {
             const int r = (wave * 4 + mf) * 16 + li;
-            if (r < nrows && !(p.debug & 1)) {
+            if (r < nrows) {
 #pragma unroll
                 for (int nf = 0; nf < 8; ++nf) {
                     const int n = n0 + nf * 16 + 4 * g;
@@ -345,14 +345,12 @@ bool hipt_seqgemm_supported(int dtype, int K) { return dtype == HIPT_BF16 && (K 
 
 int hipt_seqgemm_launch(const SeqGemmParams& p_in, bool ln, int flags, hipStream_t st) {
     SeqGemmParams p = p_in;
-    static const int dbg = getenv("HIPT_SEQGEMM_DEBUG") ? atoi(getenv("HIPT_SEQGEMM_DEBUG")) : 0;
-    p.debug = dbg;
     HIPT_CHECK_ARG(p.M > 0 && p.N > 0 && p.N % 4 == 0 && p.N <= MAXN, "seqgemm: bad shape M=%d N=%d", p.M, p.N);
     HIPT_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0 && ((uintptr_t)p.out % 16) == 0 && p.ldc % 4 == 0 &&
                        (p.lda * (ln ? 4 : 2)) % 16 == 0,
                    "seqgemm: 16-byte alignment required");
-    static const bool no_pipe = getenv("HIPT_NO_SEQGEMM_PIPE") != nullptr;
-    if (!no_pipe && p.counter && hipt_seqgemm_pipe_supported(HIPT_BF16, p.K, p.N, ln, flags)) return hipt_seqgemm_pipe_launch(p, ln, st);
+    // the pipelined kernel streams a pre-packed weight image: callers without one (NULL *_pk) get the generic kernel
+    if (!hipt_generic_only() && p.counter && p.wpk && hipt_seqgemm_pipe_supported(HIPT_BF16, p.K, p.N, ln, flags)) return hipt_seqgemm_pipe_launch(p, ln, st);
     HIPT_CHECK_ARG(p.img == 0, "seqgemm: activation images / head-major output exist only in the pipelined kernel (img=%d)", p.img);
     const int tiles_n = (p.N + 127) / 128, tiles_m = (p.M + TM - 1) / TM;
     // whole rounds of 256 CUs run one workgroup per row tile; the tiles of the last partial round are

@@ -421,14 +421,18 @@ int hipt_seqgemm_pipe_launch_dbg(const SeqGemmParams& p_in, hipStream_t st) {
     // p.img: bit 0 = A is an activation image (LN = false), bit 1 = the output is written as one (N = ldc = 384); both
     // need the packed weights (one instantiation less) and whole 16-row fragments
     // bit 2 = head-major q|k|v output (N = 1152 = ldc, p.out_ntok set, the buffer under 4 GiB)
-    if (p.img && (!p.wpk || ((p.img & 3) && (LN || p.M % 16 != 0)) || p.img > 5 || p.img == 3 + 4 || ((p.img & 2) && (p.N != K || p.ldc != K)) ||
+    if (p.img && (((p.img & 3) && (LN || p.M % 16 != 0)) || p.img > 5 || p.img == 3 + 4 || ((p.img & 2) && (p.N != K || p.ldc != K)) ||
                   ((p.img & 1) && p.lda != K) || ((p.img & 4) && (p.N != 3 * K || p.ldc != 3 * K || p.out_ntok <= 0 || (p.img & 2) ||
                                                                 (int64_t)p.M * p.N * 2 >= ((int64_t)1 << 32) - 65536)))) {
         hipt_set_error("seqgemm_pipe: activation images: unsupported combination (img=%d LN=%d M=%d N=%d lda=%lld ldc=%lld packed=%d)", p.img,
                        (int)LN, p.M, p.N, (long long)p.lda, (long long)p.ldc, p.wpk != nullptr);
         return HIPT_E_BADARG;
     }
-    auto k = p.wpk ? seqgemm_pipe_kernel<LN, DBG, true> : seqgemm_pipe_kernel<LN, DBG, false>;
+    if (!p.wpk) {
+        hipt_set_error("seqgemm_pipe: needs the packed weight image (hipt_seqgemm_pack_launch)");
+        return HIPT_E_BADARG;
+    }
+    auto k = seqgemm_pipe_kernel<LN, DBG, true>;
     if constexpr (LN) {
         if (p.img == 4) k = seqgemm_pipe_kernel<true, DBG, true, false, false, true>;
     }
@@ -447,8 +451,7 @@ int hipt_seqgemm_pipe_launch_dbg(const SeqGemmParams& p_in, hipStream_t st) {
             hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<false, DBG, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<LN, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<LN, DBG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            hipFuncSetAttribute((const void*)seqgemm_pipe_kernel<LN, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(seqgemm_pipe) failed");
             return HIPT_E_LAUNCH;
         }

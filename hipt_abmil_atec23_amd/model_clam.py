@@ -139,8 +139,12 @@ class Attn_Net_Gated(nn.Module):
         return A.reshape(*x.shape[:-1], 1), x
 
 
-def _train_supported(sizes, k_att, n_classes) -> bool:
-    return all(v > 0 and v % 4 == 0 for v in sizes) and 1 <= k_att <= 8 and 1 <= n_classes <= 8
+def _train_supported(sizes, k_att, n_classes, need_dbag=False) -> bool:
+    """Do the training kernels take this shape (widths, branches, classes AND the LDS their row tiles need)?  Asked of the
+    library itself (hipt_clam_train_shape_supported), so the answer cannot drift from the kernels' own checks."""
+    if not (all(v > 0 and v % 4 == 0 for v in sizes) and 1 <= k_att <= 8 and 1 <= n_classes <= 8):
+        return False
+    return bool(N.lib().hipt_clam_train_shape_supported(int(sizes[0]), int(sizes[1]), int(sizes[2]), int(k_att), int(n_classes), int(need_dbag)))
 
 
 class _ClamTrainFn(torch.autograd.Function):
@@ -180,6 +184,11 @@ class _ClamTrainFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.w = w          # (the pointers stay valid: every tensor they name is in ctx.keep)
         ctx.keep = keep
+        # `f` returns the parameter's own storage when it is already fp32 and contiguous: an in-place update between forward
+        # and backward (optimizer.step) would silently change what the backward reads -- autograd's saved-tensor version
+        # check raises there, and so does this
+        srcs = [bag, m1, ma, mb, w1, b1, wa, ba, wb, bb, wc, bc, *cls]
+        ctx.versions = [(t, t._version) for t in srcs if t is not None]
         ctx.saved = (h1, t, s, A_raw, stats, M, ids)
         ctx.set_materialize_grads(False)
         if ids is None:
@@ -190,6 +199,10 @@ class _ClamTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits, dA_raw, dM, dh1_sel, _ids, _yhat):
         cfg, w, keep = ctx.cfg, ctx.w, ctx.keep
+        for t, v in ctx.versions:
+            if t._version != v:
+                raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation "
+                                   f"(CLAM training step: a {tuple(t.shape)} tensor is at version {t._version}, expected {v})")
         x, m1, ma, mb = keep[:4]
         h1, t, s, A_raw, stats, M, ids = ctx.saved
         dev = x.device
@@ -391,7 +404,7 @@ class CLAM_SB(nn.Module):
         if not self._gate or not h.is_cuda:
             return False
         K = self.attention_net[-1].attention_c.out_features
-        if not _train_supported(self._sizes, K, self.n_classes):
+        if not _train_supported(self._sizes, K, self.n_classes, need_dbag=torch.is_grad_enabled() and h.requires_grad):
             return False
         return self._multi or dropout_on or _needs_autograd(self, h)
 
@@ -419,11 +432,10 @@ class CLAM_SB(nn.Module):
             w.n_classes = self.classifiers.out_features
             for k, t in keep.items():
                 setattr(w, k, t.data_ptr())
-            nb = N.lib().hipt_clam_ring_packed_bytes(C_.byref(w))
-            if nb and os.environ.get("HIPT_ABMIL_RING"):  # register-order image for the opt-in bf16 [384,128,64] ring kernel
-                keep["ring_pk"] = torch.empty(nb, dtype=torch.uint8, device=device)
-                N.call("hipt_clam_pack_ring", C_.byref(w), N.ptr(keep["ring_pk"]), N.stream_ptr(device))
-                w.ring_pk = keep["ring_pk"].data_ptr()
+            # |A_raw - bc| <= sum |wc_j| (tanh * sigmoid lies in (-1, 1)): lets the streaming kernel exponentiate against a fixed
+            # shift instead of a running maximum (include/hipt_abmil.h, hipt_clam_weights.logit_bound); one tiny reduction per
+            # set of weights, read back here once
+            w.logit_bound = float(keep["wc"].abs().sum().item())
             self._packed = (key, w, keep)
         return self._packed[1]
 
@@ -432,7 +444,9 @@ class CLAM_SB(nn.Module):
         if self._use_train_kernels(h, dropout_on):
             N.same_device(type(self).__name__, h.device, *self.parameters())
             return self._train_forward(h, label, instance_eval, return_features, attention_only)
-        if not self._gate or ((dropout_on or _needs_autograd(self, h)) and not h.is_cuda) or self._multi:
+        # whatever the training kernels do not take (ungated head, CPU tensors, > 8 classes, widths beyond their LDS) keeps the
+        # PyTorch-op sequence as soon as dropout is active or a gradient is needed: the inference kernels have neither
+        if not self._gate or dropout_on or _needs_autograd(self, h) or self._multi:
             return self._torch_forward(h, label, instance_eval, return_features, attention_only)
         N.require_cuda(h, "CLAM_SB")
         if h.dim() != 2 or h.shape[0] == 0:

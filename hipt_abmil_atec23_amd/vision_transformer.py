@@ -83,14 +83,14 @@ class _PackedVit:
     def _prepack(self, depth: int, dev) -> None:
         """Ring-ordered images of the block matrices for the streaming kernels (include/hipt_abmil.h, *_pk): one extra
         copy of the bf16 weights, made once per set of weights (this object is rebuilt when a parameter changes)."""
-        if os.environ.get("HIPT_NO_PREPACK") or dev.type != "cuda":
+        if dev.type != "cuda":
             return
         lib = N.lib()
-        for what, field in ((N.PACK_QKV, "qkv_pk"), (N.PACK_PROJ, "proj_pk"), (N.PACK_MLP, "mlp_pk")):
+        for what, field in ((N.PACK_QKV, "qkv_pk"), (N.PACK_PROJ, "proj_pk"), (N.PACK_MLP, "mlp_pk"), (N.PACK_QKV_ATT, "qkv_att_pk")):
             nbytes = lib.hipt_vit_packed_bytes(C.byref(self.w), what)
             if not nbytes:
                 continue
-            # (the library has several fused-MLP kernels, each with its own image order: the format travels with the image)
+            # (the image format travels with the fused-MLP image: hipt_block_weights.mlp_pk_fmt)
             fmt = lib.hipt_vit_mlp_pack_format(C.byref(self.w)) if what == N.PACK_MLP else 0
             for i in range(depth):
                 img = torch.empty(nbytes, dtype=torch.uint8, device=dev)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HIPT_ABI_VERSION 3
+#define HIPT_ABI_VERSION 4
 
 enum { HIPT_F32 = 0, HIPT_BF16 = 1 };
 
@@ -73,15 +73,19 @@ typedef struct hipt_block_weights {
      * one run of consecutive bytes instead of eight 128-byte row segments (2.4x the L2->LDS rate on MI355X).  They
      * are a cache of qkv_w / proj_w / fc1_w+fc2_w: re-pack after the weights change. */
     const void*  qkv_pk;  const void* proj_pk;  const void* mlp_pk;
-    /* Which fused-MLP kernel mlp_pk was packed for: the value hipt_vit_mlp_pack_format returned when it was packed (the
-     * library has more than one fused-MLP kernel, each with its own image order; an image is only valid with its format;
-     * format 1 also holds proj_w, which that kernel applies itself: re-pack after proj_w changes, too). */
+    /* The image format of mlp_pk: the value hipt_vit_mlp_pack_format returned when it was packed (1 = the streaming kernel's
+     * fragment image, the only format of this version; 0 = no packed form for this shape). */
     int32_t      mlp_pk_fmt;  int32_t reserved;
+    /* Optional: qkv_w once more, head by head in the operand order of the fused QKV + attention kernel (HIPT_PACK_QKV_ATT;
+     * ViT-256 shape only: D = 384, 6 heads of 64, 257 tokens).  NULL: LayerNorm-chained blocks run the QKV GEMM and the
+     * attention as two kernels with the q|k|v tensor in HBM between them. */
+    const void*  qkv_att_pk;
 } hipt_block_weights;
 
 #define HIPT_PACK_QKV  0
 #define HIPT_PACK_PROJ 1
 #define HIPT_PACK_MLP  2   /* fc1 and fc2 in one image, in the format hipt_vit_mlp_pack_format names */
+#define HIPT_PACK_QKV_ATT 3
 
 /* One ViT (ViT-256 `vit_small` or ViT-4K `vit4k_xs`, or any width the classes are built with).
  * `pos` is the ALREADY INTERPOLATED positional table for this token grid
@@ -161,9 +165,8 @@ size_t hipt_vit_workspace_bytes(const hipt_vit_weights* w, int nseq);
  * Done once per set of weights by the module that owns them (vision_transformer.py:_PackedVit here). */
 size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what);
 /* The fused-MLP image format hipt_vit_pack_weights(.., HIPT_PACK_MLP, ..) writes for this model, to be stored in
- * hipt_block_weights.mlp_pk_fmt beside the pointer: 1 = the 32x32x16-MFMA kernel (default), 0 = the 16x16x32-MFMA kernel
- * (HIPT_NO_MLP32 in the environment, or a shape the other one does not take), 2 = the wave-specialised kernel (HIPT_MLP_WS,
- * experimental).  The environment is read on every call; a packed image keeps the format it was made with. */
+ * hipt_block_weights.mlp_pk_fmt beside the pointer: 1 = the streaming (32x32x16-MFMA) kernel's fragment image, 0 = this
+ * dtype / shape has no packed form (the generic kernel reads the row-major matrices). */
 int hipt_vit_mlp_pack_format(const hipt_vit_weights* w);
 int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* out, void* stream);
 /* Scratch of the whole-forward calls below (residual stream + block scratch + bf16 input copy). */
@@ -271,21 +274,18 @@ typedef struct hipt_clam_weights {
                                               rows [0,S2) = a, rows [S2,2*S2) = b; bias likewise */
     const float* wc;  const float* bc;     /* attention_c Linear(S2,1): [S2], [1]               */
     const float* wcls; const float* bcls;  /* classifiers Linear(S1,C): [C,S1], [C]             */
-    const void*  ring_pk;     /* optional (NULL = absent): w1 and wab as MFMA operand fragments in register order for the
-                                 bf16 [384,128,64] kernel, written by hipt_clam_pack_ring -- a cache of w1 / wab: re-pack
-                                 after the weights change                                                        */
+    float        logit_bound; /* optional (0 = unknown): an upper bound of |A_raw - bc| = sum_j |wc_j| (tanh * sigmoid lies in
+                                 (-1, 1)), computed in fp32 by the owner of the weights; lets the streaming kernels exponentiate against
+                                 the fixed shift bc + bound instead of a running maximum when the bound is small enough */
+    int32_t      reserved2;
 } hipt_clam_weights;
 
-/* Packed weight image of the ring kernel (hipt_clam_weights.ring_pk): its size (0: this dtype / shape has none, leave the
- * pointer NULL) and the pack itself into `out` (device memory of that size).  Once per set of weights. */
-size_t hipt_clam_ring_packed_bytes(const hipt_clam_weights* w);
-int hipt_clam_pack_ring(const hipt_clam_weights* w, void* out, void* stream);
-
 /* Scratch of the calls below.  ONE piece of state lives in it: the 256-byte "ticket block" at byte offset
- * hipt_clam_ticket_offset() (the arrival counter of the in-kernel combine).  It must be ZERO before the first call that
- * uses a given workspace (zero it once when allocating) and every completed call leaves it zero again -- no memset per
- * call, any dispatch order, graph-replayable.  Calls that may run concurrently (different streams) need different
- * workspaces. */
+ * hipt_clam_ticket_offset() (= 0: the head of the workspace, whatever the widths; the arrival counter of the in-kernel
+ * combine).  It must be ZERO before the first call that uses a given workspace (zero it once when allocating) and every
+ * completed call leaves it zero again -- no memset per call, any dispatch order, graph-replayable; no path of the library
+ * writes anything else there, so one workspace may serve modules of different widths.  Calls that may run concurrently
+ * (different streams) need different workspaces. */
 size_t hipt_clam_workspace_bytes(const hipt_clam_weights* w, int N);
 size_t hipt_clam_ticket_offset(const hipt_clam_weights* w, int N);
 
@@ -334,6 +334,10 @@ typedef struct hipt_clam_train_grads {     /* outputs of the backward, same shap
 } hipt_clam_train_grads;
 
 size_t hipt_clam_train_workspace_bytes(const hipt_clam_train_weights* w, int N);   /* scratch of the backward */
+/* 1 when the training kernels take this size_dict entry with K = n_att attention branches and C = n_classes (widths multiples
+ * of 4, K and C <= 8, the row tiles of forward AND backward within the 160 KiB of LDS; need_dbag: the bag requires a
+ * gradient too), else 0: the caller then keeps the PyTorch-op sequence ('big' [1024,512,384] with a bag gradient does not fit). */
+int hipt_clam_train_shape_supported(int s0, int s1, int s2, int n_att, int n_classes, int need_dbag);
 
 /* Forward.  bag [N,S0] fp32.  m1 [N,S1], ma / mb [N,S2]: dropout masks already scaled (0 or 1/(1-p)), or NULL
  * (nn.Dropout after the ReLU, :86-87, and inside Attn_Net_Gated, :48-52; the caller draws them).

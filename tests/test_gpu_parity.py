@@ -331,43 +331,27 @@ def test_vit256_bf16_cls_pruned_last_block_matches_full(vit256):
     assert rel_l2(pruned, full.cpu().numpy()) < 3e-3 and cosine(pruned, full.cpu().numpy()) > 0.99999
 
 
-def test_vit256_prepacked_weight_images_change_nothing(vit256, monkeypatch):
-    """The ring-ordered weight images (hipt_block_weights.*_pk, made by hipt_vit_pack_weights) hold the same values as the
-    row-major matrices: forward() and the full-block path give identical bits with and without them -- for the kernels that
-    run from either (QKV, proj, and the 16x16x32 fused MLP, HIPT_NO_MLP32=1).  The default fused MLP (32x32x16 MFMAs, its own
-    image, mlp_pk_fmt = 1) exists only in packed form: it sums in another order and uses the 3-coefficient GELU, so against the
-    row-major path it is held to the bf16 bar instead."""
-    if os.environ.get("HIPT_NO_PREPACK") or os.environ.get("HIPT_MLP_WS"):
-        pytest.skip("HIPT_NO_PREPACK / HIPT_MLP_WS is set for the whole run (the latter overrides the formats this test switches between)")
-    x = synth.hash_uniform_torch((4, 3, 256, 256), 19, device=DEV)
+def test_vit256_streaming_kernels_vs_generic_kernels(vit256, monkeypatch):
+    """The streaming kernels (packed weight images hipt_block_weights.*_pk made by hipt_vit_pack_weights, LayerNorm chaining,
+    32x32x16 fused MLP with the 3-coefficient GELU, fused QKV + attention) against the generic kernels of the same operators
+    reading the row-major matrices (HIPT_GENERIC=1: seqgemm.hip, attention.hip, mlp.hip with the erf GELU): other summation
+    orders, the same model -- held to the bf16 bar, forward() and the full-block path alike."""
+    x = synth.hash_uniform_torch((16, 3, 256, 256), 19, device=DEV)
     vit256.set_compute_dtype("bf16")
     try:
         pk = vit256._tokens(x)[0]
-        assert all(pk.blocks[i].mlp_pk and pk.blocks[i].qkv_pk and pk.blocks[i].proj_pk for i in range(pk.w.depth))
-        # (a whole run under HIPT_NO_MLP32 starts from that kernel's format instead of the default's)
-        exp_fmt = 0 if os.environ.get("HIPT_NO_MLP32") else 1
-        assert all(pk.blocks[i].mlp_pk_fmt == exp_fmt for i in range(pk.w.depth))
+        assert all(pk.blocks[i].mlp_pk and pk.blocks[i].qkv_pk and pk.blocks[i].proj_pk and pk.blocks[i].qkv_att_pk for i in range(pk.w.depth))
+        assert all(pk.blocks[i].mlp_pk_fmt == 1 for i in range(pk.w.depth))
         default = vit256(x), vit256.get_intermediate_layers(x, n=2)
-        monkeypatch.setenv("HIPT_NO_MLP32", "1")  # read when the images are made: the format travels with the image
-        vit256._packed.clear()
-        pk1 = vit256._tokens(x)[0]
-        assert all(pk1.blocks[i].mlp_pk and pk1.blocks[i].mlp_pk_fmt == 0 for i in range(pk1.w.depth))
-        with_img = vit256(x), vit256.get_intermediate_layers(x, n=2)
-        monkeypatch.setenv("HIPT_NO_PREPACK", "1")
-        vit256._packed.clear()
-        pk0 = vit256._tokens(x)[0]
-        assert not any(pk0.blocks[i].mlp_pk or pk0.blocks[i].qkv_pk or pk0.blocks[i].proj_pk for i in range(pk0.w.depth))
-        without = vit256(x), vit256.get_intermediate_layers(x, n=2)
+        monkeypatch.setenv("HIPT_GENERIC", "1")
+        generic = vit256(x), vit256.get_intermediate_layers(x, n=2)
     finally:
-        monkeypatch.delenv("HIPT_NO_PREPACK", raising=False)
-        monkeypatch.delenv("HIPT_NO_MLP32", raising=False)
-        vit256._packed.clear()
+        monkeypatch.delenv("HIPT_GENERIC", raising=False)
         vit256.set_compute_dtype("fp32")
-    assert torch.equal(with_img[0], without[0])
-    assert all(torch.equal(a, b) for a, b in zip(with_img[1], without[1]))
-    rel = float((default[0] - without[0]).norm() / without[0].norm())
-    print(f"32x32x16 fused MLP vs the row-major path: rel-L2 {rel:.2e}")
-    assert rel < 1.3e-2
+    rel = float((default[0] - generic[0]).norm() / generic[0].norm())
+    rel_i = max(float((a - b).norm() / b.norm()) for a, b in zip(default[1], generic[1]))
+    print(f"streaming kernels vs generic kernels: [CLS] features rel-L2 {rel:.2e}, last two blocks' tokens {rel_i:.2e}")
+    assert 0 < rel < 1.3e-2 and rel_i < 1.3e-2  # (0 would mean the switch did nothing)
     # fp32 weights have no packed form: the size query says so and packing is refused
     pk32 = vit256._tokens(x)[0]
     assert N.lib().hipt_vit_packed_bytes(pk32.ref, N.PACK_MLP) == 0
@@ -375,155 +359,97 @@ def test_vit256_prepacked_weight_images_change_nothing(vit256, monkeypatch):
         N.call("hipt_vit_pack_weights", pk32.ref, 0, N.PACK_MLP, N.ptr(x), N.stream_ptr(x.device))
 
 
-def test_vit256_experimental_wave_specialised_mlp(vit256, monkeypatch):
-    """csrc/mlp_ws.hip (HIPT_MLP_WS=1 when the images are made, mlp_pk_fmt = 2): 8 waves per workgroup, fc1 + GELU waves and fc2
-    waves sharing rows through LDS.  Opt-in; held to the same bars as the default kernel: against the row-major 16x16x32 path
-    and bitwise against itself under a different batching."""
-    if os.environ.get("HIPT_NO_PREPACK"):
-        pytest.skip("HIPT_NO_PREPACK is set for the whole run")
-    x = synth.hash_uniform_torch((5, 3, 256, 256), 29, device=DEV)
-    vit256.set_compute_dtype("bf16")
-    try:
-        monkeypatch.setenv("HIPT_MLP_WS", "1")
-        vit256._packed.clear()
-        pk = vit256._tokens(x)[0]
-        assert all(pk.blocks[i].mlp_pk_fmt == 2 for i in range(pk.w.depth))
-        ws = vit256(x)
-        ws_sub = vit256(x[1:4])
-        monkeypatch.delenv("HIPT_MLP_WS")
-        monkeypatch.setenv("HIPT_NO_PREPACK", "1")
-        vit256._packed.clear()
-        plain = vit256(x)
-    finally:
-        monkeypatch.delenv("HIPT_MLP_WS", raising=False)
-        monkeypatch.delenv("HIPT_NO_PREPACK", raising=False)
-        vit256._packed.clear()
-        vit256.set_compute_dtype("fp32")
-    rel = float((ws - plain).norm() / plain.norm())
-    print(f"wave-specialised fused MLP vs the row-major path: rel-L2 {rel:.2e}")
-    assert rel < 1.3e-2
-    assert torch.equal(ws[1:4], ws_sub)
-
-
-def test_vit256_experimental_column_owned_mlp(vit256, monkeypatch):
-    """csrc/mlp_co.hip (HIPT_MLP_CO=1, read per launch; same format-1 weight image): fc2 column-owned -- W2 fragments go L2 ->
-    registers and feed four MFMAs each, the GELU'd hidden tile is exchanged through LDS.  Its x is the default kernel's bit for
-    bit (same products in the same order); the chained LayerNorm sums a row across four waves, so the features differ in the
-    last bits only.  Bitwise against itself under a different batching."""
-    if any(os.environ.get(k) for k in ("HIPT_NO_PREPACK", "HIPT_NO_MLP32", "HIPT_MLP_WS", "HIPT_MLP_CO", "HIPT_NO_IMG", "HIPT_NO_SEQGEMM_PIPE",
-                                       "HIPT_NO_MLP_PIPE", "HIPT_NO_LN_CHAIN", "HIPT_PROJ_FOLD", "HIPT_NO_SEQGEMM", "HIPT_ATTN_V1", "HIPT_NO_PRUNE")):
-        pytest.skip("needs the default kernel, its (format 1) weight images and activation images as the other side of the comparison")
-    x = synth.hash_uniform_torch((32, 3, 256, 256), 37, device=DEV)  # (activation images need rows % 16 == 0: 16 | patches)
-    vit256.set_compute_dtype("bf16")
-    try:
-        base = vit256(x)
-        monkeypatch.setenv("HIPT_MLP_CO", "1")
-        co = vit256(x)
-        co_sub = vit256(x[8:24])
-    finally:
-        monkeypatch.delenv("HIPT_MLP_CO", raising=False)
-        vit256.set_compute_dtype("fp32")
-    rel = float((co - base).norm() / base.norm())
-    print(f"column-owned fused MLP vs the default kernel: rel-L2 {rel:.2e}")
-    assert 0 < rel < 5e-3  # (0 would mean the switch did nothing)
-    assert torch.equal(co[8:24], co_sub)
-
-
 def test_vit256_patch_embedding_from_fp32_pixels(vit256, monkeypatch):
     """csrc/embed32.hip reads the fp32 image itself (pixels rounded to bf16 in registers, weights through the LDS-DMA ring); the
-    round-1 path (HIPT_NO_EMBED32=1) makes a bf16 copy of the image and runs the generic GEMM over an im2col view.  Same bf16
-    products, another summation order: the [CLS] features agree far inside the bf16 bar, also for a batch that is not a whole
-    region and for a sub-batch (bitwise: a token's result does not depend on its neighbours)."""
+    generic path (HIPT_GENERIC=1) makes a bf16 copy of the image and runs the generic GEMM over an im2col view.  Same bf16
+    products, another summation order: the tokens agree with an fp64 Conv2d on the bf16-rounded operands to 1e-4 on both paths,
+    also for a batch that is not a whole region and for a sub-batch (bitwise: a token's result does not depend on its
+    neighbours)."""
     x = synth.hash_uniform_torch((7, 3, 256, 256), 31, device=DEV)
     vit256.set_compute_dtype("bf16")
     try:
         fused = vit256(x)
         fused_sub = vit256(x[2:5])
         tok = vit256.prepare_tokens(x)
-        monkeypatch.setenv("HIPT_NO_EMBED32", "1")
-        plain = vit256(x)
+        monkeypatch.setenv("HIPT_GENERIC", "1")
         tok_plain = vit256.prepare_tokens(x)
     finally:
-        monkeypatch.delenv("HIPT_NO_EMBED32", raising=False)
+        monkeypatch.delenv("HIPT_GENERIC", raising=False)
         vit256.set_compute_dtype("fp32")
-    rel = float((fused - plain).norm() / plain.norm())
     # the tokens themselves against Conv2d on the bf16-rounded operands in fp64 (what both kernels compute, up to summation order)
     w = vit256.patch_embed.proj.weight.detach().to(torch.bfloat16).double()
     ref = torch.nn.functional.conv2d(x.to(torch.bfloat16).double(), w, vit256.patch_embed.proj.bias.detach().double(), stride=16)
     ref = ref.flatten(2).transpose(1, 2) + vit256.interpolate_pos_encoding(tok, 256, 256)[:, 1:].double()
     e_new, e_old = float((tok[:, 1:] - ref).abs().max()), float((tok_plain[:, 1:] - ref).abs().max())
-    print(f"fused patch embedding vs bf16-copy + GEMM: [CLS] features rel-L2 {rel:.2e}; tokens vs fp64 Conv2d: max |err| {e_new:.2e} (round-1 path {e_old:.2e})")
-    assert rel < 5e-3 and e_new < 1e-4 and e_old < 1e-4
+    print(f"fused patch embedding: tokens vs fp64 Conv2d: max |err| {e_new:.2e} (generic path {e_old:.2e})")
+    assert e_new < 1e-4 and e_old < 1e-4
     assert torch.equal(tok[:, 0], tok_plain[:, 0])
     assert torch.equal(fused[2:5], fused_sub)
 
 
 def test_hipt4k_patch_embedding_addresses_regions(hipt, monkeypatch):
     """The pixel-reading patch embedding inside HIPT_4K: 256 x 256 patches addressed inside non-square regions (grid 2 x 3, batch of
-    two; one region per call takes the patch-range entry hipt_vit256_forward_range_px): the same bits as the round-1 path."""
+    two; one region per call takes the patch-range entry hipt_vit256_forward_range_px): the same features as the generic path
+    (bf16 copy of the image + im2col GEMM + generic block kernels) up to the bf16 bar -- a patch read from the wrong place would
+    be off by O(1) -- and identical bits for one region alone."""
     x = synth.hash_uniform_torch((2, 3, 512, 768), 37, device=DEV)
     hipt.set_compute_dtype("bf16")
     try:
         fused = hipt(x)
         fused_one = hipt(x[1:2])
-        monkeypatch.setenv("HIPT_NO_EMBED32", "1")
+        monkeypatch.setenv("HIPT_GENERIC", "1")
         plain = hipt(x)
     finally:
-        monkeypatch.delenv("HIPT_NO_EMBED32", raising=False)
+        monkeypatch.delenv("HIPT_GENERIC", raising=False)
         hipt.set_compute_dtype("fp32")
-    assert torch.equal(fused, plain)
+    rel = float((fused - plain).norm() / plain.norm())
+    assert rel < 1.3e-2, rel
     assert torch.equal(fused[1:2], fused_one)
-
-
-def test_vit256_proj_folded_into_the_mlp(vit256, monkeypatch):
-    """HIPT_PROJ_FOLD=1: the fused MLP kernel applies the attention branch's proj Linear itself (six more weight units in its image,
-    v = x + proj(att) + b kept in the fc2 accumulator's registers through LayerNorm-2; csrc/mlp32.hip, FOLD).  The attention
-    branch then stays fp32 instead of passing through a bf16 y1: held to the bf16 bar against the default path, bitwise against
-    itself under another batching."""
-    if os.environ.get("HIPT_NO_PREPACK"):
-        pytest.skip("HIPT_NO_PREPACK is set for the whole run")
-    x = synth.hash_uniform_torch((16, 3, 256, 256), 41, device=DEV)  # 16 x 257 rows: whole fragments, i.e. activation images
-    vit256.set_compute_dtype("bf16")
-    try:
-        plain = vit256(x)
-        inter = vit256.get_intermediate_layers(x, n=2)
-        monkeypatch.setenv("HIPT_PROJ_FOLD", "1")
-        fold = vit256(x)
-        fold_inter = vit256.get_intermediate_layers(x, n=2)
-        fold32 = vit256(torch.cat([x, x], dim=0))
-    finally:
-        monkeypatch.delenv("HIPT_PROJ_FOLD", raising=False)
-        vit256.set_compute_dtype("fp32")
-    rel = float((fold - plain).norm() / plain.norm())
-    rel_i = max(float((a - b).norm() / b.norm()) for a, b in zip(fold_inter, inter))
-    print(f"proj folded into the MLP vs separate proj: [CLS] features rel-L2 {rel:.2e}, last two blocks' tokens {rel_i:.2e}")
-    assert rel < 1.3e-2 and rel_i < 1.3e-2
-    assert torch.equal(fold32[:16], fold) and torch.equal(fold32[16:], fold)
 
 
 def test_vit256_activation_images_change_nothing(vit256, monkeypatch):
     """forward() keeps the residual stream, the attention-branch output and the pre-normalised QKV operands of blocks
     2..11 as fragment-blocked "activation images" (csrc/kernels.h) when the batch has whole 16-row fragments: a pure
-    re-ordering of bytes in private buffers -- identical bits to the row-major path (HIPT_NO_IMG=1), also for a batch
-    whose row count is not a multiple of 16 (which never uses them)."""
-    if os.environ.get("HIPT_MLP_WS") or os.environ.get("HIPT_MLP_CO") or os.environ.get("HIPT_PROJ_FOLD"):
-        pytest.skip("the experimental fused-MLP forms exist with images only: with and without images are different kernels")
+    re-ordering of bytes in private buffers -- identical bits to the row-major path (HIPT_NO_IMG=1) when both sides run the
+    same kernels (HIPT_NO_FUSED_ATTN=1: the fused QKV + attention kernel exists with images only), also for a batch whose
+    row count is not a multiple of 16 (which never uses them)."""
     vit256.set_compute_dtype("bf16")
     try:
+        monkeypatch.setenv("HIPT_NO_FUSED_ATTN", "1")
         for nseq in (16, 48, 5):  # 16 * 257 and 48 * 257 rows: whole fragments; 5 * 257: not
             x = synth.hash_uniform_torch((nseq, 3, 256, 256), 23 + nseq, device=DEV)
             img = vit256(x)
-            monkeypatch.setenv("HIPT_NO_QKV_HM", "1")  # images, but q | k | v row-major between the QKV GEMM and the attention
-            rowqkv = vit256(x)
-            monkeypatch.delenv("HIPT_NO_QKV_HM")
             monkeypatch.setenv("HIPT_NO_IMG", "1")
             plain = vit256(x)
             monkeypatch.delenv("HIPT_NO_IMG")
-            assert torch.equal(img, plain) and torch.equal(rowqkv, plain), nseq
+            assert torch.equal(img, plain), nseq
     finally:
         monkeypatch.delenv("HIPT_NO_IMG", raising=False)
-        monkeypatch.delenv("HIPT_NO_QKV_HM", raising=False)
+        monkeypatch.delenv("HIPT_NO_FUSED_ATTN", raising=False)
         vit256.set_compute_dtype("fp32")
+
+
+def test_vit256_fused_qkv_attention_vs_two_kernels(vit256, monkeypatch):
+    """LayerNorm-chained blocks run the QKV projection INSIDE the attention kernel (csrc/qkv_attention.hip: q | k | v never reach
+    HBM); HIPT_NO_FUSED_ATTN=1 runs the QKV GEMM and the attention as two kernels with the tensor between them.  Same bf16
+    operands, other MFMA shapes and summation orders: the [CLS] features agree far inside the bf16 bar; bitwise against itself
+    under another batching (a patch's result does not depend on its neighbours or on which workgroup takes it)."""
+    x = synth.hash_uniform_torch((48, 3, 256, 256), 43, device=DEV)
+    vit256.set_compute_dtype("bf16")
+    try:
+        before = N.calls
+        fused = vit256(x)
+        fused_sub = vit256(x[16:32])
+        assert N.calls > before
+        monkeypatch.setenv("HIPT_NO_FUSED_ATTN", "1")
+        two = vit256(x)
+    finally:
+        monkeypatch.delenv("HIPT_NO_FUSED_ATTN", raising=False)
+        vit256.set_compute_dtype("fp32")
+    rel = float((fused - two).norm() / two.norm())
+    print(f"fused QKV + attention vs QKV GEMM + attention kernel: [CLS] features rel-L2 {rel:.2e}")
+    assert 0 < rel < 5e-3  # (0 would mean the switch did nothing)
+    assert torch.equal(fused[16:32], fused_sub)
 
 
 def test_hipt4k_region_batch_equals_single_regions(hipt):
@@ -788,6 +714,76 @@ def test_clam_two_streams_do_not_share_partials_or_ticket():
             w = m._pack(torch.device(DEV))
             off = N.lib().hipt_clam_ticket_offset(__import__("ctypes").byref(w), 50000)
             assert int(ws[off:off + 256].sum()) == 0, key
+
+
+def test_clam_generic_then_streaming_model_share_one_workspace():
+    """One scratch per (device, stream) serves every CLAM module.  A model on the generic path ('small' [1024,512,256] fp32:
+    GEMM + gate + pool kernels writing per-block partials and a running maximum) followed by the bf16 [384,128,64] model on
+    the SAME stream: the streaming kernel's arrival counter lives in the first 256 bytes of the workspace, which no other path
+    writes, so the second model still combines (outputs written, ticket zero again) -- both orders, repeated."""
+    big = make_clam("small", (1024, 512, 256), 1024, 8, False, 0.0)
+    fast = make_clam("hipt_384", (384, 128, 64), 384, 8, False, 0.0).set_compute_dtype("bf16")
+    hb = synth.hash_uniform_torch((3000, 1024), 81, device=DEV)
+    hf = synth.hash_uniform_torch((5000, 384), 82, device=DEV)
+    with torch.no_grad():
+        ref_f = [t.clone() for t in fast(hf)[:4]]
+        ref_b = [t.clone() for t in big(hb)[:4]]
+        for _ in range(3):
+            out_b = big(hb)[:4]
+            out_f = fast(hf)[:4]
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(out_f, ref_f))
+            assert all(torch.equal(a, b) for a, b in zip(out_b, ref_b))
+    assert float(ref_f[1].sum()) == pytest.approx(1.0, abs=1e-6)
+    for key, ws in Fn._workspaces.items():
+        if isinstance(key[2], tuple) and key[2][0] == "clam":
+            assert int(ws[:256].sum()) == 0, key
+
+
+def test_clam_sb_bf16_hipt_big_stream_kernel():
+    """The aggregator BASELINE configs[4] runs (CLAM_SB 'hipt_big' [192,128,64] in bf16 = abmil_stream_kernel<3>) against the
+    reference golden at N = 500 and against the fp64 oracle on an 8 192 x 192 bag (the size of a slide's feature bag).
+    Bars = 2 x measured, as test_clam_sb_bf16_config1."""
+    g = golden("clam_hipt_big_n500")
+    m = make_clam("hipt_big", (192, 128, 64), 192, 8, False, 0.0).set_compute_dtype("bf16")
+    h = synth.hash_uniform_torch((500, 192), 5, device=DEV)
+    with torch.no_grad():
+        logits, y_prob, y_hat, a_raw, res = m(h, return_features=True)
+    print(f"CLAM_SB hipt_big bf16 500x192 vs reference: A_raw max abs {md(a_raw, g['A_raw']):.2e}, M rel-L2 {rel_l2(res['features'], g['M']):.2e}, "
+          f"logits max abs {md(logits, g['logits']):.2e}")
+    assert md(a_raw, g["A_raw"]) < 4e-2 and rel_l2(res["features"], g["M"]) < 2e-3 and md(logits, g["logits"]) < 1e-3
+    assert np.array_equal(y_hat.cpu().numpy(), g["Y_hat"])
+    n = 8192
+    p = synth.make_params_np(synth.clam_param_specs((192, 128, 64)), 192)
+    hb = synth.hash_uniform_torch((n, 192), 15, device=DEV)
+    with torch.no_grad():
+        logits, y_prob, y_hat, a_raw, res = m(hb, return_features=True)
+        a_sub = m(hb[:1000].contiguous(), attention_only=True)
+    r = O.clam_sb_forward(hb.cpu().numpy().astype(np.float64), {k: v.astype(np.float64) for k, v in p.items()})
+    print(f"CLAM_SB hipt_big bf16 8192x192 vs fp64 oracle: A_raw max abs {md(a_raw, r['A_raw']):.2e}, M rel-L2 {rel_l2(res['features'], r['M']):.2e}, "
+          f"logits max abs {md(logits, r['logits']):.2e}")
+    assert md(a_raw, r["A_raw"]) < 4e-2 and rel_l2(res["features"], r["M"]) < 2e-3 and md(logits, r["logits"]) < 1e-3
+    assert np.array_equal(y_hat.cpu().numpy(), r["Y_hat"]) and abs(float(y_prob.sum()) - 1.0) < 1e-6
+    assert torch.equal(a_sub[0], a_raw[0, :1000])  # rows are independent
+
+
+def test_clam_sb_training_shapes_outside_the_training_kernels_keep_autograd():
+    """A gated CLAM_SB the training kernels do not take (9 classes > 8) must still train on the GPU: dropout active and
+    gradients flowing through the PyTorch-op sequence, not a silent fall-through to the inference kernel."""
+    from hipt_abmil_atec23_amd import CLAM_SB
+    m = CLAM_SB(gate=True, size_arg="hipt_big", dropout=0.25, k_sample=4, n_classes=9).to(DEV)
+    m.relocate()
+    m.train()
+    h = synth.hash_uniform_torch((64, 192), 91, device=DEV)
+    logits, y_prob, y_hat, a_raw, _ = m(h)
+    assert logits.shape == (1, 9) and logits.grad_fn is not None and a_raw.grad_fn is not None
+    logits.sum().backward()
+    assert m.attention_net[0].weight.grad is not None and float(m.attention_net[0].weight.grad.abs().sum()) > 0
+    m.eval()
+    with torch.no_grad():
+        before = N.calls
+        out = m(h)
+        assert N.calls > before and out[0].grad_fn is None  # inference: the HIP forward
 
 
 # ---------------------------------------------------------------------------------------------

@@ -13,11 +13,11 @@ bool hipt_mlp_pipe_supported(int, int, int) { return false; }
 int hipt_mlp_pipe_launch(const MlpParams&, hipStream_t) { return -1; }
 #define LAUNCH(DBG, p) launch<6, DBG>(p, 0)
 #elif defined(PROBE_WS)  // the wave-specialised form (mlp_ws.hip); -DPROBE_WS
-#include "../hipt_abmil_atec23_amd/csrc/mlp_ws.hip"
+#include "experiments/mlp_ws.hip"
 #define LAUNCH(DBG, p) hipt_mlp_ws_launch_dbg<DBG>(p, 0)
 #define hipt_mlp_pack_launch hipt_mlp_ws_pack_launch
 #elif defined(PROBE_CO)  // fc2 column-owned (mlp_co.hip); -DPROBE_CO, link hipt_abmil_atec23_amd/csrc/build/mlp32.o for the pack kernel
-#include "../hipt_abmil_atec23_amd/csrc/mlp_co.hip"
+#include "experiments/mlp_co.hip"
 #define LAUNCH(DBG, p) hipt_mlp_co_launch(p, 0)
 #define hipt_mlp_pack_launch hipt_mlp32_pack_launch
 #elif defined(PROBE_32)  // the 32x32x16 form (mlp32.hip); -DPROBE_32
@@ -25,7 +25,7 @@ int hipt_mlp_pipe_launch(const MlpParams&, hipStream_t) { return -1; }
 #define LAUNCH(DBG, p) hipt_mlp32_launch_dbg<DBG>(p, 0)
 #define hipt_mlp_pack_launch hipt_mlp32_pack_launch
 #else  // the pipelined D = 384 kernel (mlp_pipe.hip)
-#include "../hipt_abmil_atec23_amd/csrc/mlp_pipe.hip"
+#include "experiments/mlp_pipe.hip"
 #define LAUNCH(DBG, p) hipt_mlp_pipe_launch_dbg<DBG>(p, 0)
 #endif
 
