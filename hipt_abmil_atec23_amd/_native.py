@@ -87,6 +87,7 @@ SIGNATURES = {
     "hipt_vit_blocks": (_i, [_VW, _p, _i, _i, _i, _p, _p, _sz, _p]),
     "hipt_vit_head": (_i, [_VW, _p, _i, _i, _p, _p]),
     "hipt_vit_cls_attention": (_i, [_VW, _p, _i, _p, _p, _sz, _p]),
+    "hipt_vit_attention_unit": (_i, [_VW, _i, _p, _i, _p, _i, _p, _sz, _p]),
     "hipt_vit256_forward": (_i, [_VW, _p, _IL, _i, _i, _p, _p, _sz, _p]),
     "hipt_vit4k_forward": (_i, [_VW, _p, _i, _p, _p, _sz, _p]),
     "hipt_image_compute_bytes": (_sz, [_VW, _IL, _i, _i]),

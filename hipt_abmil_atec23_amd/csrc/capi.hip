@@ -37,10 +37,10 @@ struct Carver {
 };
 
 // ---- optional per-kernel timing (bench.py's roofline leg): HIP events around every launch -----
-enum { PC_EMBED, PC_LN, PC_QKV, PC_ATTN, PC_PROJ, PC_FC1, PC_FC2, PC_MLP, PC_ABMIL, PC_COMBINE, PC_OTHER, PC_VIT4K, PC_LASTCLS, PC_N };
+enum { PC_EMBED, PC_LN, PC_QKV, PC_ATTN, PC_PROJ, PC_FC1, PC_FC2, PC_MLP, PC_ABMIL, PC_COMBINE, PC_OTHER, PC_VIT4K, PC_LASTCLS, PC_QKVATT, PC_CLSROWS, PC_N };
 const char* const kProfNames[PC_N] = {"embed_gemm", "layernorm", "qkv_gemm", "attention", "proj_gemm",
                                       "fc1_gemm",   "fc2_gemm",  "mlp_fused",   "abmil_fused", "abmil_combine", "other",
-                                      "vit4k_blocks", "last_block_cls"};
+                                      "vit4k_blocks", "last_block_cls", "qkv_attention_fused", "qkv_cls_rows"};
 constexpr int kProfMax = 8192;
 struct Prof {
     bool on = false, created = false;
@@ -170,7 +170,22 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             q.counter = (int*)s.hid + 16;
             q.counter_zeroed = qz ? 1 : 0;
             q.out_ntok = w->ntok;
-            if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue
+            // LayerNorm-chained block with activation images: the QKV projection runs inside the attention kernel (qkv_attention.hip),
+            // q | k | v never reach HBM.  The [CLS] rows (257 = 8 x 32 + 1) get their q | k | v from a side GEMM over nseq rows.
+            const bool fuse = have_xn && img && b.qkv_att_pk && hipt_qkv_attn_supported(dt, D, w->heads, w->ntok) && !last_probs &&
+                              !hipt_env_on("HIPT_NO_FUSED_ATTN");
+            const void* att_out = s.att;
+            if (fuse) {
+                char* qa = (char*)s.hid + 4096 + al256((size_t)nseq * D * 4);   // (the hidden slot is free on this path; its head holds tile queues)
+                char* qcls = qa + al256((size_t)nseq * D * 2);                   // [nseq, 3 D] bf16 + 1 KiB the kernel's row DMA may read past the end
+                PROF(PC_CLSROWS, hipt_gather_cls_bf16_launch(s.att, qa, nseq, w->ntok, D, st, 1));
+                q.M = nseq; q.A = qa; q.ln_w = q.ln_b = nullptr; q.out = qcls; q.img = 0;
+                q.counter = (int*)s.hid + 32;
+                PROF(PC_CLSROWS, hipt_seqgemm_launch(q, false, 0, st));
+                q.M = M; q.counter = (int*)s.hid + 16;
+                PROF(PC_QKVATT, hipt_qkv_attn_launch(s.att, b.qkv_att_pk, b.qkv_b, qcls, s.qkv, nseq, scale, st));
+                att_out = s.qkv;
+            } else if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue
                 q.A = s.att; q.ln_w = q.ln_b = nullptr;
                 q.img = (img ? 1 : 0) | (hm ? 4 : 0);
                 PROF(cQKV, hipt_seqgemm_launch(q, false, 0, st));
@@ -180,10 +195,10 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             }
             q.img = 0;
             // (with activation images the attention output is one too: proj then reads its operands 1 KiB at a time)
-            PROF(cATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st, img ? 1 : 0, hm ? 1 : 0));
+            if (!fuse) PROF(cATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st, img ? 1 : 0, hm ? 1 : 0));
             if (last_probs) break;
             // (proj folded into the fused MLP was measured break-even -- DESIGN.md -- and lives on as an experiment build only)
-            q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
+            q.A = att_out; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
             q.counter = (int*)s.hid + 32;
             q.img = img ? 3 : 0;  // A = the attention output image, out = y1 image
             PROF(cPROJ, hipt_seqgemm_launch(q, false, 0, st));
@@ -550,6 +565,44 @@ int hipt_vit_cls_attention(const hipt_vit_weights* w, float* x, int nseq, float*
     return hipt_attn_cls_probs_launch(s.qkv, probs_cls, nseq, w->ntok, w->heads, dh, attn_scale(w), w->dtype, st);
 }
 
+int hipt_vit_attention_unit(const hipt_vit_weights* w, int block, const void* xn_img, int nseq, void* out_img, int fused, void* workspace,
+                            size_t ws_bytes, void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(xn_img && out_img && xn_img != out_img && nseq > 0 && block >= 0 && block < w->depth, "vit_attention_unit: bad argument");
+    const int D = w->dim, M = nseq * w->ntok;
+    if (!hipt_qkv_attn_supported(w->dtype, D, w->heads, w->ntok) || M % 16 != 0) {
+        hipt_set_error("vit_attention_unit: bf16, D = 384, 6 heads, 257 tokens and nseq * 257 %% 16 == 0 only");
+        return HIPT_E_UNSUPPORTED;
+    }
+    Carver c(workspace, ws_bytes);
+    BlockScratch s = carve_blocks(c, w, nseq);
+    if (!c.ok()) {
+        hipt_set_error("vit_attention_unit: workspace %zu B too small / unaligned (need %zu)", ws_bytes, c.used);
+        return HIPT_E_WORKSPACE;
+    }
+    hipStream_t st = S(stream);
+    const hipt_block_weights& b = w->blocks[block];
+    SeqGemmParams q;
+    memset(&q, 0, sizeof(q));
+    q.K = D; q.lda = D; q.W = b.qkv_w; q.wpk = b.qkv_pk; q.N = 3 * D; q.bias = b.qkv_b; q.ldc = 3 * D; q.out_ntok = w->ntok;
+    q.counter = (int*)s.hid;
+    HIPT_CHECK_ARG(b.qkv_pk != nullptr, "vit_attention_unit: blocks[%d].qkv_pk is NULL", block);
+    if (fused) {
+        HIPT_CHECK_ARG(b.qkv_att_pk != nullptr, "vit_attention_unit: blocks[%d].qkv_att_pk is NULL", block);
+        char* qa = (char*)s.hid + 4096;
+        char* qcls = qa + al256((size_t)nseq * D * 2);
+        if ((rc = hipt_gather_cls_bf16_launch(xn_img, qa, nseq, w->ntok, D, st, 1))) return rc;
+        q.M = nseq; q.A = qa; q.out = qcls;
+        if ((rc = hipt_seqgemm_launch(q, false, 0, st))) return rc;
+        return hipt_qkv_attn_launch(xn_img, b.qkv_att_pk, b.qkv_b, qcls, out_img, nseq, attn_scale(w), st);
+    }
+    const bool hm = (int64_t)M * 3 * D * 2 < ((int64_t)1 << 32) - 65536;
+    q.M = M; q.A = xn_img; q.out = s.qkv; q.img = 1 | (hm ? 4 : 0);
+    if ((rc = hipt_seqgemm_launch(q, false, 0, st))) return rc;
+    return hipt_attention_launch(s.qkv, out_img, nullptr, nseq, w->ntok, w->heads, D / w->heads, attn_scale(w), w->dtype, st, 1, hm ? 1 : 0);
+}
+
 int hipt_vit_mlp_pack_format(const hipt_vit_weights* w) { return (w && hipt_mlp32_supported(w->dtype, w->dim, w->hidden)) ? 1 : 0; }
 
 size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {
@@ -559,6 +612,7 @@ size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {
         case HIPT_PACK_QKV: return hipt_seqgemm_pipe_supported(w->dtype, D, 3 * D, false, 0) ? (size_t)3 * D * D * 2 : 0;
         case HIPT_PACK_PROJ: return hipt_seqgemm_pipe_supported(w->dtype, D, D, false, 0) ? (size_t)D * D * 2 : 0;
         case HIPT_PACK_MLP: return hipt_vit_mlp_pack_format(w) == 1 ? (size_t)2 * D * w->hidden * 2 : 0;
+        case HIPT_PACK_QKV_ATT: return hipt_qkv_attn_supported(w->dtype, D, w->heads, w->ntok) ? hipt_qkv_attn_packed_bytes() : 0;
         default: return 0;
     }
 }
@@ -578,6 +632,7 @@ int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* 
     switch (what) {
         case HIPT_PACK_QKV: return hipt_seqgemm_pack_launch(b.qkv_w, 3 * D, D, out, st);
         case HIPT_PACK_PROJ: return hipt_seqgemm_pack_launch(b.proj_w, D, D, out, st);
+        case HIPT_PACK_QKV_ATT: return hipt_qkv_attn_pack_launch(b.qkv_w, out, st);
         default:
             // the format the caller recorded beside the pointer (hipt_vit_mlp_pack_format): pack and launch read the same field
             if (b.mlp_pk_fmt == 1 && hipt_mlp32_supported(w->dtype, D, w->hidden)) return hipt_mlp32_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);

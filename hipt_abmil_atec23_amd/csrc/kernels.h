@@ -135,6 +135,14 @@ int hipt_attention_launch(const void* qkv, void* out, float* probs, int B, int n
 bool hipt_attention64_supported(int dtype, int dh, int ntok, bool want_probs);
 int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int heads, float scale, hipStream_t st, int out_img = 0, int qkv_hm = 0);
 
+// QKV projection + attention of a LayerNorm-chained ViT-256 block in one kernel (qkv_attention.hip): xn_img = LayerNorm-1(x) and
+// out_img = the attention output, both bf16 activation images [nseq * 257, 384]; qkv_cls = bf16 [nseq, 1152] (+ 1 KiB readable
+// slack) = q | k | v of the [CLS] rows (a side GEMM); wpk = qkv_w in the kernel's operand order (hipt_qkv_attn_pack_launch)
+bool hipt_qkv_attn_supported(int dtype, int D, int heads, int ntok);
+size_t hipt_qkv_attn_packed_bytes();
+int hipt_qkv_attn_pack_launch(const void* qkv_w, void* packed, hipStream_t st);
+int hipt_qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b, const void* qkv_cls, void* out_img, int nseq, float scale, hipStream_t st);
+
 // attention of the [CLS] query only (bf16, head dim 64): out[B, heads*64] bf16 and/or probs[B, heads, ntok] fp32 (either may be null)
 int hipt_attn_cls_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale, hipStream_t st);
 // probabilities of the [CLS] query only, any compute dtype, head dim 32 / 64: probs[B, heads, ntok] fp32

@@ -192,6 +192,16 @@ int hipt_vit4k_prepare_tokens(const hipt_vit_weights* w, const float* tokens_in,
 int hipt_vit_blocks(const hipt_vit_weights* w, float* x, int nseq, int blk_begin, int blk_end,
                     float* probs, void* workspace, size_t ws_bytes, void* stream);
 
+/* The attention unit of ONE LayerNorm-chained ViT-256 block as the streaming path runs it (Attention.forward before proj,
+ * vision_transformer.py:121-128), exposed for the parity tests: xn_img = LayerNorm-1(x) and out_img = the attention output,
+ * both bf16 "activation images" of [nseq * 257, 384] (16-row fragments in MFMA operand order: element (row 16 F + i,
+ * column 32 c + 8 g + e) at F * 6144 + c * 512 + (16 g + i) * 8 + e).  fused != 0: the QKV projection runs inside the
+ * attention kernel (needs blocks[block].qkv_att_pk); fused == 0: QKV GEMM + attention kernel with q | k | v in the workspace
+ * (needs blocks[block].qkv_pk).  bf16 ViT-256 shape only (D = 384, 6 heads, 257 tokens), nseq * 257 a multiple of 16.
+ * workspace >= hipt_vit_workspace_bytes(w, nseq); out_img must not alias xn_img. */
+int hipt_vit_attention_unit(const hipt_vit_weights* w, int block, const void* xn_img, int nseq, void* out_img, int fused,
+                            void* workspace, size_t ws_bytes, void* stream);
+
 /* [CLS] row of the last block's attention map: probs_cls[nseq, heads, ntok] fp32 =
  * get_last_selfattention(x)[:, :, 0, :] (vision_transformer.py:255-262 as consumed by the heat-maps,
  * HIPT_4K/hipt_4k.py:143-158) without materialising [nseq, heads, ntok, ntok].  x = prepared tokens, modified.

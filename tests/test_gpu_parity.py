@@ -429,6 +429,57 @@ def test_vit256_activation_images_change_nothing(vit256, monkeypatch):
         vit256.set_compute_dtype("fp32")
 
 
+def _to_image(x):
+    """[M, 384] row-major -> activation image (include/hipt_abmil.h, hipt_vit_attention_unit): fragment F, column chunk c, lane 16 g + i, 8 elements"""
+    m = x.shape[0]
+    return x.view(m // 16, 16, 12, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(m, 384)
+
+
+def _from_image(img):
+    m = img.shape[0]
+    return img.view(m // 16, 12, 4, 16, 8).permute(0, 3, 1, 2, 4).contiguous().view(m, 384)
+
+
+@pytest.mark.parametrize("nseq", [16, 48])
+def test_attention_unit_fused_kernel_vs_torch_and_two_kernels(vit256, nseq):
+    """The attention unit of one block (qkv Linear + softmax(q k^T * scale) v, vision_transformer.py:121-128) through
+    hipt_vit_attention_unit: the fused QKV + attention kernel, the QKV GEMM + attention kernel pair, and an fp32 PyTorch
+    evaluation on the same bf16-rounded operands.  Bar: 1e-2 of the largest output (bf16 q / k / v / probabilities and a bf16
+    result: measured 4e-3) against fp32, the two HIP paths within that of each other; every row of every patch is compared,
+    the [CLS] row (which the fused kernel computes by another route) separately."""
+    import ctypes as C
+    vit256.set_compute_dtype("bf16")
+    try:
+        pk = vit256._tokens(synth.hash_uniform_torch((1, 3, 256, 256), 2, device=DEV))[0]
+        blk = 3
+        M = nseq * 257
+        x = (synth.hash_uniform_torch((M, 384), 57 + nseq, device=DEV) * 6.0).bfloat16()  # (scores of std ~2: a peaky softmax, sensitive to any mis-ordered operand)
+        xi = _to_image(x)
+        need = N.lib().hipt_vit_workspace_bytes(pk.ref, nseq)
+        ws = Fn.workspace(torch.device(DEV), need)
+        outs = []
+        for fused in (1, 0):
+            o = torch.full((M, 384), float("nan"), dtype=torch.bfloat16, device=DEV)
+            N.call("hipt_vit_attention_unit", pk.ref, blk, N.ptr(xi), nseq, N.ptr(o), fused, N.ptr(ws), ws.numel(), N.stream_ptr(torch.device(DEV)))
+            torch.cuda.synchronize()
+            outs.append(_from_image(o).float())
+        att = vit256.blocks[blk].attn
+        wq = att.qkv.weight.detach().bfloat16().float()
+        qkv = (x.float() @ wq.t() + att.qkv.bias.detach().float()).bfloat16().float().view(nseq, 257, 3, 6, 64).permute(2, 0, 3, 1, 4)
+        pr = torch.softmax((qkv[0] @ qkv[1].transpose(-1, -2)) * att.scale, dim=-1)
+        ref = (pr @ qkv[2]).transpose(1, 2).reshape(M, 384)
+    finally:
+        vit256.set_compute_dtype("fp32")
+    rmax = float(ref.abs().max())
+    for name, o in zip(("fused", "two kernels"), outs):
+        assert bool(torch.isfinite(o).all()), name
+        e_all = float((o - ref).abs().max())
+        e_cls = float((o.view(nseq, 257, 384)[:, 0] - ref.view(nseq, 257, 384)[:, 0]).abs().max())
+        print(f"attention unit, {name}, {nseq} patches: max |err| vs fp32 torch {e_all:.2e} ([CLS] rows {e_cls:.2e}); |ref| max {rmax:.2f}")
+        assert e_all < 1e-2 * rmax, name
+    assert float((outs[0] - outs[1]).abs().max()) < 1e-2 * rmax
+
+
 def test_vit256_fused_qkv_attention_vs_two_kernels(vit256, monkeypatch):
     """LayerNorm-chained blocks run the QKV projection INSIDE the attention kernel (csrc/qkv_attention.hip: q | k | v never reach
     HBM); HIPT_NO_FUSED_ATTN=1 runs the QKV GEMM and the attention as two kernels with the tensor between them.  Same bf16

@@ -1,6 +1,8 @@
 """Audit of a -save-temps .s: between an inline-asm ds_read and the inline-asm s_waitcnt lgkmcnt(N) that retires it,
 no compiler-generated instruction may read or write its destination registers (the data lands asynchronously;
-hipcc treats the destination as written at ;;#ASMEND).  usage: audit_asm_reads.py file.s [kernel-symbol-substring]"""
+hipcc treats the destination as written at ;;#ASMEND).  The same for inline-asm global_load_* destinations, which stay
+in flight until the inline-asm wait marked `; XOP_FENCE` (qkv_attention.hip).
+usage: audit_asm_reads.py file.s [kernel-symbol-substring]"""
 import re
 import sys
 
@@ -8,6 +10,7 @@ src = open(sys.argv[1]).read().split("\n")
 want = sys.argv[2] if len(sys.argv) > 2 else ""
 inside = want == ""
 queue = []  # [(line, set(regs))]
+gqueue = []  # asm global loads in flight
 inasm = False
 bad = 0
 for i, l in enumerate(src):
@@ -16,6 +19,7 @@ for i, l in enumerate(src):
     if want and lab:
         inside = want in lab.group(1)
         queue = []
+        gqueue = []
     if not inside:
         continue
     if t.startswith(";;#ASMSTART"):
@@ -29,6 +33,12 @@ for i, l in enumerate(src):
         if m:
             regs = set(range(int(m.group(2)), int(m.group(3)) + 1)) if m.group(2) else {int(m.group(4))}
             queue.append((i + 1, regs))
+        m = re.match(r"global_load\w* (v\[(\d+):(\d+)\]|v(\d+)),", t)
+        if m:
+            regs = set(range(int(m.group(2)), int(m.group(3)) + 1)) if m.group(2) else {int(m.group(4))}
+            gqueue.append((i + 1, regs))
+        if "XOP_FENCE" in t:
+            gqueue = []
         for mm in re.finditer(r"lgkmcnt\((\d+)\)", t):
             n = int(mm.group(1))
             queue = queue[len(queue) - n:] if n > 0 else []
@@ -40,12 +50,13 @@ for i, l in enumerate(src):
         continue
     if t.startswith("s_branch") or t.startswith("s_endpgm"):  # (control flow is not followed: the fall-through code
         queue = []                                             #  below an unconditional branch is another path)
+        gqueue = []
         continue
     regs = set()
     for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", t):
         regs.update(range(int(a), int(b) + 1))
     regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", t))
-    for ln, rs in queue:
+    for ln, rs in queue + gqueue:
         hit = regs & rs
         if hit:
             bad += 1
