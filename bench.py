@@ -109,13 +109,15 @@ def build_models(dev, dtype):
 def kernel_flops(cat, rows, D=384, H=1536, heads=6, ntok=257):
     """Algorithmic FLOPs of one launch of a kernel category over `rows` token rows."""
     dh = D // heads
+    att = 4 * (rows // ntok) * heads * ntok * ntok * dh
     return {"qkv_gemm": 2 * rows * 3 * D * D, "proj_gemm": 2 * rows * D * D,
             "fc1_gemm": 2 * rows * D * H, "fc2_gemm": 2 * rows * D * H, "mlp_fused": 4 * rows * D * H,
-            "attention": 4 * (rows // ntok) * heads * ntok * ntok * dh}.get(cat)
+            "attention": att, "qkv_attention_fused": 2 * rows * 3 * D * D + att}.get(cat)
 
 
 # rocprofv3 kernel names of the categories, most specific first (keys of profiles/<tag>_traffic.json)
-TRAFFIC_KEYS = {"mlp_fused": ["void mlp32_kernel<true, true, 0, true>", "void mlp32_kernel<true, true, 0, false>", "void mlp32_kernel<true, true, 0>", "void mlp_pipe_kernel<0, true, true, true>", "void mlp_pipe_kernel<0, true, false, false>", "void mlp_pipe_kernel<0>"],
+TRAFFIC_KEYS = {"mlp_fused": ["void mlp32_kernel<true, true, 0, false>", "void mlp32_kernel<true, true, 0>"],
+                "qkv_attention_fused": ["qkv_attn_kernel"],
                 "qkv_gemm": ["void seqgemm_pipe_kernel<false, 0, true, true, false, true>", "void seqgemm_pipe_kernel<true, 0, true, false, false, false>",
                              "void seqgemm_pipe_kernel<true, 0>"],
                 "proj_gemm": ["void seqgemm_pipe_kernel<false, 0, true, true, true, false>", "void seqgemm_pipe_kernel<false, 0, true, false, false, false>",
@@ -367,10 +369,7 @@ def main():
     # under 'last_block_cls'): rows per launch = one chunk of patches x 257, or all of the step's patches when fewer
     rows_launch = min(chunk, 256 * R) * 257
     mf = {c: v for c, v in kernels.items() if kernel_flops(c, rows_launch)}
-    # the fused MLP applies the attention branch's proj Linear itself when it can (csrc/mlp32.hip, FOLD): no proj launches then,
-    # and the kernel's algorithmic FLOPs are fc1 + fc2 + proj
-    proj_folded = "mlp_fused" in mf and "proj_gemm" not in mf and "qkv_gemm" in mf
-    flops_of = lambda c: kernel_flops(c, rows_launch) + (kernel_flops("proj_gemm", rows_launch) if (c == "mlp_fused" and proj_folded) else 0)
+    flops_of = lambda c: kernel_flops(c, rows_launch)
     if mf and (256 * R) % min(chunk, 256 * R) == 0:
         frac = {}
         for c, v in mf.items():
@@ -381,13 +380,18 @@ def main():
                            "frac": frac[dom]["frac"], "traffic": pmc_traffic(dom), "flops_per_launch": flops_of(dom),
                            "rows_per_launch": rows_launch, "launches_per_step": mf[dom]["launches_per_step"], "avg_launch_us": mf[dom]["avg_us"]}
         out["roofline_all"] = {c: round(f["frac"], 4) for c, f in frac.items()}
-        if proj_folded and all(c in frac for c in ("qkv_gemm", "attention")):
-            us = sum(frac[c]["avg_launch_us"] for c in ("qkv_gemm", "attention"))
-            fl = sum(kernel_flops(c, rows_launch) for c in ("qkv_gemm", "attention"))
-            out["roofline_attention_unit"] = {"kernels": ["qkv_gemm", "attention"], "bound": "mfma", "us_per_launch_set": us,
+        if all(c in frac for c in ("qkv_attention_fused", "proj_gemm")):
+            # north_star's "ViT-256 attention" unit (LN1 + QKV + QK^T + softmax + PV + proj = 404 620 800 FLOP per patch and block) as the
+            # LayerNorm-chained blocks run it: the fused QKV + attention kernel, the side GEMM over the [CLS] rows (two small launches,
+            # booked as 'qkv_cls_rows': their time per block is added), the proj GEMM
+            side = kernels.get("qkv_cls_rows", {}).get("ms_per_step", 0.0) / kernels["qkv_attention_fused"]["launches_per_step"] * 1e3
+            us = frac["qkv_attention_fused"]["avg_launch_us"] + side + frac["proj_gemm"]["avg_launch_us"]
+            fl = kernel_flops("qkv_attention_fused", rows_launch) + kernel_flops("proj_gemm", rows_launch)
+            out["roofline_attention_unit"] = {"kernels": ["qkv_attention_fused", "qkv_cls_rows", "proj_gemm"], "bound": "mfma", "us_per_launch_set": us,
+                                              "cls_rows_us_per_block": side,
                                               "achieved": fl / (us * 1e-6) / 1e12, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                               "frac": fl / (us * 1e-6) / 1e12 / PEAK_TFLOPS[args.dtype], "target": 0.60,
-                                              "note": "proj is applied inside mlp_fused (its FLOPs are counted there): LN1 + QKV + QK^T + softmax + PV only"}
+                                              "traffic": pmc_traffic("qkv_attention_fused")}
         elif all(c in frac for c in ("qkv_gemm", "attention", "proj_gemm")):
             # north_star's "ViT-256 attention" unit: LN1 + QKV + QK^T + softmax + PV + proj = 404 620 800 FLOP per patch and block
             us = sum(frac[c]["avg_launch_us"] for c in ("qkv_gemm", "attention", "proj_gemm"))

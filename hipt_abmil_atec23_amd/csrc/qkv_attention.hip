@@ -25,6 +25,9 @@
 //                the partial (max, sum, o[64]) goes through LDS and one wave merges the eight.
 // LDS: ring 72 KiB | K image 36 KiB | V image 36 KiB | bias 4.5 KiB | [CLS] partials | [CLS] q k v rows = 158.75 KiB.
 // HBM per patch: xn read (197 KB; the five re-reads per patch are L2 / MALL hits) + output written (197 KB).
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 #include "pipe_common.h"
@@ -98,13 +101,53 @@ struct QkvAttnParams {
     int nseq;
     float sl2e;            // scale * log2(e)
     unsigned out_bytes;
+    int ngroups;           // groups of six workgroups (one head each) that walk the patches g, g + ngroups, ..
+    int xcd_groups;        // > 0: groups per XCD -- workgroup id -> XCD id % 8, slot id / 8: group xcd * xcd_groups + slot / 6, head slot % 6
+                           // (workgroups id and id + 8 share an XCD: the six heads of a patch then read its rows through ONE L2); 0: group id / 6
+    unsigned long long* stamps;  // diagnostic builds: per-workgroup cycle sums of the phases (8 per workgroup), or null
 };
 
+// phase stamps (make DEBUG_STAMPS=1 only): wave 0 of every workgroup adds the cycles between consecutive marks to a sum per phase
+#ifdef HIPT_QKVATT_STAMPS_BUILD  // (-DHIPT_QKVATT_STAMPS_BUILD on top of DEBUG_STAMPS: the stamps perturb the kernel, the ablation variants must not carry them)
+#define QST_ON(ptr) ((ptr) != nullptr)
+#else
+#define QST_ON(ptr) false
+#endif
+#define QSTAMP_DECL unsigned long long st_prev = 0, st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define QSTAMP_BEGIN()                                                          \
+    do {                                                                        \
+        if (QST_ON(p.stamps) && w == 0) st_prev = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define QSTAMP(k)                                                               \
+    do {                                                                        \
+        if (QST_ON(p.stamps) && w == 0) {                               \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
+            st_sum[k] += t_ - st_prev;                                          \
+            st_prev = t_;                                                       \
+        }                                                                       \
+    } while (0)
+
+constexpr int NW = 8;  // waves per workgroup (two per SIMD, 256 registers each); a wave owns 32 tokens = one B operand
+
+// DBG (diagnostic builds only, HIPT_QKVATT_DBG): 1 = no weight DMA / ring syncs, 2 = no weight fragment reads, 4 = no attention
+// phase, 8 = no GEMM MFMAs, 16 = no [CLS]-query section, 32 = no exponentials, 64 = no operand loads -- timing ablations,
+// the results are garbage
+template <int DBG>
 __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hh = lane >> 5;
+    // this workgroup: ONE head of the patches of its group (kernel header: the six workgroups of a group share an XCD's L2)
+    int hs, g0;
+    if (p.xcd_groups > 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        hs = slot % HEADS;
+        g0 = xcd * p.xcd_groups + slot / HEADS;
+    } else {
+        hs = blockIdx.x % HEADS;
+        g0 = blockIdx.x / HEADS;
+    }
+    const int gstep = p.ngroups;
 
     // ---- one-time LDS contents (no DMA in flight yet: plain stores) ----
     {
@@ -113,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
             const int U = i >> 5, hb = (i >> 4) & 1, ii = i & 15;
             bias_s[i] = p.bias[unit_row(U, (ii & 3) + 8 * (ii >> 2) + 4 * hb)];
         }
-        uint32_t* kz = (uint32_t*)(smem + OFF_K + 8 * 4096);  // key tile 8: row 0 = the [CLS] key (written per head), rows 1.. stay zero
+        uint32_t* kz = (uint32_t*)(smem + OFF_K + 8 * 4096);  // key tile 8: row 0 = the [CLS] key (written per patch), rows 1.. stay zero
         for (int i = tid; i < 1024; i += 512) kz[i] = 0u;
         for (int t = 0; t < 2; ++t) {                          // V rows 256 .. 287: row 256 = the [CLS] value, the rest stay zero
             uint32_t* vz = (uint32_t*)(smem + OFF_V + t * VSUB + 256 * 64);
@@ -125,14 +168,15 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     const uint32_t lbase = lds_addr(smem);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.out_bytes, 0x00020000);
 
-    // ---- weight stream: unit n of this workgroup = image unit n % 36 into ring slot n % 3; wave w moves pieces w, w + 8, w + 16 ----
+    // ---- weight stream: the six units of head hs, round and round; unit n into ring slot n % 3; wave w moves pieces w, w + 8, w + 16 ----
     int iU = 0, islot = 0;
     auto issue_unit = [&]() __attribute__((always_inline)) {
-        const char* src = p.wpk + (size_t)iU * UNIT + lane * 16;
+        const char* src = p.wpk + (size_t)(hs * 6 + iU) * UNIT + lane * 16;
         char* dst = smem + islot * UNIT;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) glds16(src + (w + 8 * j) * 1024, dst + (w + 8 * j) * 1024);
-        iU = iU + 1 == NUNIT ? 0 : iU + 1;
+        for (int j = 0; j < 3; ++j)
+            if constexpr ((DBG & 1) == 0) glds16(src + (w + 8 * j) * 1024, dst + (w + 8 * j) * 1024);
+        iU = iU + 1 == 6 ? 0 : iU + 1;
         islot = islot + 1 == 3 ? 0 : islot + 1;
     };
     auto cls_dma = [&](int b, int par) __attribute__((always_inline)) {  // (wave 0) the [CLS] row of patch b -> LDS
@@ -144,8 +188,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     // this wave's tokens as the B operand: 24 k-steps, lane (r, hh) holds row R, 16-byte chunk 2 s + hh of the image
     u32x4 xop[24];
     auto load_xop = [&](int b) __attribute__((always_inline)) {
-        const int64_t R = (int64_t)b * NTOK + 1 + 32 * w + r;
-        const char* x0 = p.xn + (R >> 4) * 12288 + (R & 15) * 16 + hh * 256;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int64_t R = (int64_t)b * NTOK + 1 + 32 * w + (ln & 31);
+        const char* x0 = p.xn + (R >> 4) * 12288 + (R & 15) * 16 + (ln >> 5) * 256;
         const char* x1 = x0 + 4096;
         const char* x2 = x0 + 8192;
         sfor<0, 24>([&](auto S_) __attribute__((always_inline)) {
@@ -162,15 +208,15 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     // (the asm loads land asynchronously: nothing may touch xop between them and this statement, which is the counted wait
     //  AND the point from which the compiler may use the registers)
 #define XOP_FENCE(N)                                                                                                              \
-    asm volatile("s_waitcnt vmcnt(" #N ") ; XOP_FENCE"                                                                                       \
+    asm volatile("s_waitcnt vmcnt(" #N ") ; XOP_FENCE"                                                                            \
                  : "+v"(xop[0]), "+v"(xop[1]), "+v"(xop[2]), "+v"(xop[3]), "+v"(xop[4]), "+v"(xop[5]), "+v"(xop[6]), "+v"(xop[7]), \
                    "+v"(xop[8]), "+v"(xop[9]), "+v"(xop[10]), "+v"(xop[11]), "+v"(xop[12]), "+v"(xop[13]), "+v"(xop[14]),           \
                    "+v"(xop[15]), "+v"(xop[16]), "+v"(xop[17]), "+v"(xop[18]), "+v"(xop[19]), "+v"(xop[20]), "+v"(xop[21]),         \
                    "+v"(xop[22]), "+v"(xop[23])::"memory")
 
-    // ---- merge of the eight [CLS]-query partials of one (patch, head): one wave, lane = output dimension ----
-    auto merge_cls = [&](int b, int h, int pq) __attribute__((always_inline)) {
-        int ln = lane;  // (opaque copy: see the head loop)
+    // ---- merge of the eight [CLS]-query partials of one patch: one wave, lane = output dimension ----
+    auto merge_cls = [&](int b, int pq) __attribute__((always_inline)) {
+        int ln = lane;  // (opaque copy: see the patch loop)
         asm volatile("" : "+v"(ln));
         const uint32_t base = lbase + OFF_CLSP + pq * 8 * CLSP_W, obase = base + 16 + ln * 4;
         float mk[8], lk[8], ok[8];
@@ -192,287 +238,402 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
             L += f * lk[k];
             o += f * ok[k];
         }
-        const int64_t R = (int64_t)b * NTOK;  // the [CLS] row; column 64 h + lane = chunk 8 h + (lane >> 3), element lane & 7
-        const int kc = 8 * h + (ln >> 3);
+        const int64_t R = (int64_t)b * NTOK;  // the [CLS] row; column 64 hs + lane = chunk 8 hs + (lane >> 3), element lane & 7
+        const int kc = 8 * hs + (ln >> 3);
         bf16_t* dst = (bf16_t*)(p.out + (R >> 4) * 12288 + (kc >> 2) * 1024 + (kc & 3) * 256 + (R & 15) * 16) + (ln & 7);
         *dst = (bf16_t)(o / L);
     };
 
-    int pq = 0;                       // parity of the (patch, head) counter: which [CLS] partial buffer
-    int prev_b = -1, prev_h = 0;      // (patch, head) whose partials wait for their merge
-    int par = 0;                      // parity of the patch counter: which [CLS] row buffer
-    const int b0 = blockIdx.x, bstep = gridDim.x;
-    if (w == 0) cls_dma(b0, 0);
+    QSTAMP_DECL;
+    int pq = 0;          // parity of the patch counter: which [CLS] partial buffer / [CLS] row buffer
+    int prev_b = -1;     // patch whose partials wait for their merge
+    if (g0 >= p.nseq) return;  // (uniform: a workgroup without patches)
+    if (w == 0) cls_dma(g0, 0);
     issue_unit();
     issue_unit();
-    load_xop(b0);
+    load_xop(g0);
+    // ring protocol: unit n is consumed from slot n % 3.  In the MIDDLE of unit n every wave waits for its pieces of unit n + 1,
+    // all meet at a barrier (so unit n + 1 has landed for everyone, and everyone has left unit n - 1), and unit n + 2 is
+    // requested into the slot of unit n - 1.  The fragment reads then run across unit boundaries without a restart.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // unit 0 has landed
+    int cslot = 0;                 // slot of the unit being consumed
 
-    for (int b = b0; b < p.nseq; b += bstep, par ^= 1) {
-        for (int h = 0; h < HEADS; ++h, pq ^= 1) {
-            // Per-lane addresses are re-derived per head from an opaque copy of the lane id: left loop-invariant, hipcc hoists a
-            // dozen of them out of the head loop, spills them across the attention phase and reloads them inside the ring phases --
-            // and every scratch reload waits vmcnt(0), i.e. for the weight stream.
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            const int r = ln & 31, hh = ln >> 5;
-            const uint32_t fa = lbase + ln * 16;  // this lane's 16 bytes of a 1 KiB fragment
-            // transposing V read: lane 4 q + pp of a 16-lane group supplies row (key) q, columns 4 pp .. of the group's 4 x 16 block
-            const uint32_t va = lbase + OFF_V + (4 * hh + ((ln & 15) >> 2)) * 64 + (16 * ((ln >> 4) & 1) + 4 * (ln & 3)) * 2;
-            const int64_t Rl = (int64_t)b * NTOK + 1 + 32 * w + r;                          // this lane's token row (as a query)
-            const int orow = (int)((Rl >> 4) * 12288 + (Rl & 15) * 16) + 8 * hh;            // its bytes in the output image
-            u32x4 qop[2][2];
-            // ================= GEMM phase: six ring units =================
-            sfor<0, 6>([&](auto U_) __attribute__((always_inline)) {
-                constexpr int u = decltype(U_)::value;
-                // my pieces of this unit have landed (all but the three youngest vector-memory operations are complete: those
-                // are at most the next unit's pieces) ... everyone's; and everyone is done with the unit before it
-                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                const uint32_t sa = fa + (islot == 2 ? 0 : islot + 1) * UNIT;  // slot of the unit to consume = (issue slot + 1) % 3
-                issue_unit();
-                if constexpr (u == 0) {
-                    // behind the first barrier of a head every wave has left the previous head's attention: its [CLS] partials are
-                    // complete (merge them), and the other [CLS] row buffer is free (fetch the next patch's row)
-                    if (prev_b >= 0 && w == (prev_h & 7)) merge_cls(prev_b, prev_h, pq ^ 1);
-                    if (h == 0 && w == 0 && b + bstep < p.nseq) cls_dma(b + bstep, par ^ 1);
-                    XOP_FENCE(3);
+    constexpr int PF = 7;          // weight fragments requested ahead of the MFMA that uses them (8 register sets)
+    const f32x16 Z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = g0; b < p.nseq; b += gstep, pq ^= 1) {
+        // Per-lane addresses are re-derived per patch from an opaque copy of the lane id: left loop-invariant, hipcc hoists a
+        // dozen of them out of the loop, spills them across the attention phase and reloads them inside the ring phases --
+        // and every scratch reload waits vmcnt(0), i.e. for the weight stream.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int r = ln & 31, hh = ln >> 5;
+        const uint32_t fa = lbase + ln * 16;  // this lane's 16 bytes of a 1 KiB fragment
+        // transposing V read: lane 4 q + pp of a 16-lane group supplies row (key) q, columns 4 pp .. of the group's 4 x 16 block
+        // (rows hold their 16-byte chunks rotated by (key >> 1) & 3 -- see the V^T tile store; every key base below is a multiple of 8)
+        const int vq = (ln & 15) >> 2, vch = (2 * ((ln >> 4) & 1) + ((ln & 3) >> 1) + 2 * hh + (vq >> 1)) & 3;
+        const uint32_t va = lbase + OFF_V + (4 * hh + vq) * 64 + vch * 16 + (ln & 1) * 8;
+        const int64_t Rl = (int64_t)b * NTOK + 1 + 32 * w + r;                          // this lane's token row (as a query)
+        const int orow = (int)((Rl >> 4) * 12288 + (Rl & 15) * 16) + 8 * hh + hs * 2048; // its bytes in the output image (this head's columns)
+        const uint32_t crow = lbase + OFF_CLSROW + pq * CLSROW;
+        u32x4 qop[2][2];
+        QSTAMP_BEGIN();
+        // ================= GEMM phase: six ring units = 144 MFMA steps, fragment reads PF steps ahead =================
+        {
+            u32x4 wf[8];
+            f32x4 bq[4];
+            f32x16 acc;
+            uint32_t sa = fa + cslot * UNIT, sn = sa;  // fragment base of the unit being consumed / of the next one
+            XOP_FENCE(8);  // (the eight youngest vector-memory operations are the previous patch's output stores: let them fly)
+            sfor<0, PF>([&](auto G_) __attribute__((always_inline)) {
+                constexpr int g = decltype(G_)::value;
+                u32x4& d = wf[g & 7];
+                const uint32_t a = sa;
+                if constexpr ((DBG & 2) == 0) DSR128(d, a, g * 1024);
+                else d = xop[g];
+            });
+            sfor<0, 144>([&](auto G_) __attribute__((always_inline)) {
+                constexpr int g = decltype(G_)::value, u = g / 24, s = g % 24;
+                // LDS operations younger than fragment g at its wait: the PF fragments behind it, and -- during the first PF
+                // steps of a unit -- the bias reads of this unit and the K / V writes of the unit before (in-order queue)
+                constexpr int wprev = u == 0 ? 0 : (u <= 2 ? 2 : (u <= 4 ? 4 : 0));
+                constexpr int ahead = g + PF < 144 ? PF : 143 - g;
+                if constexpr (s == 0) {
+                    const uint32_t ba = lbase + OFF_BIAS + ((hs * 6 + u) * 2 + hh) * 64;
+                    f32x4 &b0v = bq[0], &b1v = bq[1], &b2v = bq[2], &b3v = bq[3];
+                    DSR128(b0v, ba, 0);
+                    DSR128(b1v, ba, 16);
+                    DSR128(b2v, ba, 32);
+                    DSR128(b3v, ba, 48);
                 }
-                f32x16 acc;
-                {
-                    const uint32_t ba = lbase + OFF_BIAS + ((h * 6 + u) * 2 + hh) * 64;
-                    f32x4 b0v, b1v, b2v, b3v;
-                    DSR128X4_WAIT(b0v, b1v, b2v, b3v, ba, 0, 16, 32, 48);
+                if constexpr (g + PF < 144 && (DBG & 2) == 0) {
+                    u32x4& d = wf[(g + PF) & 7];
+                    if constexpr (s + PF < 24) {
+                        const uint32_t a = sa;
+                        DSR128(d, a, (s + PF) * 1024);
+                    } else {
+                        const uint32_t a = sn;
+                        DSR128(d, a, (s + PF - 24) * 1024);
+                    }
+                }
+                if constexpr ((DBG & 2) != 0) {
+                    LGKM(0);
+                } else if constexpr (s < PF) {
+                    LGKM((ahead + 4 + wprev < 15 ? ahead + 4 + wprev : 15));  // (a 4-bit counter: a smaller count only waits for more)
+                } else {
+                    LGKM(ahead);
+                }
+                if constexpr ((DBG & 8) != 0) {
+                    if constexpr (s == 0) acc = Z16;
+                    acc[s & 15] += __builtin_bit_cast(float, wf[g & 7][0]);
+                } else if constexpr (s == 0) {
+                    acc = mfma32(wf[g & 7], xop[s], Z16);
+                } else {
+                    acc = mfma32(wf[g & 7], xop[s], acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (s == 11) {
+                    // ---- ring: the next unit has landed for everyone; request the one after it ----
+                    if constexpr ((DBG & 1) == 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    issue_unit();
+                    sn = fa + (cslot == 2 ? 0 : cslot + 1) * UNIT;
+                    if constexpr (u == 0) {
+                        // behind the first barrier of a patch every wave has left the previous patch's attention: its [CLS] partials are
+                        // complete (merge them), the K / V images are free, and the other [CLS] row buffer is free (fetch the next
+                        // patch's row)
+                        if (prev_b >= 0 && w == ((prev_b / gstep) & 7)) merge_cls(prev_b, pq ^ 1);
+                        if (w == 0 && b + gstep < p.nseq) cls_dma(b + gstep, pq ^ 1);
+                    }
+                }
+                if constexpr (s == 23) {
+                    // ---- unit done: + bias, then K^T / V^T tiles to their LDS images, Q^T to its operand registers ----
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        acc[i] = b0v[i];
-                        acc[4 + i] = b1v[i];
-                        acc[8 + i] = b2v[i];
-                        acc[12 + i] = b3v[i];
+                        acc[i] += bq[0][i];
+                        acc[4 + i] += bq[1][i];
+                        acc[8 + i] += bq[2][i];
+                        acc[12 + i] += bq[3][i];
                     }
-                }
-                u32x4 wf[4];
-                {
-                    u32x4 &w0 = wf[0], &w1 = wf[1], &w2 = wf[2];
-                    DSR128(w0, sa, 0);
-                    DSR128(w1, sa, 1024);
-                    DSR128(w2, sa, 2048);
-                }
-                sfor<0, 24>([&](auto S_) __attribute__((always_inline)) {
-                    constexpr int s = decltype(S_)::value;
-                    if constexpr (s + 3 < 24) {
-                        u32x4& wn = wf[(s + 3) & 3];
-                        DSR128(wn, sa, (s + 3) * 1024);
-                        LGKM(3);
-                    } else {
-                        LGKM(23 - s);
+                    if constexpr (u < 2) {          // K^T tile u: the two A-operand fragments (k-steps) of the score product
+                        const u32x4 k0 = pack8<0>(acc), k1 = pack8<1>(acc);
+                        const uint32_t ka = fa + OFF_K + w * 4096;
+                        DSW128(ka, k0, (u * 2 + 0) * 1024);
+                        DSW128(ka, k1, (u * 2 + 1) * 1024);
+                    } else if constexpr (u < 4) {   // V^T tile: row-major [key][32 dims], dims 8 q + 4 hh ..+3 from registers 4 q ..+3
+                        // (the four 16-byte chunks of a 64-byte row are rotated by (key >> 1) & 3: sixteen consecutive keys then write to
+                        //  eight bank groups instead of two -- 2-way instead of 8-way conflicts; the transposed reads stay conflict-free)
+                        const int rot = (r >> 1) & 3;
+                        const uint32_t vw = lbase + OFF_V + (u - 2) * VSUB + (32 * w + r) * 64 + 8 * hh;
+                        const uint32_t vw0 = vw + ((0 + rot) & 3) * 16, vw1 = vw + ((1 + rot) & 3) * 16, vw2 = vw + ((2 + rot) & 3) * 16, vw3 = vw + ((3 + rot) & 3) * 16;
+                        u32x2 o0, o1, o2, o3;
+                        o0[0] = pack_bf16x2(acc[0], acc[1]);   o0[1] = pack_bf16x2(acc[2], acc[3]);
+                        o1[0] = pack_bf16x2(acc[4], acc[5]);   o1[1] = pack_bf16x2(acc[6], acc[7]);
+                        o2[0] = pack_bf16x2(acc[8], acc[9]);   o2[1] = pack_bf16x2(acc[10], acc[11]);
+                        o3[0] = pack_bf16x2(acc[12], acc[13]); o3[1] = pack_bf16x2(acc[14], acc[15]);
+                        DSW64(vw0, o0, 0);
+                        DSW64(vw1, o1, 0);
+                        DSW64(vw2, o2, 0);
+                        DSW64(vw3, o3, 0);
+                    } else {                        // Q^T tile: stays in registers as the score product's B operand
+                        qop[u - 4][0] = pack8<0>(acc);
+                        qop[u - 4][1] = pack8<1>(acc);
                     }
-                    acc = mfma32(wf[s & 3], xop[s], acc);
+                    sa = sn;
+                    cslot = cslot == 2 ? 0 : cslot + 1;
                     __builtin_amdgcn_sched_barrier(0);
-                });
-                if constexpr (u < 2) {          // K^T tile u: the two A-operand fragments (k-steps) of the score product
-                    const u32x4 k0 = pack8<0>(acc), k1 = pack8<1>(acc);
-                    const uint32_t ka = fa + OFF_K + w * 4096;
-                    DSW128(ka, k0, (u * 2 + 0) * 1024);
-                    DSW128(ka, k1, (u * 2 + 1) * 1024);
-                } else if constexpr (u < 4) {   // V^T tile: row-major [key][32 dims], dims 8 q + 4 hh ..+3 from registers 4 q ..+3
-                    const uint32_t vw = lbase + OFF_V + (u - 2) * VSUB + (32 * w + r) * 64 + 8 * hh;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        u32x2 o;
-                        o[0] = pack_bf16x2(acc[4 * q], acc[4 * q + 1]);
-                        o[1] = pack_bf16x2(acc[4 * q + 2], acc[4 * q + 3]);
-                        if (q == 0) DSW64(vw, o, 0);
-                        else if (q == 1) DSW64(vw, o, 16);
-                        else if (q == 2) DSW64(vw, o, 32);
-                        else DSW64(vw, o, 48);
-                    }
-                } else {                        // Q^T tile: stays in registers as the score product's B operand
-                    qop[u - 4][0] = pack8<0>(acc);
-                    qop[u - 4][1] = pack8<1>(acc);
                 }
             });
-            // ---- the [CLS] token's key and value of this head: K image tile 8 row 0, V image row 256 ----
-            const uint32_t crow = lbase + OFF_CLSROW + par * CLSROW;
-            if (w == 0 && r == 0) {  // lanes 0 and 32: the two lane halves of row 0
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {  // fragment (d tile f >> 1, k-step f & 1): dims 16 f + 4 hh ..+3 and 16 f + 8 + 4 hh ..+3
-                    const uint32_t ksrc = crow + (D + 64 * h + 16 * f + 4 * hh) * 2;
-                    const u32x2 lo = lds_ld64w(ksrc), hi = lds_ld64w(ksrc + 16);
-                    const u32x4 kv = {lo[0], lo[1], hi[0], hi[1]};
-                    const uint32_t ka = fa + OFF_K + 8 * 4096 + f * 1024;
-                    DSW128(ka, kv, 0);
-                }
-            }
-            if (w == 1 && lane < 16) {  // 2 sub-images x 8 pieces of 8 bytes
-                const int t = lane >> 3, part = lane & 7;
-                const u32x2 vv = lds_ld64w(crow + (2 * D + 64 * h + 32 * t + 4 * part) * 2);
-                const uint32_t vd = lbase + OFF_V + t * VSUB + 256 * 64 + part * 8;
-                DSW64(vd, vv, 0);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // K / V images of this head are complete
+        }
+        QSTAMP(0);
+        // ---- the [CLS] token's key and value of this head: K image tile 8 row 0, V image row 256 ----
+        // (the row was fetched a patch ago; its q | k | v lie at 0 | 768 | 1536 bytes)
+        if (w == 0 && r == 0) {  // lanes 0 and 32: the two lane halves of row 0; fragment f = (d tile f >> 1, k-step f & 1):
+                                 // dims 16 f + 4 hh ..+3 and 16 f + 8 + 4 hh ..+3
+            const uint32_t ksrc = crow + (D + 64 * hs + 4 * hh) * 2;
+            u32x2 k0, k1, k2, k3, k4, k5, k6, k7;
+            asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:16\n\tds_read_b64 %2, %8 offset:32\n\tds_read_b64 %3, %8 offset:48\n\t"
+                         "ds_read_b64 %4, %8 offset:64\n\tds_read_b64 %5, %8 offset:80\n\tds_read_b64 %6, %8 offset:96\n\tds_read_b64 %7, %8 offset:112\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3), "=&v"(k4), "=&v"(k5), "=&v"(k6), "=&v"(k7)
+                         : "v"(ksrc));
+            const uint32_t ka = fa + OFF_K + 8 * 4096;
+            const u32x4 f0 = {k0[0], k0[1], k1[0], k1[1]}, f1 = {k2[0], k2[1], k3[0], k3[1]}, f2 = {k4[0], k4[1], k5[0], k5[1]},
+                        f3 = {k6[0], k6[1], k7[0], k7[1]};
+            DSW128(ka, f0, 0);
+            DSW128(ka, f1, 1024);
+            DSW128(ka, f2, 2048);
+            DSW128(ka, f3, 3072);
+        }
+        if (w == 1 && ln < 16) {  // 2 sub-images x 8 pieces of 8 bytes
+            const int t = ln >> 3, part = ln & 7;
+            const u32x2 vv = lds_ld64w(crow + (2 * D + 64 * hs + 32 * t + 4 * part) * 2);
+            const uint32_t vd = lbase + OFF_V + t * VSUB + 256 * 64 + part * 8;
+            DSW64(vd, vv, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // K / V images of this patch are complete
+        QSTAMP(1);
 
-            // ================= the [CLS] query against this wave's keys (wave 0: + the [CLS] key) =================
-            // (first, while few registers are live: the partial is merged behind the next head's first barrier)
+        f32x16 O[2];
+        float l = 0.f;
+        if constexpr ((DBG & 4) != 0) {
+            O[0] = O[1] = Z16;
+            O[0][0] = __builtin_bit_cast(float, qop[0][0][0]);
+            O[1][0] = __builtin_bit_cast(float, qop[1][1][3]);
+            l = 1.f;
+            load_xop(b + gstep < p.nseq ? b + gstep : b);
+        } else {
+        // ================= the [CLS] query against this wave's keys (wave 0: + the [CLS] key) =================
+        // (first, while few registers are live: the partial is merged behind the next patch's first barrier)
+        auto cls_query = [&]() __attribute__((always_inline)) {
+        if constexpr ((DBG & 16) == 0) {
+            u32x4 qc[4];  // B operand with one live column (query 0 = lanes 0 and 32): fragment f = (d tile, k-step)
             {
-                u32x4 qc[4];  // B operand with one live column (query 0 = lanes 0 and 32): fragment f = (d tile, k-step)
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const uint32_t qsrc = crow + (64 * h + 16 * f + 4 * hh) * 2;
-                    const u32x2 lo = lds_ld64w(qsrc), hi = lds_ld64w(qsrc + 16);
-                    qc[f] = r == 0 ? u32x4{lo[0], lo[1], hi[0], hi[1]} : u32x4{0u, 0u, 0u, 0u};
-                }
-                f32x16 Sc[2];
-                const uint32_t ko = fa + OFF_K + w * 4096, k8 = fa + OFF_K + 8 * 4096;
-                {
-                    u32x4 a0, a1, a2, a3;
-                    DSR128X4_WAIT(a0, a1, a2, a3, ko, 0, 1024, 2048, 3072);
-                    Sc[0] = mfma32(a0, qc[0], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
-                    Sc[0] = mfma32(a1, qc[1], Sc[0]);
-                    Sc[0] = mfma32(a2, qc[2], Sc[0]);
-                    Sc[0] = mfma32(a3, qc[3], Sc[0]);
-                    DSR128X4_WAIT(a0, a1, a2, a3, k8, 0, 1024, 2048, 3072);
-                    Sc[1] = mfma32(a0, qc[0], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
-                    Sc[1] = mfma32(a1, qc[1], Sc[1]);
-                    Sc[1] = mfma32(a2, qc[2], Sc[1]);
-                    Sc[1] = mfma32(a3, qc[3], Sc[1]);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (w != 0 || i != 0 || hh != 0) Sc[1][i] = -INFINITY;  // the [CLS] key belongs to wave 0's share
-                float mc = Sc[1][0];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mc = fmaxf(mc, Sc[0][i]);
-                mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
-                const float mcs = -mc * p.sl2e;
-                float lc = 0.f;
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(Sc[k][i], p.sl2e, mcs));
-                        lc += e;
-                        Sc[k][i] = e;
-                    }
-                lc += __shfl_xor(lc, 32, 64);
-                f32x16 Oc[2];
-                const u32x4 pc0 = pack8<0>(Sc[0]), pc1 = pack8<1>(Sc[0]), pc8 = pack8<0>(Sc[1]);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const uint32_t vo = va + t * VSUB + 32 * w * 64, v8 = va + t * VSUB + 256 * 64;
-                    u32x2 a0, a1, b0, b1, c0, c1;
-                    asm volatile("ds_read_b64_tr_b16 %0, %6\n\tds_read_b64_tr_b16 %1, %6 offset:512\n\tds_read_b64_tr_b16 %2, %6 offset:1024\n\t"
-                                 "ds_read_b64_tr_b16 %3, %6 offset:1536\n\tds_read_b64_tr_b16 %4, %7\n\tds_read_b64_tr_b16 %5, %7 offset:512\n\t"
-                                 "s_waitcnt lgkmcnt(0)"
-                                 : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1), "=&v"(c0), "=&v"(c1)
-                                 : "v"(vo), "v"(v8));
-                    Oc[t] = mfma32(u32x4{a0[0], a0[1], a1[0], a1[1]}, pc0, f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
-                    Oc[t] = mfma32(u32x4{b0[0], b0[1], b1[0], b1[1]}, pc1, Oc[t]);
-                    Oc[t] = mfma32(u32x4{c0[0], c0[1], c1[0], c1[1]}, pc8, Oc[t]);
-                }
-                if (r == 0) {  // query 0: lane 0 holds dims 8 q + 0..3, lane 32 dims 8 q + 4..7 of each d tile
-                    const uint32_t pa = lbase + OFF_CLSP + (pq * 8 + w) * CLSP_W;
-                    if (hh == 0) {
-                        DSW32(pa, mc, 0);
-                        DSW32(pa, lc, 4);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const f32x4 v = {Oc[t][4 * q], Oc[t][4 * q + 1], Oc[t][4 * q + 2], Oc[t][4 * q + 3]};
-                            const uint32_t da = pa + 16 + (32 * t + 8 * q + 4 * hh) * 4;
-                            DSW128(da, v, 0);
-                        }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const uint32_t qsrc = crow + (64 * hs + 4 * hh) * 2;
+                u32x2 q0, q1, q2, q3, q4, q5, q6, q7;
+                asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:16\n\tds_read_b64 %2, %8 offset:32\n\tds_read_b64 %3, %8 offset:48\n\t"
+                             "ds_read_b64 %4, %8 offset:64\n\tds_read_b64 %5, %8 offset:80\n\tds_read_b64 %6, %8 offset:96\n\tds_read_b64 %7, %8 offset:112\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(q7)
+                             : "v"(qsrc));
+                const bool live = r == 0;
+                qc[0] = live ? u32x4{q0[0], q0[1], q1[0], q1[1]} : u32x4{0u, 0u, 0u, 0u};
+                qc[1] = live ? u32x4{q2[0], q2[1], q3[0], q3[1]} : u32x4{0u, 0u, 0u, 0u};
+                qc[2] = live ? u32x4{q4[0], q4[1], q5[0], q5[1]} : u32x4{0u, 0u, 0u, 0u};
+                qc[3] = live ? u32x4{q6[0], q6[1], q7[0], q7[1]} : u32x4{0u, 0u, 0u, 0u};
             }
-            // ================= attention of this wave's 32 queries =================
-            f32x16 S[9];
+            f32x16 Sc[2];
+            const uint32_t ko = fa + OFF_K + w * 4096, k8 = fa + OFF_K + 8 * 4096;
             {
-                u32x4 kf[4];
-                const uint32_t kb = fa + OFF_K;  // (ds offsets are 16-bit: the image base travels in the address register)
-                {
-                    u32x4 &k0 = kf[0], &k1 = kf[1], &k2 = kf[2];
-                    DSR128(k0, kb, 0);
-                    DSR128(k1, kb, 1024);
-                    DSR128(k2, kb, 2048);
+                u32x4 a0, a1, a2, a3, c0, c1, c2, c3;
+                asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
+                             "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:1024\n\tds_read_b128 %6, %9 offset:2048\n\tds_read_b128 %7, %9 offset:3072\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+                             : "v"(ko), "v"(k8));
+                Sc[0] = mfma32(a0, qc[0], Z16);
+                Sc[1] = mfma32(c0, qc[0], Z16);
+                Sc[0] = mfma32(a1, qc[1], Sc[0]);
+                Sc[1] = mfma32(c1, qc[1], Sc[1]);
+                Sc[0] = mfma32(a2, qc[2], Sc[0]);
+                Sc[1] = mfma32(c2, qc[2], Sc[1]);
+                Sc[0] = mfma32(a3, qc[3], Sc[0]);
+                Sc[1] = mfma32(c3, qc[3], Sc[1]);
+            }
+            // the [CLS] key (register 0 of lane half 0 of tile 8) belongs to wave 0's share
+            const float s8 = (w == 0 && hh == 0) ? Sc[1][0] : -INFINITY;
+            float mc = s8;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mc = fmaxf(mc, Sc[0][i]);
+            mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
+            const float mcs = -mc * p.sl2e;
+            float lc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(Sc[0][i], p.sl2e, mcs));
+                lc += e;
+                Sc[0][i] = e;
+            }
+            const float e8 = __builtin_amdgcn_exp2f(__builtin_fmaf(s8, p.sl2e, mcs));
+            lc += e8;
+            lc += __shfl_xor(lc, 32, 64);
+            const u32x4 pc0 = pack8<0>(Sc[0]), pc1 = pack8<1>(Sc[0]);
+            const u32x4 pc8 = {pack_bf16x2(e8, 0.f), 0u, 0u, 0u};
+            f32x16 Oc[2];
+            {
+                const uint32_t vo = va + 32 * w * 64, v8 = va + 256 * 64;
+                u32x2 a0, a1, b0v, b1v, c0, c1, d0, d1, e0, e1, f0, f1;
+                asm volatile("ds_read_b64_tr_b16 %0, %12\n\tds_read_b64_tr_b16 %1, %12 offset:512\n\tds_read_b64_tr_b16 %2, %12 offset:1024\n\t"
+                             "ds_read_b64_tr_b16 %3, %12 offset:1536\n\tds_read_b64_tr_b16 %4, %13\n\tds_read_b64_tr_b16 %5, %13 offset:512\n\t"
+                             "ds_read_b64_tr_b16 %6, %12 offset:%14\n\tds_read_b64_tr_b16 %7, %12 offset:%15\n\tds_read_b64_tr_b16 %8, %12 offset:%16\n\t"
+                             "ds_read_b64_tr_b16 %9, %12 offset:%17\n\tds_read_b64_tr_b16 %10, %13 offset:%14\n\tds_read_b64_tr_b16 %11, %13 offset:%15\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(a0), "=&v"(a1), "=&v"(b0v), "=&v"(b1v), "=&v"(c0), "=&v"(c1), "=&v"(d0), "=&v"(d1), "=&v"(e0), "=&v"(e1),
+                               "=&v"(f0), "=&v"(f1)
+                             : "v"(vo), "v"(v8), "n"(VSUB), "n"(VSUB + 512), "n"(VSUB + 1024), "n"(VSUB + 1536));
+                Oc[0] = mfma32(u32x4{a0[0], a0[1], a1[0], a1[1]}, pc0, Z16);
+                Oc[1] = mfma32(u32x4{d0[0], d0[1], d1[0], d1[1]}, pc0, Z16);
+                Oc[0] = mfma32(u32x4{b0v[0], b0v[1], b1v[0], b1v[1]}, pc1, Oc[0]);
+                Oc[1] = mfma32(u32x4{e0[0], e0[1], e1[0], e1[1]}, pc1, Oc[1]);
+                Oc[0] = mfma32(u32x4{c0[0], c0[1], c1[0], c1[1]}, pc8, Oc[0]);
+                Oc[1] = mfma32(u32x4{f0[0], f0[1], f1[0], f1[1]}, pc8, Oc[1]);
+            }
+            if (r == 0) {  // query 0: lane 0 holds dims 8 q + 0..3, lane 32 dims 8 q + 4..7 of each d tile
+                const uint32_t pa = lbase + OFF_CLSP + (pq * 8 + w) * CLSP_W;
+                if (hh == 0) {
+                    DSW32(pa, mc, 0);
+                    DSW32(pa, lc, 4);
                 }
-                sfor<0, 36>([&](auto I_) __attribute__((always_inline)) {
-                    constexpr int i = decltype(I_)::value, kt = i >> 2, f = i & 3;
-                    if constexpr (i + 3 < 36) {
-                        u32x4& kn = kf[(i + 3) & 3];
-                        const uint32_t ka2 = kb;
-                        DSR128(kn, ka2, (i + 3) * 1024);
-                        LGKM(3);
-                    } else {
-                        LGKM(35 - i);
-                    }
-                    if constexpr (f == 0) S[kt] = mfma32(kf[i & 3], qop[0][0], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
-                    else S[kt] = mfma32(kf[i & 3], qop[f >> 1][f & 1], S[kt]);
-                    __builtin_amdgcn_sched_barrier(0);
+                const uint32_t da = pa + 16 + 16 * hh;
+                sfor<0, 8>([&](auto Q_) __attribute__((always_inline)) {
+                    constexpr int tq = decltype(Q_)::value, t = tq >> 2, q = tq & 3;
+                    const f32x4 v = {Oc[t][4 * q], Oc[t][4 * q + 1], Oc[t][4 * q + 2], Oc[t][4 * q + 3]};
+                    const uint32_t a = da;
+                    DSW128(a, v, (32 * t + 8 * q) * 4);
                 });
             }
-            // tile 8 holds one key (register 0 of lane half 0): the rest is padding
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        };
+        cls_query();
+        QSTAMP(2);
+        // ================= attention of this wave's 32 queries =================
+        f32x16 S[9];
+        float m;
+        {
+            // S^T tiles; the running maximum of a finished tile is taken under the MFMAs of the next one
+            u32x4 kf[4];
+            const uint32_t kb = fa + OFF_K;  // (ds offsets are 16-bit: the image base travels in the address register)
+            {
+                u32x4 &k0 = kf[0], &k1 = kf[1], &k2 = kf[2];
+                DSR128(k0, kb, 0);
+                DSR128(k1, kb, 1024);
+                DSR128(k2, kb, 2048);
+            }
+            sfor<0, 36>([&](auto I_) __attribute__((always_inline)) {
+                constexpr int i = decltype(I_)::value, kt = i >> 2, f = i & 3;
+                if constexpr (i + 3 < 36) {
+                    u32x4& kn = kf[(i + 3) & 3];
+                    const uint32_t ka2 = kb;
+                    DSR128(kn, ka2, (i + 3) * 1024);
+                    LGKM(3);
+                } else {
+                    LGKM(35 - i);
+                }
+                if constexpr (f == 0) S[kt] = mfma32(kf[i & 3], qop[0][0], Z16);
+                else S[kt] = mfma32(kf[i & 3], qop[f >> 1][f & 1], S[kt]);
+                if constexpr (kt >= 1) {  // a quarter of tile kt - 1 per step: 2 x v_max3_f32
+                    constexpr int e = 4 * f;
+                    if constexpr (kt == 1 && f == 0) m = __builtin_fmaxf(__builtin_fmaxf(S[0][0], S[0][1]), __builtin_fmaxf(S[0][2], S[0][3]));
+                    else m = __builtin_fmaxf(__builtin_fmaxf(m, S[kt - 1][e]), S[kt - 1][e + 1]), m = __builtin_fmaxf(__builtin_fmaxf(m, S[kt - 1][e + 2]), S[kt - 1][e + 3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        QSTAMP(3);
+        // tile 8 holds one key (register 0 of lane half 0): the rest is padding and gets probability 0 without an exponential
+        const float s8m = hh == 0 ? S[8][0] : -INFINITY;
+        m = fmaxf(m, s8m);
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float ms = -m * p.sl2e;
+        auto exp_quarter = [&](auto KT_, auto Q_) __attribute__((always_inline)) {  // registers 4 q ..+3 of tile kt -> probabilities
+            constexpr int kt = decltype(KT_)::value, q = decltype(Q_)::value;
+            if constexpr ((DBG & 32) != 0) {
+                if constexpr (q == 0) l += S[kt][0];
+            } else if constexpr (kt < 8) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (i != 0 || hh != 0) S[8][i] = -INFINITY;
-            float m = fmaxf(S[0][0], S[0][1]);
-#pragma unroll
-            for (int kt = 0; kt < 9; ++kt)
-#pragma unroll
-                for (int i = 0; i < 16; i += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, S[kt][i]), S[kt][i + 1]);  // v_max3_f32
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            const float ms = -m * p.sl2e;
-            float l = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 9; ++kt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
+                for (int i = 4 * q; i < 4 * q + 4; ++i) {
                     const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][i], p.sl2e, ms));
                     l += e;
                     S[kt][i] = e;
                 }
+            } else if constexpr (q == 0) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s8m, p.sl2e, ms));
+                l += e;
+                S[8][0] = e;
+                S[8][1] = S[8][2] = S[8][3] = S[8][4] = S[8][5] = S[8][6] = S[8][7] = 0.f;
+            }
+        };
+        typedef std::integral_constant<int, 0> I0_;
+        exp_quarter(I0_{}, I0_{});
+        exp_quarter(I0_{}, std::integral_constant<int, 1>{});
+        exp_quarter(I0_{}, std::integral_constant<int, 2>{});
+        exp_quarter(I0_{}, std::integral_constant<int, 3>{});
+        QSTAMP(4);
+        // O^T = V^T P^T: 17 (key tile, k-step) pairs (tile 8: its first k-step holds the one key) x 2 d tiles; the exponentials of
+        // tile kt + 1 run under the four MFMAs of tile kt, and in the second half the operands of the NEXT patch are requested
+        // into the registers the spent score tiles leave (unconditionally -- past the last patch the current one again)
+        {
+            const int nb = b + gstep < p.nseq ? b + gstep : b;
+            const int64_t Rn = (int64_t)nb * NTOK + 1 + 32 * w + r;
+            const char* x0 = p.xn + (Rn >> 4) * 12288 + (Rn & 15) * 16 + hh * 256;
+            const char* x1 = x0 + 4096;
+            const char* x2 = x0 + 8192;
+            u32x2 vf[4][2];
+            auto rdv = [&](auto J_) __attribute__((always_inline)) {
+                constexpr int j = decltype(J_)::value, pi = j >> 1, t = j & 1, kt = pi >> 1, s = pi & 1;
+                constexpr int off = t * VSUB + (32 * kt + 16 * s) * 64;
+                u32x2 &lo = vf[j & 3][0], &hi = vf[j & 3][1];
+                const uint32_t a = va;
+                DSRTR(lo, a, off);
+                DSRTR(hi, a, off + 8 * 64);
+            };
+            rdv(std::integral_constant<int, 0>{});
+            rdv(std::integral_constant<int, 1>{});
+            u32x4 pop;
+            sfor<0, 34>([&](auto J_) __attribute__((always_inline)) {
+                constexpr int j = decltype(J_)::value, pi = j >> 1, t = j & 1, kt = pi >> 1, s = pi & 1;
+                if constexpr (j + 2 < 34) {
+                    rdv(std::integral_constant<int, j + 2>{});
+                    LGKM(4);
+                } else {
+                    LGKM((33 - j) * 2);
+                }
+                if constexpr (kt + 1 < 9) exp_quarter(std::integral_constant<int, kt + 1>{}, std::integral_constant<int, (j & 3)>{});
+                if constexpr (t == 0) pop = s == 0 ? pack8<0>(S[kt]) : pack8<1>(S[kt]);
+                const u32x4 vfrag = {vf[j & 3][0][0], vf[j & 3][0][1], vf[j & 3][1][0], vf[j & 3][1][1]};
+                if constexpr (pi == 0) O[t] = mfma32(vfrag, pop, Z16);
+                else O[t] = mfma32(vfrag, pop, O[t]);
+                if constexpr (j >= 10 && (DBG & 64) == 0) {  // operand chunk j - 10: by now the score tiles before (j / 4) are spent, registers to spare
+                    constexpr int c = j - 10;
+                    u32x4& d = xop[c];
+                    const char *a0 = x0, *a1 = x1, *a2 = x2;
+                    if constexpr (c < 8) GLD128(d, a0, c * 512);
+                    else if constexpr (c < 16) GLD128(d, a1, (c - 8) * 512);
+                    else GLD128(d, a2, (c - 16) * 512);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        }
+        QSTAMP(5);
+        // store: registers 4 q ..+3 of tile t = dims 32 t + 8 q + 4 hh ..+3 = chunk 8 hs + 4 t + q, bytes 8 hh ..+7
+        {
             l += __shfl_xor(l, 32, 64);
             const float inv = 1.0f / l;
-            // O^T = V^T P^T: 17 (key tile, k-step) pairs (tile 8: its first k-step holds the one key) x 2 d tiles
-            f32x16 O[2];
-            {
-                u32x2 vf[4][2];
-                auto rdv = [&](auto J_) __attribute__((always_inline)) {
-                    constexpr int j = decltype(J_)::value, pi = j >> 1, t = j & 1, kt = pi >> 1, s = pi & 1;
-                    constexpr int off = t * VSUB + (32 * kt + 16 * s) * 64;
-                    u32x2 &lo = vf[j & 3][0], &hi = vf[j & 3][1];
-                    const uint32_t a = va;
-                    DSRTR(lo, a, off);
-                    DSRTR(hi, a, off + 8 * 64);
-                };
-                rdv(std::integral_constant<int, 0>{});
-                rdv(std::integral_constant<int, 1>{});
-                u32x4 pop;
-                sfor<0, 34>([&](auto J_) __attribute__((always_inline)) {
-                    constexpr int j = decltype(J_)::value, pi = j >> 1, t = j & 1, kt = pi >> 1, s = pi & 1;
-                    if constexpr (j + 2 < 34) {
-                        rdv(std::integral_constant<int, j + 2>{});
-                        LGKM(4);
-                    } else {
-                        LGKM((33 - j) * 2);
-                    }
-                    if constexpr (t == 0) pop = s == 0 ? pack8<0>(S[kt]) : pack8<1>(S[kt]);
-                    const u32x4 vfrag = {vf[j & 3][0][0], vf[j & 3][0][1], vf[j & 3][1][0], vf[j & 3][1][1]};
-                    if constexpr (pi == 0) O[t] = mfma32(vfrag, pop, f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
-                    else O[t] = mfma32(vfrag, pop, O[t]);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            }
-            // the registers of the scores are free: request the operands of the next head (same rows) or the next patch
-            // (unconditionally -- past the last patch the current one again: a conditional load would keep the OLD operands alive
-            //  through the whole attention phase on the not-taken path, 96 registers the scores need)
-            {
-                const int nb = h + 1 < HEADS ? b : b + bstep;
-                load_xop(nb < p.nseq ? nb : b);
-            }
-            // store: registers 4 q ..+3 of tile t = dims 32 t + 8 q + 4 hh ..+3 = chunk 8 h + 4 t + q, bytes 8 hh ..+7
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -480,18 +641,19 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                     u32x2 o;
                     o[0] = pack_bf16x2(O[t][4 * q] * inv, O[t][4 * q + 1] * inv);
                     o[1] = pack_bf16x2(O[t][4 * q + 2] * inv, O[t][4 * q + 3] * inv);
-                    __builtin_amdgcn_raw_buffer_store_b64(o, orsrc, orow + h * 2048 + t * 1024 + q * 256, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, orsrc, orow + t * 1024 + q * 256, 0, 0);
                 }
-
-            prev_b = b;
-            prev_h = h;
         }
+        QSTAMP(6);
+        prev_b = b;
     }
-    // ---- the last (patch, head)'s [CLS] partials ----
+    // ---- the last patch's [CLS] partials ----
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (prev_b >= 0 && w == (prev_h & 7)) merge_cls(prev_b, prev_h, pq ^ 1);
+    if (prev_b >= 0 && w == ((prev_b / gstep) & 7)) merge_cls(prev_b, pq ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (continuous stream: pieces of units nobody consumes)
+    if (QST_ON(p.stamps) && tid == 0)
+        for (int k = 0; k < 8; ++k) p.stamps[(size_t)blockIdx.x * 8 + k] = st_sum[k];
 }
 
 }  // namespace
@@ -516,7 +678,13 @@ int hipt_qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b
     static DevOnce once;
     HIPT_CUR_DEVICE(dev);
     if (!once.done[dev]) {
-        if (hipFuncSetAttribute((const void*)qkv_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+        bool ok = hipFuncSetAttribute((const void*)qkv_attn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+#ifdef HIPT_DEBUG_STAMPS
+#define QKV_DBG_LIST(X) X(1) X(2) X(3) X(4) X(7) X(8) X(12) X(16) X(32) X(48) X(64) X(15)
+#define QKV_SETATTR(n) ok = ok && hipFuncSetAttribute((const void*)qkv_attn_kernel<n>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+        QKV_DBG_LIST(QKV_SETATTR)
+#endif
+        if (!ok) {
             hipt_set_error("hipFuncSetAttribute(qkv_attention) failed");
             return HIPT_E_LAUNCH;
         }
@@ -537,8 +705,50 @@ int hipt_qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b
     p.nseq = nseq;
     p.sl2e = scale * 1.4426950408889634f;
     p.out_bytes = (unsigned)((int64_t)nseq * NTOK * D * 2);
-    const int grid = nseq < once.ncu[dev] ? nseq : once.ncu[dev];
-    hipLaunchKernelGGL(qkv_attn_kernel, dim3(grid), dim3(512), LDS_BYTES, st, p);
+    p.stamps = nullptr;
+    // groups of six workgroups: with whole XCDs to fill (8 XCDs x (CUs / 8 / 6) groups: 40 groups = 240 of 256 CUs on MI355X) the six
+    // heads of a patch are placed on one XCD, so that its rows come through ONE L2 instead of from the fabric six times
+    const int ncu = once.ncu[dev], per_xcd = (ncu / 8) / HEADS;
+    if (per_xcd > 0 && nseq >= 8 * per_xcd) {
+        p.xcd_groups = per_xcd;
+        p.ngroups = 8 * per_xcd;
+    } else {
+        p.xcd_groups = 0;
+        p.ngroups = nseq < ncu / HEADS ? nseq : (ncu / HEADS > 0 ? ncu / HEADS : 1);
+    }
+    const int grid = p.ngroups * HEADS;
+#ifdef HIPT_DEBUG_STAMPS  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
+    static const bool want_stamps = getenv("HIPT_QKVATT_STAMPS") != nullptr;
+    static unsigned long long* dbuf = nullptr;
+    if (want_stamps) {
+        if (!dbuf) (void)hipMalloc(&dbuf, 1024 * 8 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbuf, 0, 1024 * 8 * sizeof(unsigned long long), st);
+        p.stamps = dbuf;
+    }
+#endif
+#ifdef HIPT_DEBUG_STAMPS
+    static const int dbg = getenv("HIPT_QKVATT_DBG") ? atoi(getenv("HIPT_QKVATT_DBG")) : 0;
+    auto k = qkv_attn_kernel<0>;
+#define QKV_PICK(n) if (dbg == n) k = qkv_attn_kernel<n>;
+    QKV_DBG_LIST(QKV_PICK)
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS_BYTES, st, p);
+#else
+    hipLaunchKernelGGL(qkv_attn_kernel<0>, dim3(grid), dim3(512), LDS_BYTES, st, p);
+#endif
     HIPT_CHECK_LAUNCH();
+#ifdef HIPT_DEBUG_STAMPS
+    if (want_stamps && grid <= 1024) {
+        static unsigned long long h[1024 * 8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, dbuf, (size_t)grid * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const double heads = (double)((nseq + p.ngroups - 1) / p.ngroups);
+        for (int b = 0; b < grid; ++b)
+            for (int k = 0; k < 8; ++k) ph[k] += (double)h[b * 8 + k] / grid / heads;
+        fprintf(stderr, "[qkv_attention nseq=%d grid=%d] cycles per (patch, head) (wave 0): GEMM units %.0f | [CLS] k/v + barrier %.0f | [CLS] query %.0f | scores %.0f | "
+                        "softmax %.0f | PV %.0f | operand loads + stores %.0f  (sum %.0f)\n",
+                nseq, grid, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5] + ph[6]);
+    }
+#endif
     return HIPT_OK;
 }

@@ -37,6 +37,9 @@ for i, l in enumerate(src):
         if m:
             regs = set(range(int(m.group(2)), int(m.group(3)) + 1)) if m.group(2) else {int(m.group(4))}
             gqueue.append((i + 1, regs))
+        m = re.match(r"global_load\w* a\[(\d+):(\d+)\],", t)  # (accumulator-file destination: registers 1000 + n below)
+        if m:
+            gqueue.append((i + 1, set(range(1000 + int(m.group(1)), 1000 + int(m.group(2)) + 1))))
         if "XOP_FENCE" in t:
             gqueue = []
         for mm in re.finditer(r"lgkmcnt\((\d+)\)", t):
@@ -56,6 +59,9 @@ for i, l in enumerate(src):
     for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", t):
         regs.update(range(int(a), int(b) + 1))
     regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", t))
+    for a, b in re.findall(r"\ba\[(\d+):(\d+)\]", t):
+        regs.update(range(1000 + int(a), 1000 + int(b) + 1))
+    regs.update(1000 + int(a) for a in re.findall(r"\ba(\d+)\b", t))
     for ln, rs in queue + gqueue:
         hit = regs & rs
         if hit:
