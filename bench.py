@@ -68,6 +68,9 @@ def parse_args(argv=None):
     ap.add_argument("--slides", type=int, default=64, help="config 5: synthetic slides over all ranks (0 = skip the leg)")
     ap.add_argument("--slide-regions", type=int, default=8192, help="config 5: nominal regions per slide")
     ap.add_argument("--slide-sample", type=int, default=8, help="config 5: regions per slide actually extracted (stated sub-sample)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearsal of the multi-rank leg without a GPU: gloo backend, CPU tensors, stand-in models -- the same spawn / "
+                         "init / barrier / timed loop / config 5 / gather / rank-0 JSON code path (tests/test_pipeline.py runs it with --gpus 2)")
     return ap.parse_args(argv)
 
 
@@ -78,7 +81,7 @@ def spawn_ranks(args) -> int:
 
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not args.dry_run:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
     s = socket.socket()
@@ -89,6 +92,26 @@ def spawn_ranks(args) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def dry_models():
+    """--dry-run stand-ins with the call surface of HIPT_4K / CLAM_SB (CPU, deterministic): the driver code around them is the
+    code under rehearsal, not they."""
+    import torch
+
+    def model(regions):
+        r = regions.float().flatten(1)
+        return r[:, :r.shape[1] // 192 * 192].reshape(r.shape[0], 192, -1).mean(dim=-1)
+
+    def clam(bag):
+        b = bag.float()
+        a_raw = b.mean(dim=1).reshape(1, -1)
+        m = torch.softmax(a_raw, dim=1) @ b
+        logits = m[:, :2] * 3.0
+        return logits, torch.softmax(logits, dim=1), logits.argmax(dim=1, keepdim=True), a_raw, {}
+
+    model.streams = model.chunk = 0
+    return model, clam, clam
 
 
 def build_models(dev, dtype):
@@ -161,7 +184,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline():
+def cpu_baseline(check_bag_seed=None):
     """SURVEY.md §8(d) / BASELINE.md §4: the PyTorch-CPU restatement of the path (oracle/torch_cpu.py, pinned against the
     reference's outputs by tests/test_oracle_vs_golden.py) on the box's host cores, fp32, torch.set_num_threads(cores),
     warm-up 2 + min-of-5: ViT-256 on 16 patches (extrapolated to the 256 of a region) + one full ViT-4K; CLAM_SB on the
@@ -207,6 +230,12 @@ def cpu_baseline():
         bag = torch.from_numpy(synth.hash_uniform_np((BAG_N, BAG_S0), 4))
         t_2k = best(lambda: TO.clam_sb_forward(bag[:2000], pc))
         t_100k = best(lambda: TO.clam_sb_forward(bag, pc))
+        # the checker's answer on the bag the GPU's last timed step pooled (rank 0, bag 40 + i): what `selfcheck` compares with
+        chk = {}
+        if check_bag_seed is not None:
+            cb = torch.from_numpy(synth.hash_uniform_np((BAG_N, BAG_S0), check_bag_seed)).to(torch.bfloat16).float()  # (the resident bag is bf16)
+            lg_, _, yh_, ar_, _ = TO.clam_sb_forward(cb, pc)
+            chk = {"logits": lg_.reshape(-1).tolist(), "Y_hat": int(yh_.reshape(-1)[0]), "A_raw_head": ar_.reshape(-1)[:4096].tolist()}
     region_s = t_p / n_p * 256 + t_4k
     # the numpy oracle, one un-repeated bounded sample (round 1's figure, kept for continuity)
     xs = synth.hash_uniform_np((8, 3, 256, 256), 3)
@@ -220,7 +249,7 @@ def cpu_baseline():
                       f"256 patches of one 4096x4096 region ({t_p:.2f} s) extrapolated + one full ViT-4K ({t_4k * 1e3:.1f} ms); "
                       f"CLAM_SB on the full 2000x384 and 100000x384 fp32 bags",
             "patches_per_s": n_p / t_p, "seconds_per_region": region_s, "vit256_one_patch_ms": t_1 * 1e3,
-            "abmil_fwd_ms": t_100k * 1e3, "abmil_2000_fwd_ms": t_2k * 1e3,
+            "abmil_fwd_ms": t_100k * 1e3, "abmil_2000_fwd_ms": t_2k * 1e3, "_check": chk,
             "numpy_port": {"regions_per_s": 1.0 / (t_np + t_4k), "sample": "numpy oracle, ViT-256 on 8 patches, one pass, extrapolated"}}
 
 
@@ -237,27 +266,43 @@ def main():
     from hipt_abmil_atec23_amd import pipeline as PL
     from hipt_abmil_atec23_amd import synth
 
-    rank, world, local = D.init_from_env()
+    dry = args.dry_run
+    rank, world, local = D.init_from_env(backend="gloo" if dry else None)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the job has WORLD_SIZE={world} rank(s): refusing to report a number for a "
                          f"different GPU count than asked for")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    N.lib()  # fail loudly before doing anything if the native library is missing
-
-    model, clam, clam192 = build_models(dev, args.dtype)
+    if dry:
+        # the rehearsal: every line of the multi-rank leg below runs, on CPU tensors over gloo, with stand-in models and small shapes
+        dev = torch.device("cpu")
+        model, clam, clam192 = dry_models()
+        REGION_PX, n_bag = 32, 2000
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+        N.lib()  # fail loudly before doing anything if the native library is missing
+        model, clam, clam192 = build_models(dev, args.dtype)
+        REGION_PX, n_bag = REGION, BAG_N
     model.streams = args.streams
     model.chunk = args.chunk
     R = args.regions
-    region = synth.hash_uniform_torch((R, 3, REGION, REGION), 3 + rank, device=dev)
+    region = synth.hash_uniform_torch((R, 3, REGION_PX, REGION_PX), 3 + rank, device=dev)
     if args.u8:  # the same pixels as decoded 8-bit RGB tiles (interleaved), 4x fewer bytes
         region = ((region * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
     n_bags = 5  # 5 x 76.8 MB > 256 MiB Infinity Cache
     bag_dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    bags = [synth.hash_uniform_torch((BAG_N, BAG_S0), 40 + 10 * rank + i, device=dev).to(bag_dt) for i in range(n_bags)]
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    bags = [synth.hash_uniform_torch((n_bag, BAG_S0), 40 + 10 * rank + i, device=dev).to(bag_dt) for i in range(n_bags)]
+
+    class _HostEvent:  # (--dry-run: the same bracketing, host clock)
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    new_event = _HostEvent if dry else (lambda: torch.cuda.Event(enable_timing=True))
+    ev = [(new_event(), new_event()) for _ in range(args.steps)]
 
     def step(i, timed):
         f = model(region)
@@ -272,7 +317,8 @@ def main():
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i, False)
@@ -327,6 +373,22 @@ def main():
     if rank != 0:
         if world > 1:
             torch.distributed.barrier()  # rank 0's single-GPU legs below: keep the group alive until it is done
+            torch.distributed.destroy_process_group()
+        return
+
+    if dry:
+        out = {"metric": METRIC, "value": world * args.steps * R / dt, "unit": "regions/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic", "dry_run": True,
+               "config": {"workload": "DRY RUN (no GPU, not a measurement): stand-in models on CPU tensors over gloo through the code path of the "
+                                      "multi-rank leg", "regions_per_step": R, "parallelism": f"slide-sharded x{world}, one all-gather"},
+               "abmil_fwd_ms": abmil_ms}
+        if cfg5:
+            out["config5"] = cfg5
+        print(json.dumps(out))
+        sys.stdout.flush()
+        if world > 1:
+            torch.distributed.barrier()
             torch.distributed.destroy_process_group()
         return
 
@@ -449,8 +511,31 @@ def main():
         model.streams = args.streams
         out["extras"] = ex
 
+    # ---- selfcheck: the timed workload's own outputs against the committed golden vector / the CPU checker ----
+    sc = {}
+    if args.dtype == "bf16" and not args.u8 and R >= 1:
+        try:  # region 0 of rank 0 = seed 3 = the input of tests/golden/hipt4k_4096.npz (the reference's own output on it)
+            g = np.load(os.path.join(ROOT, "tests", "golden", "hipt4k_4096.npz"))["out"].astype(np.float64).ravel()
+            f0 = last[0][0].float().cpu().numpy().astype(np.float64).ravel()
+            sc["region0_rel_l2_vs_reference_golden"] = float(np.linalg.norm(f0 - g) / np.linalg.norm(g))
+            sc["region0_ok"] = bool(sc["region0_rel_l2_vs_reference_golden"] <= 1.3e-2)  # the bf16 bar of tests/test_gpu_parity.py
+        except Exception as e:  # a missing fixture must not eat the bench line
+            sc["region0_error"] = repr(e)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        cb = cpu_baseline(check_bag_seed=40 + (args.steps - 1) % n_bags if args.steps else None)
+        chk = cb.pop("_check", {})
+        out["cpu_baseline"] = cb
+        if chk and args.dtype == "bf16":  # the last timed step's bag through the PyTorch-CPU restatement (bf16-rounded bag, fp32 math)
+            lg = last[1].float().cpu().numpy().ravel()
+            ar = last[2].float().cpu().numpy().ravel()[:len(chk["A_raw_head"])]
+            sc["bag_logits_max_abs"] = float(np.abs(lg - np.asarray(chk["logits"])).max())
+            sc["bag_a_raw_max_abs"] = float(np.abs(ar - np.asarray(chk["A_raw_head"])).max())
+            sc["bag_ok"] = bool(sc["bag_logits_max_abs"] <= 1e-3 and sc["bag_a_raw_max_abs"] <= 4e-2 and int(np.argmax(lg)) == chk["Y_hat"])
+    else:
+        out.pop("_check", None)
+    oks = [v for k, v in sc.items() if k.endswith("_ok")]
+    out["selfcheck"] = ("ok" if oks and all(oks) else ("FAILED" if oks else "skipped"))
+    out["selfcheck_detail"] = sc
     print(json.dumps(out))
     sys.stdout.flush()
     if world > 1:

@@ -1,4 +1,4 @@
-"""Multi-GPU harness: one process per GPU, slides sharded round-robin, ONE all-gather at the end.
+"""Multi-GPU harness: one process per GPU, slides sharded round-robin, ONE all-gather (+ a 3-integer all-reduce for its shape) at the end.
 
 The reference has no distributed code (an unused ``import torch.distributed`` and two ineffective
 ``nn.DataParallel`` wraps, extract_features_fp.py:217-218).  Regions are independent through
@@ -55,9 +55,12 @@ def gather_slide_outputs(slide_ids: Sequence[int], logits: Sequence[torch.Tensor
 
     ``logits[j]`` is [C] (or [1,C]) and ``a_raw[j]`` is [n_j] (or [1,n_j]) for local slide
     ``slide_ids[j]``.  Returns ``(all_logits [n_slides, C], all_a_raw: list of [n_i] tensors)``
-    ordered by global slide id, identical on every rank.  One collective carries everything: each
-    rank contributes a [S, 2 + C + n_max] fp32 block (slide id, n_i, logits, padded A_raw) where S
-    and n_max are the maxima over ranks (agreed by one tiny all-reduce of two integers)."""
+    ordered by global slide id, identical on every rank.  Two collectives in all: one 3-integer
+    all-reduce (MAX) that agrees on the block shape (slides per rank, longest bag, classes), then ONE
+    all-gather that carries everything -- each rank contributes a [S, 4 + C + n_max] fp32 block whose
+    first four words are NOT floats but the int64 slide id and the int64 length n_i as raw bits
+    (two 32-bit words each: an id or a length above 2**24 would not survive a float), followed by
+    the logits and the zero-padded A_raw."""
     if device is None:
         device = logits[0].device if len(logits) else torch.device("cpu")
     C = int(logits[0].numel()) if len(logits) else 0
@@ -68,14 +71,16 @@ def gather_slide_outputs(slide_ids: Sequence[int], logits: Sequence[torch.Tensor
     if ws > 1:
         dist.all_reduce(meta, op=dist.ReduceOp.MAX)
     S, n_max, C = (int(v) for v in meta.tolist())
-    block = torch.zeros((S, 2 + C + n_max), dtype=torch.float32, device=device)
-    block[:, 0] = -1.0  # empty slot marker
+    HDR = 4  # int64 id | int64 length, bit-cast into four fp32 slots
+    block = torch.zeros((S, HDR + C + n_max), dtype=torch.float32, device=device)
+    hdr = torch.full((S, 2), -1, dtype=torch.int64, device=device)  # id -1: empty slot
     for j, sid in enumerate(slide_ids):
         n = int(a_raw[j].numel())
-        block[j, 0] = float(sid)
-        block[j, 1] = float(n)
-        block[j, 2:2 + C] = logits[j].reshape(-1).float()
-        block[j, 2 + C:2 + C + n] = a_raw[j].reshape(-1).float()
+        hdr[j, 0] = int(sid)
+        hdr[j, 1] = n
+        block[j, HDR:HDR + C] = logits[j].reshape(-1).float()
+        block[j, HDR + C:HDR + C + n] = a_raw[j].reshape(-1).float()
+    block[:, :HDR] = hdr.view(torch.float32)  # raw bits: the collective moves bytes, nothing interprets these words as floats
     if ws > 1:
         out = torch.empty((ws * S, block.shape[1]), dtype=torch.float32, device=device)  # concatenated along dim 0
         dist.all_gather_into_tensor(out, block)
@@ -83,11 +88,11 @@ def gather_slide_outputs(slide_ids: Sequence[int], logits: Sequence[torch.Tensor
         out = block
     all_logits = torch.zeros((n_slides, C), dtype=torch.float32, device=device)
     all_a: List[torch.Tensor] = [torch.empty(0, device=device) for _ in range(n_slides)]
-    ids = out[:, 0].round().to(torch.int64).tolist()
-    lens = out[:, 1].round().to(torch.int64).tolist()
+    meta_i = out[:, :HDR].contiguous().view(torch.int64)
+    ids, lens = meta_i[:, 0].tolist(), meta_i[:, 1].tolist()
     for row, (sid, n) in enumerate(zip(ids, lens)):
         if sid < 0:
             continue
-        all_logits[sid] = out[row, 2:2 + C]
-        all_a[sid] = out[row, 2 + C:2 + C + n].clone()
+        all_logits[sid] = out[row, HDR:HDR + C]
+        all_a[sid] = out[row, HDR + C:HDR + C + n].clone()
     return all_logits, all_a

@@ -67,3 +67,15 @@ def test_single_process_degenerates_to_noop():
     lg, ar = zip(*[_slide(i) for i in range(3)])
     all_logits, all_a = D.gather_slide_outputs([0, 1, 2], list(lg), list(ar), 3)
     assert all(torch.equal(all_logits[i], lg[i]) and torch.equal(all_a[i], ar[i]) for i in range(3))
+
+
+def test_gather_carries_ids_and_lengths_as_integers():
+    """Slide ids and bag lengths travel as int64 bits inside the gathered block: a bag of 2**24 + 1 rows keeps its last row
+    (a float32 length would have lost it)."""
+    from hipt_abmil_atec23_amd import distributed as D
+    n = 2 ** 24 + 1
+    a = torch.zeros(n)
+    a[-1] = 7.0
+    all_logits, all_a = D.gather_slide_outputs([1, 0], [torch.tensor([1.0, 2.0]), torch.tensor([3.0, 4.0])], [a, torch.arange(3.0)], 2)
+    assert all_a[1].numel() == n and float(all_a[1][-1]) == 7.0 and all_a[0].tolist() == [0.0, 1.0, 2.0]
+    assert all_logits.tolist() == [[3.0, 4.0], [1.0, 2.0]]

@@ -103,6 +103,37 @@ def test_process_slides_sampling_skip_existing_and_coords(tmp_path):
     assert len(sl) == 64 and all(7168 <= s.n_regions <= 8192 for s in sl) and len({s.n_regions for s in sl}) > 1
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_dry_run_two_ranks(launcher):
+    """bench.py's multi-rank leg rehearsed without a GPU (--dry-run: gloo, CPU tensors, stand-in models): spawn_ranks (or the
+    driver's own `python -m torch.distributed.run ...` form) -> init_from_env -> barriers + timed loop -> config 5 over 64
+    slides -> the all-gather -> ONE JSON line from rank 0.  The first contact of that code path with more than one rank must
+    not be the 8-GPU node."""
+    import json
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    tail = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"]
+    if launcher == "self":
+        cmd = [sys.executable, bench] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), bench] + tail
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 alone reports
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config5"]["slides"] == 64 and d["config5"]["gathered_logits_shape"] == [64, 2]
+    assert d["config5"]["gathered_a_raw_total"] == sum(s.n_regions for s in __import__("hipt_abmil_atec23_amd.pipeline", fromlist=["x"]).synthetic_slides(64, 8192))
+    # a job with another world size than asked for refuses to report
+    bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), bench, "--gpus", "4", "--dry-run", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert bad.returncode != 0 and not any(l.startswith("{") for l in bad.stdout.splitlines())
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # GPU: the real models
 # ---------------------------------------------------------------------------------------------------------------------
