@@ -49,7 +49,7 @@ class ClamWeights(C.Structure):
                 ("n_classes", C.c_int32), ("reserved", C.c_int32),
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("wab", C.c_void_p), ("bab", C.c_void_p),
                 ("wc", C.c_void_p), ("bc", C.c_void_p), ("wcls", C.c_void_p), ("bcls", C.c_void_p),
-                ("logit_bound", C.c_float), ("reserved2", C.c_int32)]
+                ("logit_bound", C.c_float), ("reserved2", C.c_int32), ("stream_pk", C.c_void_p)]
 
 
 class ClamTrainWeights(C.Structure):
@@ -102,6 +102,8 @@ SIGNATURES = {
     "hipt_hipt4k_forward_u8": (_i, [_VW, _VW, _p, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "hipt_u8_normalize": (_i, [_p, _i, C.c_int64, C.c_int64, _p, _i, _p]),
     "hipt_clam_workspace_bytes": (_sz, [_CW, _i]),
+    "hipt_clam_stream_packed_bytes": (_sz, [_CW]),
+    "hipt_clam_stream_pack": (_i, [_CW, _p, _p]),
     "hipt_clam_ticket_offset": (_sz, [_CW, _i]),
     "hipt_clam_sb_forward": (_i, [_CW, _p, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "hipt_attn_net_gated": (_i, [_CW, _p, _i, _p, _p, _sz, _p]),

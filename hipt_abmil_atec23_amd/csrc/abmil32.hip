@@ -1,0 +1,641 @@
+// CLAM_SB / ABMIL gated-attention pooling, bf16 hot configuration [S0, 128, 64] (S0 = 384: the BASELINE bag; 192: the slide
+// aggregator over HIPT_4K's region features), streaming form on 32x32x16 MFMAs
+// (models/model_clam.py:41-64, 83-92, 147-183; same math as abmil.hip, which remains the general kernel).
+//
+// HBM-bound design: the 100 000 x 384 bf16 bag (76.8 MB) is read exactly once; nothing else moves.
+//   * one 4-wave workgroup per CU (one wave per SIMD, the whole register file each); the weights are staged ONCE per workgroup
+//     into LDS as MFMA A-operand fragments of 1 KiB (W1: [k-step][hidden tile]; [Wa;Wb]: [k-step][gate tile], its k order
+//     permuted to the accumulator-as-operand order of the h1 tiles);
+//   * a WAVE owns 32-row blocks end to end (block b -> wave b mod #waves): no barrier, no LDS exchange in steady state.  The
+//     32 rows of a block are ONE B operand of v_mfma_f32_32x32x16_bf16 (row on the lane), loaded HBM -> registers in operand
+//     layout, re-loaded in place for the next block as soon as a k-step has used its chunk (a range-checked buffer: rows past
+//     the bag read as zero, no traffic);
+//   * h1^T = W1 x^T + b1 (4 hidden tiles x KS k-steps), ReLU, packed IN PLACE as the B operand of the gate product
+//     [a;b]^T = [Wa;Wb] h1^T (accumulator-as-operand: no data movement); the gate tiles hold a_j and b_j of a row in the same
+//     lane, so tanh * sigmoid * wc is lane-local and a row's logit is one cross-half add;
+//   * softmax pooling WITHOUT a running maximum: |A - bc| <= sum |wc| =: B because tanh * sigmoid lies in (-1, 1), so every
+//     exponent is taken against the FIXED shift bc, the centre of the interval the logits can lie in: p = e^(A - bc) lies in
+//     [e^-B, e^B], and for B < 60 neither p nor sum p (N < 2^22 rows) nor sum p h1 can leave fp32's range (e^88).  The caller
+//     supplies B (hipt_clam_weights.logit_bound); larger / unknown bounds take the general kernel.  No rescale of the pooled
+//     sums per step, and the cross-workgroup merge is a plain sum of (sum p, sum p h1[128]);
+//   * software pipeline: the gate arithmetic and the pooling of block s-1 are dealt out under the 96 phase-1 MFMAs of block s;
+//   * the last workgroup to finish (arrival ticket, sc1 hand-off) adds the partials in a fixed order and applies the bag
+//     classifier, softmax and argmax: one launch, deterministic bits.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+#include "pipe_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int S1 = 128, S2 = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int PSTRIDE = 2 + S1;  // floats per workgroup partial: (shift = 0, sum p, acc[128]) -- the layout hipt_clam_combine_launch reads
+
+__device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// 16 bytes at an 8-byte-aligned offset through a buffer resource, sc1 (bypasses the L1: see the fused combine)
+__device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, int off) {
+    const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 16), hi = __builtin_amdgcn_raw_buffer_load_b64(r, off + 8, 0, 16);
+    const f32x2 l = __builtin_bit_cast(f32x2, lo), h = __builtin_bit_cast(f32x2, hi);
+    return f32x4{l[0], l[1], h[0], h[1]};
+}
+// sum over the 64 lanes without the LDS crossbar (ds_bpermute costs ~100 cycles a step, six dependent steps): quads and 16-lane rows by
+// DPP, the four row sums by readlane; every lane gets the result; a fixed order, like wave_sum's
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+    DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    DPP_ADD(0x124);  // row_ror:4
+    DPP_ADD(0x128);  // row_ror:8
+#undef DPP_ADD
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+// column of accumulator register i in lane half hh of a 32 x 32 tile
+__host__ __device__ __forceinline__ int acc_col(int i, int hh) { return (i & 3) + 8 * (i >> 2) + 4 * hh; }
+// row of the stacked [Wa; Wb] matrix that gate tile t holds in its A-operand row c: tiles a[0:32] b[0:32] a[32:64] b[32:64]
+__host__ __device__ __forceinline__ int gate_row(int t, int c) { return (t & 1) * S2 + (t >> 1) * 32 + c; }
+
+// The weight image = the kernel's LDS content: W1 fragments (k-step, hidden tile) of 1 KiB | [Wa;Wb] fragments (k-step, gate tile) |
+// b1 [4 tiles][2 lane halves][16] and the gate bias likewise (1 KiB) | wc [2 tile pairs][2][16] (256 B) | padding to 4 KiB
+__host__ __device__ constexpr int off_wab(int KS) { return 4 * KS * 1024; }
+__host__ __device__ constexpr int off_cst(int KS) { return off_wab(KS) + 32 * 1024; }
+__host__ __device__ constexpr int image_bytes(int KS) { return off_cst(KS) + 4096; }
+
+// LDS-DMA as inline asm: 16 bytes per lane to (wave-uniform LDS address in M0) + 16 lane.  hipcc must not know of these loads: with its
+// own builtin in flight it opens every step of the main loop with s_waitcnt vmcnt(0) (all 24 chunks of a block) instead of the counted
+// per-chunk waits.  They are OLDER than every load the compiler counts (loads retire in order), so its counts stay right.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_wave_base) : "memory");  // (M0 is reserved: hipcc neither allocates it nor, in this kernel, uses it for anything else)
+}
+
+// one thread per 16 bytes of the image
+__global__ void abmil32_pack_kernel(const bf16_t* __restrict__ w1, const float* __restrict__ b1, const bf16_t* __restrict__ wab,
+                                    const float* __restrict__ bab, const float* __restrict__ wc, int KS, char* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S0 = 16 * KS, nw1 = off_wab(KS) / 16, ng = 32 * 64, total = image_bytes(KS) / 16;
+    if (c >= total) return;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (c < nw1) {
+        // W1 fragment (k, T) at (4 k + T) KiB: lane (r, hh) <- W1[32 T + r][16 k + 8 hh ..+7] (A operand of v_mfma_f32_32x32x16_bf16)
+        const int frag = c >> 6, lane = c & 63, k = frag >> 2, T = frag & 3, r = lane & 31, hh = lane >> 5;
+        v = *(const u32x4*)(w1 + (int64_t)(32 * T + r) * S0 + 16 * k + 8 * hh);
+    } else if (c < nw1 + ng) {
+        // [Wa;Wb] fragment (kk, t): k-step kk = 2 T' + s' of hidden tile T'; lane (r, hh) element j <- hidden 16 kk + 8 (j >> 2) + 4 hh + (j & 3),
+        // the order in which pack8<s'> of the h1 accumulator tile T' feeds its k slots
+        const int c2 = c - nw1, frag = c2 >> 6, lane = c2 & 63, kk = frag >> 2, t = frag & 3, r = lane & 31, hh = lane >> 5;
+        const bf16_t* src = wab + (int64_t)gate_row(t, r) * S1 + 16 * kk + 4 * hh;
+        const u32x2 lo = *(const u32x2*)src, hi = *(const u32x2*)(src + 8);
+        v = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    } else {
+        const int f0 = (c - nw1 - ng) * 4;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f = f0 + e, T = (f >> 5) & 3, hb = (f >> 4) & 1, i = f & 15;
+            if (f < 128) o[e] = b1[32 * T + acc_col(i, hb)];
+            else if (f < 256) o[e] = bab[gate_row(T, acc_col(i, hb))];
+            else if (f < 320) o[e] = wc[32 * (T & 1) + acc_col(i, hb)];
+        }
+        v = __builtin_bit_cast(u32x4, o);
+    }
+    *(u32x4*)(out + (int64_t)c * 16) = v;
+}
+
+template <int S>
+__device__ __forceinline__ u32x4 pack8(const f32x16& a) {
+    u32x4 o;
+    o[0] = pack_bf16x2(a[8 * S + 0], a[8 * S + 1]);
+    o[1] = pack_bf16x2(a[8 * S + 2], a[8 * S + 3]);
+    o[2] = pack_bf16x2(a[8 * S + 4], a[8 * S + 5]);
+    o[3] = pack_bf16x2(a[8 * S + 6], a[8 * S + 7]);
+    return o;
+}
+
+// tanh(x) * sigmoid(y) * w with ONE reciprocal: (E - 1) w / ((E + 1)(1 + F)), E = e^{2x}, F = e^{-y}; x clamped to +-15
+// (contraction off: a row's logit must be the same bits wherever the row sits -- pipelined step, drain, any block)
+__device__ __forceinline__ float gate_term(float x, float y, float w) {
+#pragma clang fp contract(off)
+    const float xs = __builtin_amdgcn_fmed3f(x, -15.0f, 15.0f) * (2.0f * LOG2E);
+    const float ys = y * -LOG2E;
+    const float E = __builtin_amdgcn_exp2f(xs), F = __builtin_amdgcn_exp2f(ys);
+    const float num = (E - 1.0f) * w, den = (E + 1.0f) * (F + 1.0f);
+    return num * __builtin_amdgcn_rcpf(den);
+}
+
+struct Abmil32Params {
+    const bf16_t* bag;
+    int N, nblocks, nwaves;
+    const char* image;  // the LDS image of the weights (abmil32_pack_kernel)
+    const float* bc;
+    float* A_raw;
+    float* partials;
+    int attention_only;
+    unsigned* ticket;
+    const float* wcls;
+    const float* bcls;
+    int C;
+    float* M;
+    float* logits;
+    float* Y_prob;
+    int64_t* Y_hat;
+    unsigned long long* stamps;  // diagnostic builds: [grid][24] s_memrealtime ticks (100 MHz) of wave 0
+};
+
+template <int KS>  // k-steps of 16 input features: S0 = 16 KS
+__global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) {
+    constexpr int S0 = 16 * KS;
+    constexpr int OFF_WAB = off_wab(KS), OFF_CST = off_cst(KS), IMG_BYTES = image_bytes(KS);
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // W1 fragments | [Wa;Wb] fragments | b1, gate bias, wc in accumulator order
+
+    const int tid = threadIdx.x, lane = tid & 63;
+#define ASTAMP(k)                                                                                                                       \
+    do {                                                                                                                                \
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+    ASTAMP(0);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int gw = blockIdx.x * 4 + w;                                  // this wave; its blocks: gw, gw + nwaves, ..
+    const int nstep = gw < p.nblocks ? (p.nblocks - gw + p.nwaves - 1) / p.nwaves : 0;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.bag, 0, (int)((int64_t)p.N * S0 * 2), 0x00020000);
+    constexpr int OOR = 0x7fff0000;                                     // (beyond any bag the launcher accepts)
+    const int vrow = r * (S0 * 2) + hh * 16;                            // lane (r, hh): row r of a block, 16-byte chunk 2 k + hh
+
+    // ---- stage the weights: the image is the LDS content byte for byte, 1 KiB per LDS-DMA wave instruction ----
+    {
+        constexpr int PER_WAVE = IMG_BYTES / 4096;  // KiB per wave
+        const char* src = p.image + (w * PER_WAVE) * 1024 + lane * 16;
+        char* dst = smem + (w * PER_WAVE) * 1024;
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) glds16_asm(src + j * 1024, lds_addr(dst) + j * 1024);
+    }
+    // this wave's first block: requested behind the image, so that "all but the youngest KS" below means "the image has landed"
+    // (the bag through a buffer resource that ends with it: a chunk of a row past the end reads as zero, no traffic)
+    // A block's chunks live in two register sets: the lower half of the k-steps in xlo, re-requested IN PLACE for the next block as
+    // soon as its k-step is done (first half of phase 1); the upper half alternately in xa / xb, the idle one of which is filled
+    // for the next block during the gate product and the gate arithmetic.  The 24 requests of a block are thus spread over the
+    // whole step: issued in one burst they hold the CU's address unit for longer than phase 1 lasts, and the waves stall on issue.
+    constexpr int KH = KS / 2;
+    u32x4 xlo[KH], xa[KH], xb[KH];
+    {
+        const int v0 = nstep > 0 ? gw * 32 * S0 * 2 + vrow : OOR;  // (no block: out of range, zeros)
+#pragma unroll
+        for (int k = 0; k < KH; ++k) xlo[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + k * 32, 0, 0);
+#pragma unroll
+        for (int k = 0; k < KH; ++k) xa[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + (KH + k) * 32, 0, 0);
+    }
+    // s_waitcnt vmcnt(KS) as the builtin (vmcnt = bits 15:14 | 3:0; expcnt, lgkmcnt: no wait): hipcc's own wait-count bookkeeping sees
+    // it -- behind an opaque asm wait it would take every load as still in flight and open each step with vmcnt(0)
+    __builtin_amdgcn_s_waitcnt(((KS >> 4) << 14) | 0x0F70 | (KS & 15));
+    ASTAMP(1);
+    __builtin_amdgcn_s_barrier();  // (raw: __syncthreads() would wait for the first block's loads too)  weights are in LDS; from here on the waves never synchronise again (until the merge)
+
+    const uint32_t lbase = lds_addr(smem);
+    const uint32_t fa = lbase + lane * 16;
+    const uint32_t fb = fa + (KS > 12 ? 48 * 1024 : 0);   // (ds offsets are 16-bit: W1 fragments beyond 48 KiB through a second base)
+    const uint32_t fg = fa + OFF_WAB;
+    const uint32_t cb1 = lbase + OFF_CST + hh * 64, cgb = cb1 + 512;
+    // wc of this lane's 32 gate pairs, in pair order (tile pair tp, register i): kept in registers
+    // (through asm reads: a visible LDS access makes hipcc wait for every load in flight, the first block's included)
+    float wcr[32];
+#pragma unroll
+    for (int q4 = 0; q4 < 8; ++q4) {
+        const f32x4 v = lds_ld128(lbase + OFF_CST + 1024 + (((q4 >> 2) * 2 + hh) * 16 + (q4 & 3) * 4) * 4);
+        wcr[4 * q4] = v[0];
+        wcr[4 * q4 + 1] = v[1];
+        wcr[4 * q4 + 2] = v[2];
+        wcr[4 * q4 + 3] = v[3];
+    }
+    const float bcv = p.bc[0];
+
+    f32x16 pool[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) pool[T] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+    f32x16 HA[4], G[4];
+    u32x4 hf[8];
+    float gs = 0.f, prow = 0.f;
+
+    // one gate pair of the block being gated: q = 16 tp + i -> a = G[2 tp][i], b = G[2 tp + 1][i] (biases already in)
+    auto gate_q = [&](auto Q_) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+        constexpr int q = decltype(Q_)::value, tp = q >> 4, i = q & 15;
+        const float t = gate_term(G[2 * tp][i], G[2 * tp + 1][i], wcr[q]);
+        if constexpr (q == 0) gs = t;
+        else gs = gs + t;
+    };
+    // the row's logit (lane halves hold the two halves of its gate units), A_raw, softmax weight against the fixed shift
+    auto gate_finish = [&](int blk) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+        const float g2 = gs + __shfl_xor(gs, 32, 64);   // (the same bits in both halves: the pooling of either half uses prow)
+        const int row = blk * 32 + r;
+        const bool valid = row < p.N;
+        if (valid && hh == 0) p.A_raw[row] = g2 + bcv;
+        prow = valid ? __builtin_amdgcn_exp2f(g2 * LOG2E) : 0.f;  // e^(A - bc), in [e^-B, e^B]
+        if (hh == 0) lsum += prow;
+    };
+    auto pool_tile = [&](auto T_, auto Hh_, f32x16 (&Hp)[4]) __attribute__((always_inline)) {  // half a tile: 8 registers
+        constexpr int T = decltype(T_)::value, h8 = decltype(Hh_)::value;
+#pragma unroll
+        for (int i = 8 * h8; i < 8 * h8 + 8; ++i) pool[T][i] = __builtin_fmaf(prow, Hp[T][i], pool[T][i]);
+    };
+
+    // request j of the next block's upper half (byte offset vnext of the lane's row) into the idle set
+    auto load_hi = [&](auto J_, u32x4 (&xn)[KH], int vnext) __attribute__((always_inline)) {
+        constexpr int j = decltype(J_)::value;
+        xn[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, vnext + (KH + j) * 32, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr int NL2 = KH / 3, NLG = KH - NL2;  // requests placed in the gate product / between the gate pairs
+
+    // phase 1: H = b1 + W1 x^T over KS k-steps x 4 hidden tiles; a k-step of the lower half that is done with its chunk requests the next block's
+    auto phase1 = [&](f32x16 (&H)[4], u32x4 (&xhi)[KH], int vnext) __attribute__((always_inline)) {
+        {   // H = b1 (accumulator order: 16 floats per (tile, lane half))
+            const uint32_t a = cb1;
+            sfor<0, 4>([&](auto T_) __attribute__((always_inline)) {
+                constexpr int T = decltype(T_)::value;
+                f32x4 v0, v1, v2, v3;
+                const uint32_t a2 = a;
+                DSR128X4_WAIT(v0, v1, v2, v3, a2, T * 128, T * 128 + 16, T * 128 + 32, T * 128 + 48);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    H[T][i] = v0[i];
+                    H[T][4 + i] = v1[i];
+                    H[T][8 + i] = v2[i];
+                    H[T][12 + i] = v3[i];
+                }
+            });
+        }
+        u32x4 wfr[8];
+        constexpr int NSL = 4 * KS, PFD = 5;  // MFMA slots (k, T); fragments requested ahead
+        auto rd = [&](auto G_) __attribute__((always_inline)) {
+            constexpr int g = decltype(G_)::value;  // slot g = 4 k + T = the fragment's KiB index
+            u32x4& d = wfr[g & 7];
+            if constexpr (g < 48) {
+                const uint32_t a = fa;
+                DSR128(d, a, g * 1024);
+            } else {
+                const uint32_t a = fb;
+                DSR128(d, a, (g - 48) * 1024);
+            }
+        };
+        sfor<0, PFD>([&](auto G_) __attribute__((always_inline)) { rd(G_); });
+        sfor<0, NSL>([&](auto G_) __attribute__((always_inline)) {
+            constexpr int g = decltype(G_)::value, k = g >> 2, T = g & 3;
+            if constexpr (g + PFD < NSL) {
+                rd(std::integral_constant<int, g + PFD>{});
+                LGKM(PFD);
+            } else {
+                LGKM(NSL - 1 - g);
+            }
+            if constexpr (k < KH) {
+                H[T] = mfma32(wfr[g & 7], xlo[k], H[T]);
+                if constexpr (T == 3) xlo[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, vnext + k * 32, 0, 0);
+            } else {
+                H[T] = mfma32(wfr[g & 7], xhi[k - KH], H[T]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // h1 = ReLU(H) in place (fp32, for the pooling one block later) and as the B operand of the gate product
+    auto relu_pack = [&](f32x16 (&H)[4]) __attribute__((always_inline)) {
+        sfor<0, 4>([&](auto T_) __attribute__((always_inline)) {
+            constexpr int T = decltype(T_)::value;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) H[T][i] = fmaxf(H[T][i], 0.f);
+            hf[2 * T] = pack8<0>(H[T]);
+            hf[2 * T + 1] = pack8<1>(H[T]);
+        });
+    };
+
+    // phase 2: G = gate bias + [Wa;Wb] h1^T: 8 k-steps x 4 gate tiles
+    auto phase2 = [&](u32x4 (&xn)[KH], int vnext) __attribute__((always_inline)) {
+        {
+            const uint32_t a = cgb;
+            sfor<0, 4>([&](auto T_) __attribute__((always_inline)) {
+                constexpr int T = decltype(T_)::value;
+                f32x4 v0, v1, v2, v3;
+                const uint32_t a2 = a;
+                DSR128X4_WAIT(v0, v1, v2, v3, a2, T * 128, T * 128 + 16, T * 128 + 32, T * 128 + 48);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    G[T][i] = v0[i];
+                    G[T][4 + i] = v1[i];
+                    G[T][8 + i] = v2[i];
+                    G[T][12 + i] = v3[i];
+                }
+            });
+        }
+        u32x4 wfr[8];
+        constexpr int PFD = 5;
+        auto rd = [&](auto G_) __attribute__((always_inline)) {
+            constexpr int g = decltype(G_)::value;  // slot g = 4 kk + t
+            u32x4& d = wfr[g & 7];
+            const uint32_t a = fg;
+            DSR128(d, a, g * 1024);
+        };
+        sfor<0, PFD>([&](auto G_) __attribute__((always_inline)) { rd(G_); });
+        sfor<0, 32>([&](auto G_) __attribute__((always_inline)) {
+            constexpr int g = decltype(G_)::value, kk = g >> 2, t = g & 3;
+            if constexpr (g + PFD < 32) {
+                rd(std::integral_constant<int, g + PFD>{});
+                LGKM(PFD);
+            } else {
+                LGKM(31 - g);
+            }
+            G[t] = mfma32(wfr[g & 7], hf[kk], G[t]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (g % (32 / NL2) == 0) load_hi(std::integral_constant<int, g / (32 / NL2)>{}, xn, vnext);
+        });
+    };
+
+    // gate arithmetic, logit, softmax weight and pooling of the block
+    auto gate_pool = [&](f32x16 (&Hp)[4], int blk, u32x4 (&xn)[KH], int vnext) __attribute__((always_inline)) {
+        sfor<0, 32>([&](auto Q_) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q_)::value;
+            gate_q(Q_);
+            if constexpr (q % (32 / NLG) == 0) load_hi(std::integral_constant<int, NL2 + q / (32 / NLG)>{}, xn, vnext);
+        });
+        gate_finish(blk);
+        sfor<0, 8>([&](auto HH_) __attribute__((always_inline)) {
+            constexpr int ht = decltype(HH_)::value;
+            pool_tile(std::integral_constant<int, (ht >> 1)>{}, std::integral_constant<int, (ht & 1)>{}, Hp);
+        });
+    };
+
+    // one block: its upper half is in xr; the next block's goes to xn
+    auto step = [&](int s, u32x4 (&xr)[KH], u32x4 (&xn)[KH]) __attribute__((always_inline)) {
+        const int blk = gw + s * p.nwaves;
+        const int vnext = s + 1 < nstep ? (blk + p.nwaves) * 32 * S0 * 2 + vrow : OOR;
+        phase1(HA, xr, vnext);
+        if (s < 4) ASTAMP(3 + 3 * s);
+        relu_pack(HA);
+        phase2(xn, vnext);
+        if (s < 4) ASTAMP(4 + 3 * s);
+        gate_pool(HA, blk, xn, vnext);
+        if (s < 4) ASTAMP(5 + 3 * s);
+    };
+    ASTAMP(2);
+    {
+        int s = 0;
+        for (; s + 1 < nstep; s += 2) {
+            step(s, xa, xb);
+            step(s + 1, xb, xa);
+        }
+        if (s < nstep) step(s, xa, xb);
+    }
+    ASTAMP(15);
+    if (p.attention_only) return;
+
+    // ---- this workgroup's partial: sum over the rows (= lanes) of every wave, then over the 4 waves, through LDS (weights are dead) ----
+    __syncthreads();
+    constexpr int RS = S1 + 4;   // row stride in floats: 16 bytes of padding, or the 32 lanes of a store all hit the same banks
+    float* red = (float*)smem;  // [4 waves][32 rows][RS] fp32 = 66 KiB | lsum [4][32] behind it
+    {
+        float* dst = red + ((w * 32 + r) * RS);
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)  // registers 4 q ..+3 = hidden 32 T + 8 q + 4 hh ..+3
+                *(f32x4*)(dst + 32 * T + 8 * q + 4 * hh) = f32x4{pool[T][4 * q], pool[T][4 * q + 1], pool[T][4 * q + 2], pool[T][4 * q + 3]};
+        if (hh == 0) red[4 * 32 * RS + w * 32 + r] = lsum;
+    }
+    __syncthreads();
+    float* pw = p.partials + (int64_t)blockIdx.x * PSTRIDE;
+    {
+        // thread (half, col): rows [64 half, 64 half + 64) of column col, in row order; the two halves are added by half 0
+        const int col = tid & 127, half = tid >> 7;
+        float a = 0.f;
+#pragma unroll 16
+        for (int j = 0; j < 64; ++j) a += red[(half * 64 + j) * RS + col];
+        float l2 = 0.f;
+        if (col < 64) l2 = red[4 * 32 * RS + half * 64 + col];
+        l2 = wave_sum_dpp(l2);  // (waves 0, 1: half 0; waves 2, 3: half 1; only the waves with col < 64 hold values)
+        __syncthreads();
+        float* ex = red;  // exchange: [2][128] column sums, [4] wave sums of l
+        ex[half * S1 + col] = a;
+        if (lane == 0) ex[256 + w] = l2;
+        __syncthreads();
+        // (agent-scope relaxed stores = sc1 stores: they leave the XCD's L2, the merging workgroup reads them with sc1 loads and no fence)
+        if (tid < S1) __hip_atomic_store(&pw[2 + tid], ex[tid] + ex[S1 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(&pw[0], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every partial against the same shift
+            __hip_atomic_store(&pw[1], (ex[256] + ex[257]) + (ex[258] + ex[259]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- fused combine (model_clam.py:180-183): the workgroup whose ticket is the last one adds all partials in a fixed order,
+    //      applies the bag classifier, softmax and argmax.  Hand-off without fences (MI355X_MICROARCH.md, hand-off table row 1): sc1 stores,
+    //      every storing wave waits vmcnt(0), workgroup barrier, ONE agent-scope atomic per workgroup; the workgroup whose add came
+    //      last reads with sc1 loads after a workgroup barrier.  The ticket starts at zero and the last arriver puts it back.
+    if (!p.ticket) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ASTAMP(16);
+    __syncthreads();
+    int* flag = (int*)(red + 512);
+    if (tid == 0) {
+        const bool last = atomicAdd(p.ticket, 1u) == gridDim.x - 1;
+        *flag = last;
+        if (last) __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    ASTAMP(17);
+    if (!*flag) return;
+    {
+        const int Gn = gridDim.x;
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)p.partials, 0, Gn * PSTRIDE * 4, 0x00020000);
+        constexpr int SC1 = 16;
+        // 32 threads x 16 B cover the 128 sums of one partial, 8 partials per pass; all of a thread's share is requested at once
+        // (rows past Gn are out of the buffer's range and read as zero); summed in partial order: deterministic
+        const int c4 = tid & 31, part = tid >> 5;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        f32x4 rowv[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) rowv[i] = ld4(prs, ((part + 8 * i) * PSTRIDE + 2 + 4 * c4) * 4);  // (rows 520 B apart: 8-byte aligned)
+        // the classifier rows this wave will need (classes w, w + 4): requested now, with the partials -- one round trip, not two
+        const int k0 = w, k1 = w + 4;
+        const float wc0a = k0 < p.C ? p.wcls[(int64_t)k0 * S1 + lane] : 0.f, wc0b = k0 < p.C ? p.wcls[(int64_t)k0 * S1 + lane + 64] : 0.f;
+        const float wc1a = k1 < p.C ? p.wcls[(int64_t)k1 * S1 + lane] : 0.f, wc1b = k1 < p.C ? p.wcls[(int64_t)k1 * S1 + lane + 64] : 0.f;
+        float lv = tid < Gn ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, tid * PSTRIDE * 4 + 4, 0, SC1)) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a += rowv[i];
+        ASTAMP(18);
+        float* Cs = red + 1024;   // [8][128] column partial sums
+        float* Ms = red + 2048;   // [128]
+        float* Ls = red + 2176;   // [C <= 64]
+        float* wr = red + 2240;   // [4] wave sums of l
+        *(f32x4*)(Cs + part * S1 + 4 * c4) = a;
+        lv = wave_sum_dpp(lv);
+        if (lane == 0) wr[w] = lv;
+        __syncthreads();
+        const float L = (wr[0] + wr[1]) + (wr[2] + wr[3]);
+        if (tid < S1) {
+            float m = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m += Cs[q * S1 + tid];
+            m /= L;
+            Ms[tid] = m;
+            p.M[tid] = m;
+        }
+        __syncthreads();
+        ASTAMP(19);
+        for (int k = w; k < p.C; k += 4) {
+            const float wa = k == k0 ? wc0a : k == k1 ? wc1a : p.wcls[(int64_t)k * S1 + lane];
+            const float wb = k == k0 ? wc0b : k == k1 ? wc1b : p.wcls[(int64_t)k * S1 + lane + 64];
+            float v = Ms[lane] * wa + Ms[lane + 64] * wb;
+            v = wave_sum_dpp(v);
+            if (lane == 0) Ls[k] = v + p.bcls[k];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float lm = -INFINITY;
+            int arg = 0;
+            for (int k = 0; k < p.C; ++k)
+                if (Ls[k] > lm) {
+                    lm = Ls[k];
+                    arg = k;
+                }
+            float se = 0.f;
+            for (int k = 0; k < p.C; ++k) se += expf(Ls[k] - lm);
+            for (int k = 0; k < p.C; ++k) {
+                p.logits[k] = Ls[k];
+                p.Y_prob[k] = expf(Ls[k] - lm) / se;
+            }
+            p.Y_hat[0] = arg;
+        }
+        ASTAMP(20);
+    }
+}
+
+template <int KS>
+int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, float* partials, int* n_partials,
+           unsigned* ticket, float* M, float* logits, float* Y_prob, int64_t* Y_hat, hipStream_t st) {
+    constexpr int lds = image_bytes(KS);
+    constexpr int lds_alloc = lds > 72 * 1024 ? lds : 72 * 1024;  // (the reduction at the end uses 66.5 KiB of it)
+    auto k = abmil32_kernel<KS>;
+    static DevOnce once;
+    HIPT_CUR_DEVICE(dev);
+    if (!once.done[dev]) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_alloc) != hipSuccess) {
+            hipt_set_error("hipFuncSetAttribute(abmil32) failed");
+            return HIPT_E_LAUNCH;
+        }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            hipt_set_error("abmil32: cannot query the device");
+            return HIPT_E_LAUNCH;
+        }
+        once.ncu[dev] = prop.multiProcessorCount;
+        once.done[dev] = true;
+    }
+    Abmil32Params p;
+    p.bag = (const bf16_t*)bag;
+    p.N = N;
+    p.nblocks = (N + 31) / 32;
+    // every wave the same number of blocks (+-1): 100 000 rows are 3125 blocks = 4 rounds of 782 waves (196 workgroups), not 3 rounds
+    // of 1024 and a fourth of 53 -- the time is the slowest wave's either way, and the even spread asks less of the HBM per round
+    const int maxg = once.ncu[dev] < 256 ? once.ncu[dev] : 256;  // (the merge reads up to 256 partials in one round trip)
+    const int rounds = (p.nblocks + 4 * maxg - 1) / (4 * maxg);
+    const int grid = ((p.nblocks + rounds - 1) / rounds + 3) / 4;
+    p.nwaves = grid * 4;
+    p.image = (const char*)w->stream_pk;
+    p.bc = w->bc;
+    p.A_raw = A_raw;
+    p.partials = partials;
+    p.attention_only = attention_only;
+    const bool fuse = !attention_only && ticket && M && w->n_classes <= 64;
+    p.ticket = fuse ? ticket : nullptr;
+    p.wcls = w->wcls;
+    p.bcls = w->bcls;
+    p.C = w->n_classes;
+    p.M = M;
+    p.logits = logits;
+    p.Y_prob = Y_prob;
+    p.Y_hat = Y_hat;
+    p.stamps = nullptr;
+#ifdef HIPT_DEBUG_STAMPS  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
+    static const bool want_stamps = getenv("HIPT_ABMIL_STAMPS") != nullptr;
+    static unsigned long long* dbuf = nullptr;
+    if (want_stamps && !dbuf) (void)hipMalloc(&dbuf, 256 * 24 * sizeof(unsigned long long));
+    if (want_stamps) {
+        (void)hipMemsetAsync(dbuf, 0, 256 * 24 * sizeof(unsigned long long), st);
+        p.stamps = dbuf;
+    }
+#endif
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_alloc, st, p);
+    HIPT_CHECK_LAUNCH();
+#ifdef HIPT_DEBUG_STAMPS
+    if (want_stamps) {
+        static unsigned long long h[256 * 24];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, dbuf, (size_t)grid * 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < grid; ++b)
+            if (h[b * 24] < t0) t0 = h[b * 24];
+        // per stamp: mean and maximum over the workgroups of (stamp - earliest start), us
+        fprintf(stderr, "[abmil32 N=%d grid=%d] stamp: mean / max us since the first workgroup started (0 start, 1 weights staged, 2 loop, 3+3s phase 1, 4+3s gate GEMM, 5+3s gate+pool, 15 loop end, 16 partial stored, 17 ticket taken; last workgroup: 18 partials read, 19 M, 20 done)\n", N, grid);
+        for (int k2 = 0; k2 < 24; ++k2) {
+            double sum = 0, mx = 0;
+            int n = 0;
+            for (int b = 0; b < grid; ++b) {
+                if (!h[b * 24 + k2]) continue;
+                const double d = (double)(h[b * 24 + k2] - t0) * 0.01;
+                sum += d;
+                mx = d > mx ? d : mx;
+                ++n;
+            }
+            if (n) fprintf(stderr, "   %2d: %7.2f / %7.2f  (%d workgroups)\n", k2, sum / n, mx, n);
+        }
+    }
+#endif
+    *n_partials = fuse ? 0 : grid;  // 0: the kernel has already produced M / logits / Y_prob / Y_hat
+    return HIPT_OK;
+}
+
+}  // namespace
+
+// bf16 [384 | 192, 128, 64] with a usable logit bound: e^B times the row count times |h1| must stay inside fp32's range
+bool hipt_clam_stream_supported(const hipt_clam_weights* w) {
+    return w->dtype == HIPT_BF16 && w->s1 == S1 && w->s2 == S2 && (w->s0 == 384 || w->s0 == 192) && w->stream_pk && w->logit_bound > 0.f &&
+           w->logit_bound < 60.f && !hipt_generic_only();
+}
+
+size_t hipt_clam_stream_image_bytes(const hipt_clam_weights* w) {
+    if (w->dtype != HIPT_BF16 || w->s1 != S1 || w->s2 != S2 || (w->s0 != 384 && w->s0 != 192)) return 0;
+    return (size_t)image_bytes(w->s0 / 16);
+}
+
+int hipt_clam_stream_pack_launch(const hipt_clam_weights* w, void* out, hipStream_t st) {
+    const size_t nb = hipt_clam_stream_image_bytes(w);
+    if (!nb) {
+        hipt_set_error("clam stream pack: no image for dtype %d [%d,%d,%d]", w->dtype, w->s0, w->s1, w->s2);
+        return HIPT_E_UNSUPPORTED;
+    }
+    HIPT_CHECK_ARG(w->w1 && w->b1 && w->wab && w->bab && w->wc && out && ((uintptr_t)out & 15) == 0, "clam stream pack: null / unaligned pointer");
+    const int n = (int)(nb / 16);
+    hipLaunchKernelGGL(abmil32_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const bf16_t*)w->w1, w->b1, (const bf16_t*)w->wab, w->bab,
+                       w->wc, w->s0 / 16, (char*)out);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}
+
+int hipt_clam_stream_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, float* partials, int* n_partials,
+                            unsigned* ticket, float* M, float* logits, float* Y_prob, int64_t* Y_hat, hipStream_t st) {
+    HIPT_CHECK_ARG((int64_t)N * w->s0 * 2 < (int64_t)0x7fff0000, "clam stream: bag beyond 2 GiB");
+    if (w->s0 == 384) return launch<24>(w, bag, N, attention_only, A_raw, partials, n_partials, ticket, M, logits, Y_prob, Y_hat, st);
+    if (w->s0 == 192) return launch<12>(w, bag, N, attention_only, A_raw, partials, n_partials, ticket, M, logits, Y_prob, Y_hat, st);
+    hipt_set_error("clam stream: unsupported S0=%d", w->s0);
+    return HIPT_E_UNSUPPORTED;
+}

@@ -922,6 +922,13 @@ size_t hipt_clam_workspace_bytes(const hipt_clam_weights* w, int N) {
            al256((size_t)N * w->s1 * 2);
 }
 
+size_t hipt_clam_stream_packed_bytes(const hipt_clam_weights* w) { return w ? hipt_clam_stream_image_bytes(w) : 0; }
+
+int hipt_clam_stream_pack(const hipt_clam_weights* w, void* out, void* stream) {
+    HIPT_CHECK_ARG(w != nullptr, "clam_stream_pack: null weights");
+    return hipt_clam_stream_pack_launch(w, out, S(stream));
+}
+
 static int gated_scores(const hipt_clam_weights* w, const void* x, int xdtype, int N, float* ab, void* xT, float* A,
                         hipStream_t st) {
     // ab = x @ [Wa;Wb]^T + [ba;bb]  (x: [N,S1] in xdtype), then the gate

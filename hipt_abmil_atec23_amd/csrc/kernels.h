@@ -164,6 +164,8 @@ bool hipt_clam_fused_supported(const hipt_clam_weights* w);
 int hipt_clam_fused_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw,
                            float* partials, int* n_partials, hipStream_t st);
 bool hipt_clam_stream_supported(const hipt_clam_weights* w);
+size_t hipt_clam_stream_image_bytes(const hipt_clam_weights* w);
+int hipt_clam_stream_pack_launch(const hipt_clam_weights* w, void* out, hipStream_t st);
 int hipt_clam_stream_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw,
                             float* partials, int* n_partials, unsigned* ticket, float* M, float* logits, float* Y_prob,
                             int64_t* Y_hat, hipStream_t st);  // n_partials = 0: combine already done in the kernel

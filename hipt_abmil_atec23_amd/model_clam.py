@@ -436,6 +436,13 @@ class CLAM_SB(nn.Module):
             # shift instead of a running maximum (include/hipt_abmil.h, hipt_clam_weights.logit_bound); one tiny reduction per
             # set of weights, read back here once
             w.logit_bound = float(keep["wc"].abs().sum().item())
+            # the streaming kernel's LDS image of these weights (bf16 [384|192,128,64]): packed once here, copied straight by
+            # LDS-DMA at every launch
+            nb = N.lib().hipt_clam_stream_packed_bytes(C_.byref(w))
+            if nb:
+                keep["stream_pk"] = torch.empty(nb, dtype=torch.uint8, device=device)
+                N.call("hipt_clam_stream_pack", C_.byref(w), N.ptr(keep["stream_pk"]), N.stream_ptr(device))
+                w.stream_pk = keep["stream_pk"].data_ptr()
             self._packed = (key, w, keep)
         return self._packed[1]
 

@@ -288,7 +288,17 @@ typedef struct hipt_clam_weights {
                                  (-1, 1)), computed in fp32 by the owner of the weights; lets the streaming kernels exponentiate against
                                  the fixed shift bc + bound instead of a running maximum when the bound is small enough */
     int32_t      reserved2;
+    const void*  stream_pk;   /* optional (NULL = absent): the weights as the LDS image of the streaming kernel (MFMA operand fragments
+                                 of W1 and [Wa;Wb], biases and wc in accumulator order), written by hipt_clam_stream_pack into
+                                 hipt_clam_stream_packed_bytes(w) bytes of device memory; bf16 [384|192,128,64] only.  With it (and a
+                                 logit_bound < 60) hipt_clam_sb_forward is ONE launch of the streaming kernel; without it the
+                                 general kernels run */
 } hipt_clam_weights;
+
+/* The streaming kernel's weight image (hipt_clam_weights.stream_pk): size in bytes (0: this shape / type has none) and the
+ * packing launch (reads w1, b1, wab, bab, wc; `out` 256-byte aligned device memory).  Pack once per set of weights. */
+size_t hipt_clam_stream_packed_bytes(const hipt_clam_weights* w);
+int hipt_clam_stream_pack(const hipt_clam_weights* w, void* out, void* stream);
 
 /* Scratch of the calls below.  ONE piece of state lives in it: the 256-byte "ticket block" at byte offset
  * hipt_clam_ticket_offset() (= 0: the head of the workspace, whatever the widths; the arrival counter of the in-kernel

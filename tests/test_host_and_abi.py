@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(N.BlockWeights) == 15 * 8 + 8 + 8  # 12 matrices / vectors + 3 optional packed images + the MLP image's format + the fused-attention image
     assert N.BlockWeights.qkv_att_pk.offset == 15 * 8 + 8
     assert C.sizeof(N.ImageLayout) == 4 * 4 + 3 * 8
-    assert C.sizeof(N.ClamWeights) == 6 * 4 + 8 * 8 + 8 and N.ClamWeights.logit_bound.offset == 6 * 4 + 8 * 8
+    assert C.sizeof(N.ClamWeights) == 6 * 4 + 8 * 8 + 8 + 8 and N.ClamWeights.logit_bound.offset == 6 * 4 + 8 * 8
     assert N.VitWeights.ln_eps.offset == 28 and N.VitWeights.attn_scale.offset == 32 and N.VitWeights.embed_w.offset == 40
 
 
