@@ -18,7 +18,13 @@
 //     [e^-B, e^B], and for B < 60 neither p nor sum p (N < 2^22 rows) nor sum p h1 can leave fp32's range (e^88).  The caller
 //     supplies B (hipt_clam_weights.logit_bound); larger / unknown bounds take the general kernel.  No rescale of the pooled
 //     sums per step, and the cross-workgroup merge is a plain sum of (sum p, sum p h1[128]);
-//   * software pipeline: the gate arithmetic and the pooling of block s-1 are dealt out under the 96 phase-1 MFMAs of block s;
+//   * biases ride in the GEMMs: a bias is split into three bf16 pieces (hi + mid + lo = the fp32 value to its last bit) that sit in
+//     three k-slots of one extra k-step whose other operand is 1, 1, 1, 0, ..: the first MFMA of every accumulator chain (C = 0)
+//     -- no accumulator initialisation, no bias tables;
+//   * software pipeline, one wave per SIMD: the MFMA pipe of a SIMD is fed by ONE wave, so everything else that wave does sits in
+//     the gaps of its own MFMA stream (24 of every 32 cycles are free for vector instructions): the gate arithmetic, the logit
+//     and the pooling of block s-1 are dealt out under the 100 phase-1 MFMAs of block s, the ReLU / bf16 packing of block s under
+//     its own gate-product MFMAs;
 //   * the last workgroup to finish (arrival ticket, sc1 hand-off) adds the partials in a fixed order and applies the bag
 //     classifier, softmax and argmax: one launch, deterministic bits.
 #include <stdio.h>
@@ -66,35 +72,55 @@ __host__ __device__ __forceinline__ int acc_col(int i, int hh) { return (i & 3) 
 // row of the stacked [Wa; Wb] matrix that gate tile t holds in its A-operand row c: tiles a[0:32] b[0:32] a[32:64] b[32:64]
 __host__ __device__ __forceinline__ int gate_row(int t, int c) { return (t & 1) * S2 + (t >> 1) * 32 + c; }
 
-// The weight image = the kernel's LDS content: W1 fragments (k-step, hidden tile) of 1 KiB | [Wa;Wb] fragments (k-step, gate tile) |
-// b1 [4 tiles][2 lane halves][16] and the gate bias likewise (1 KiB) | wc [2 tile pairs][2][16] (256 B) | padding to 4 KiB
-__host__ __device__ constexpr int off_wab(int KS) { return 4 * KS * 1024; }
-__host__ __device__ constexpr int off_cst(int KS) { return off_wab(KS) + 32 * 1024; }
+// The weight image = the kernel's LDS content, in fragments of 1 KiB (one A operand of v_mfma_f32_32x32x16_bf16 per lane, 16 B):
+//   W1 part:   4 bias fragments (hidden tile T), then fragment (k-step k, hidden tile T) at 4 (k + 1) + T
+//   gate part: 4 bias fragments (gate tile t),   then fragment (k-step kk, gate tile t) at 4 (kk + 1) + t
+//   wc [2 tile pairs][2 lane halves][16] fp32 (256 B), padding to 4 KiB
+__host__ __device__ constexpr int off_wab(int KS) { return 4 * (KS + 1) * 1024; }
+__host__ __device__ constexpr int off_cst(int KS) { return off_wab(KS) + 36 * 1024; }
 __host__ __device__ constexpr int image_bytes(int KS) { return off_cst(KS) + 4096; }
 
 // LDS-DMA as inline asm: 16 bytes per lane to (wave-uniform LDS address in M0) + 16 lane.  hipcc must not know of these loads: with its
 // own builtin in flight it opens every step of the main loop with s_waitcnt vmcnt(0) (all 24 chunks of a block) instead of the counted
 // per-chunk waits.  They are OLDER than every load the compiler counts (loads retire in order), so its counts stay right.
 __device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_wave_base) : "memory");  // (M0 is reserved: hipcc neither allocates it nor, in this kernel, uses it for anything else)
+    // (M0 is reserved: hipcc neither allocates it nor, in this kernel, uses it for anything else)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_wave_base) : "memory");
+}
+
+// fp32 -> three bf16 pieces, hi + mid + lo == v to fp32's last bit (8 + 8 + 8 mantissa bits)
+__device__ __forceinline__ void split3(float v, bf16_t (&o)[3]) {
+#pragma clang fp contract(off)
+    o[0] = (bf16_t)v;
+    const float r1 = v - (float)o[0];
+    o[1] = (bf16_t)r1;
+    o[2] = (bf16_t)(r1 - (float)o[1]);
 }
 
 // one thread per 16 bytes of the image
 __global__ void abmil32_pack_kernel(const bf16_t* __restrict__ w1, const float* __restrict__ b1, const bf16_t* __restrict__ wab,
                                     const float* __restrict__ bab, const float* __restrict__ wc, int KS, char* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int S0 = 16 * KS, nw1 = off_wab(KS) / 16, ng = 32 * 64, total = image_bytes(KS) / 16;
+    const int S0 = 16 * KS, nw1 = off_wab(KS) / 16, ng = 36 * 64, total = image_bytes(KS) / 16;
     if (c >= total) return;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (c < nw1) {
-        // W1 fragment (k, T) at (4 k + T) KiB: lane (r, hh) <- W1[32 T + r][16 k + 8 hh ..+7] (A operand of v_mfma_f32_32x32x16_bf16)
-        const int frag = c >> 6, lane = c & 63, k = frag >> 2, T = frag & 3, r = lane & 31, hh = lane >> 5;
+    const bool gate = c >= nw1;
+    const int c2 = gate ? c - nw1 : c, frag = c2 >> 6, lane = c2 & 63, r = lane & 31, hh = lane >> 5, T = frag & 3, k = (frag >> 2) - 1;
+    if (c < nw1 + ng && k < 0) {
+        // bias fragment: lane (r, 0) carries the bias of the tile's row r in k-slots 0..2 (the other operand is 1, 1, 1, 0, ..)
+        if (hh == 0) {
+            bf16_t pc[3];
+            split3(gate ? bab[gate_row(T, r)] : b1[32 * T + r], pc);
+            bf16x8 o = {pc[0], pc[1], pc[2], (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            v = __builtin_bit_cast(u32x4, o);
+        }
+    } else if (!gate) {
+        // W1 fragment (k, T): lane (r, hh) <- W1[32 T + r][16 k + 8 hh ..+7]
         v = *(const u32x4*)(w1 + (int64_t)(32 * T + r) * S0 + 16 * k + 8 * hh);
     } else if (c < nw1 + ng) {
         // [Wa;Wb] fragment (kk, t): k-step kk = 2 T' + s' of hidden tile T'; lane (r, hh) element j <- hidden 16 kk + 8 (j >> 2) + 4 hh + (j & 3),
         // the order in which pack8<s'> of the h1 accumulator tile T' feeds its k slots
-        const int c2 = c - nw1, frag = c2 >> 6, lane = c2 & 63, kk = frag >> 2, t = frag & 3, r = lane & 31, hh = lane >> 5;
-        const bf16_t* src = wab + (int64_t)gate_row(t, r) * S1 + 16 * kk + 4 * hh;
+        const bf16_t* src = wab + (int64_t)gate_row(T, r) * S1 + 16 * k + 4 * hh;
         const u32x2 lo = *(const u32x2*)src, hi = *(const u32x2*)(src + 8);
         v = u32x4{lo[0], lo[1], hi[0], hi[1]};
     } else {
@@ -102,10 +128,8 @@ __global__ void abmil32_pack_kernel(const bf16_t* __restrict__ w1, const float* 
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int f = f0 + e, T = (f >> 5) & 3, hb = (f >> 4) & 1, i = f & 15;
-            if (f < 128) o[e] = b1[32 * T + acc_col(i, hb)];
-            else if (f < 256) o[e] = bab[gate_row(T, acc_col(i, hb))];
-            else if (f < 320) o[e] = wc[32 * (T & 1) + acc_col(i, hb)];
+            const int f = f0 + e, tp = (f >> 5) & 1, hb = (f >> 4) & 1, i = f & 15;
+            if (f < 64) o[e] = wc[32 * tp + acc_col(i, hb)];
         }
         v = __builtin_bit_cast(u32x4, o);
     }
@@ -122,15 +146,32 @@ __device__ __forceinline__ u32x4 pack8(const f32x16& a) {
     return o;
 }
 
-// tanh(x) * sigmoid(y) * w with ONE reciprocal: (E - 1) w / ((E + 1)(1 + F)), E = e^{2x}, F = e^{-y}; x clamped to +-15
-// (contraction off: a row's logit must be the same bits wherever the row sits -- pipelined step, drain, any block)
-__device__ __forceinline__ float gate_term(float x, float y, float w) {
-#pragma clang fp contract(off)
-    const float xs = __builtin_amdgcn_fmed3f(x, -15.0f, 15.0f) * (2.0f * LOG2E);
-    const float ys = y * -LOG2E;
-    const float E = __builtin_amdgcn_exp2f(xs), F = __builtin_amdgcn_exp2f(ys);
-    const float num = (E - 1.0f) * w, den = (E + 1.0f) * (F + 1.0f);
-    return num * __builtin_amdgcn_rcpf(den);
+// ---- the vector work that rides in the gaps of the MFMA streams, as lists of micro-operations dealt to the MFMA slots by issue cost
+// (MI355X_MICROARCH.md: 4 cycles a vector instruction, 8 a transcendental; 24 of an MFMA's 32 cycles are free) ----
+// Phase 1 carries the block before: 32 gate pairs x 12 micro-ops (tanh(x) sigmoid(y) w with ONE reciprocal:
+//   acc - (w - E w) / (E (1 + F) + (1 + F)), E = e^{2x}, F = e^{-y}, x clamped to +-15), then the logit, then 16 quarter tiles of pooling.
+constexpr int GU = 12, P1_FIN = 32 * GU, P1_POOL = P1_FIN + 1, P1_NU = P1_POOL + 16;
+constexpr int p1_cost(int u) {
+    if (u < P1_FIN) {
+        const int j = (u % (2 * GU)) / 2;  // (two pairs interleaved, below)
+        return (j == 5 || j == 6 || j == 10) ? 8 : 4;
+    }
+    return u == P1_FIN ? 56 : 16;
+}
+// Phase 2 carries its own block's ReLU + bf16 packing: per hidden tile 8 elements, the operand of one k-step, 8 elements, the other operand
+constexpr int RU = 18, P2_NU = 4 * RU;
+constexpr int p2_cost(int u) { return (u % RU == 8 || u % RU == 17) ? 16 : 8; }
+// micro-ops [lo, hi) of slot g when every slot takes `budget` cycles' worth: hi(g) = the first u whose running cost exceeds (g + 1) budget
+template <class F>
+constexpr int dealt(F cost, int nu, int budget, int g) {
+    int acc = 0, u = 0;
+    while (u < nu && acc + cost(u) <= (g + 1) * budget) acc += cost(u++);
+    return u;
+}
+constexpr int p1_total() {
+    int t = 0;
+    for (int u = 0; u < P1_NU; ++u) t += p1_cost(u);
+    return t;
 }
 
 struct Abmil32Params {
@@ -150,6 +191,7 @@ struct Abmil32Params {
     float* Y_prob;
     int64_t* Y_hat;
     unsigned long long* stamps;  // diagnostic builds: [grid][24] s_memrealtime ticks (100 MHz) of wave 0
+    int no_traffic;              // diagnostic builds (HIPT_ABMIL_NO_TRAFFIC): every bag request out of range -- the arithmetic alone
 };
 
 template <int KS>  // k-steps of 16 input features: S0 = 16 KS
@@ -183,18 +225,13 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     }
     // this wave's first block: requested behind the image, so that "all but the youngest KS" below means "the image has landed"
     // (the bag through a buffer resource that ends with it: a chunk of a row past the end reads as zero, no traffic)
-    // A block's chunks live in two register sets: the lower half of the k-steps in xlo, re-requested IN PLACE for the next block as
-    // soon as its k-step is done (first half of phase 1); the upper half alternately in xa / xb, the idle one of which is filled
-    // for the next block during the gate product and the gate arithmetic.  The 24 requests of a block are thus spread over the
-    // whole step: issued in one burst they hold the CU's address unit for longer than phase 1 lasts, and the waves stall on issue.
-    constexpr int KH = KS / 2;
-    u32x4 xlo[KH], xa[KH], xb[KH];
+    // A block's 32 rows are ONE B operand per k-step, held in registers for the whole block and re-requested IN PLACE for the wave's next
+    // block as soon as the k-step is done with its chunk: a block's worth of requests is always in flight behind the arithmetic
+    u32x4 x[KS];
     {
-        const int v0 = nstep > 0 ? gw * 32 * S0 * 2 + vrow : OOR;  // (no block: out of range, zeros)
+        const int v0 = nstep > 0 && !p.no_traffic ? gw * 32 * S0 * 2 + vrow : OOR;  // (no block: out of range, zeros)
 #pragma unroll
-        for (int k = 0; k < KH; ++k) xlo[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + k * 32, 0, 0);
-#pragma unroll
-        for (int k = 0; k < KH; ++k) xa[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + (KH + k) * 32, 0, 0);
+        for (int k = 0; k < KS; ++k) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + k * 32, 0, 0);
     }
     // s_waitcnt vmcnt(KS) as the builtin (vmcnt = bits 15:14 | 3:0; expcnt, lgkmcnt: no wait): hipcc's own wait-count bookkeeping sees
     // it -- behind an opaque asm wait it would take every load as still in flight and open each step with vmcnt(0)
@@ -203,199 +240,184 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     __builtin_amdgcn_s_barrier();  // (raw: __syncthreads() would wait for the first block's loads too)  weights are in LDS; from here on the waves never synchronise again (until the merge)
 
     const uint32_t lbase = lds_addr(smem);
-    const uint32_t fa = lbase + lane * 16;
-    const uint32_t fb = fa + (KS > 12 ? 48 * 1024 : 0);   // (ds offsets are 16-bit: W1 fragments beyond 48 KiB through a second base)
-    const uint32_t fg = fa + OFF_WAB;
-    const uint32_t cb1 = lbase + OFF_CST + hh * 64, cgb = cb1 + 512;
+    // (ds offsets are 16-bit: three bases for the 100 + 36 fragments)
+    const uint32_t fa = lbase + lane * 16, fb = fa + 64 * 1024, fg = fa + OFF_WAB;
     // wc of this lane's 32 gate pairs, in pair order (tile pair tp, register i): kept in registers
     // (through asm reads: a visible LDS access makes hipcc wait for every load in flight, the first block's included)
     float wcr[32];
 #pragma unroll
     for (int q4 = 0; q4 < 8; ++q4) {
-        const f32x4 v = lds_ld128(lbase + OFF_CST + 1024 + (((q4 >> 2) * 2 + hh) * 16 + (q4 & 3) * 4) * 4);
+        const f32x4 v = lds_ld128(lbase + OFF_CST + (((q4 >> 2) * 2 + hh) * 16 + (q4 & 3) * 4) * 4);
         wcr[4 * q4] = v[0];
         wcr[4 * q4 + 1] = v[1];
         wcr[4 * q4 + 2] = v[2];
         wcr[4 * q4 + 3] = v[3];
     }
     const float bcv = p.bc[0];
+    // the other operand of the bias k-steps: 1, 1, 1, 0, .. in the k-slots of lane half 0
+    const u32x4 ones = hh == 0 ? u32x4{0x3f803f80u, 0x00003f80u, 0u, 0u} : u32x4{0u, 0u, 0u, 0u};
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     f32x16 pool[4];
 #pragma unroll
-    for (int T = 0; T < 4; ++T) pool[T] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int T = 0; T < 4; ++T) pool[T] = zero16;
     float lsum = 0.f;
-    f32x16 HA[4], G[4];
-    u32x4 hf[8];
+    f32x16 H[4], G[4];   // accumulators of the two products
+    f32x16 Hp[4];        // h1 = ReLU(H) in fp32, kept for the pooling one block later
+    u32x4 hf[8];         // h1 in bf16: the B operand of the gate product
     float gs = 0.f, prow = 0.f;
 
-    // one gate pair of the block being gated: q = 16 tp + i -> a = G[2 tp][i], b = G[2 tp + 1][i] (biases already in)
-    auto gate_q = [&](auto Q_) __attribute__((always_inline)) {
+    // ---- micro-ops (above) ----
+    // two gate pairs in flight, their micro-ops alternating: one wave per SIMD, so a dependent chain of vector instructions has nobody
+    // to hide its latencies behind (a transcendental's result is not ready for the next instruction) but the other pair
+    float ga[2], gb[2], xs[2], ys[2], eE[2], eF[2], nn[2], t1[2], dn[2], rc[2];
+    auto finish = [&](int blk) __attribute__((always_inline)) {
+        // the row's logit (the lane halves hold the two halves of its gate units), A_raw, softmax weight against the fixed shift
 #pragma clang fp contract(off)
-        constexpr int q = decltype(Q_)::value, tp = q >> 4, i = q & 15;
-        const float t = gate_term(G[2 * tp][i], G[2 * tp + 1][i], wcr[q]);
-        if constexpr (q == 0) gs = t;
-        else gs = gs + t;
-    };
-    // the row's logit (lane halves hold the two halves of its gate units), A_raw, softmax weight against the fixed shift
-    auto gate_finish = [&](int blk) __attribute__((always_inline)) {
-#pragma clang fp contract(off)
-        const float g2 = gs + __shfl_xor(gs, 32, 64);   // (the same bits in both halves: the pooling of either half uses prow)
+        // v_permlane32_swap on two copies: one becomes (lower, lower), the other (upper, upper): the same sum, in the same order, in
+        // both halves (the pooling of either half uses prow); no LDS crossbar in the MFMA stream
+        const unsigned gbits = __builtin_bit_cast(unsigned, gs);
+        const auto sw = __builtin_amdgcn_permlane32_swap(gbits, gbits, false, false);
+        const unsigned s0 = sw[0], s1 = sw[1];  // (scalar copies first: bit-casting a vector element reads element 0, common.h)
+        const float g2 = __builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1);
         const int row = blk * 32 + r;
         const bool valid = row < p.N;
         if (valid && hh == 0) p.A_raw[row] = g2 + bcv;
         prow = valid ? __builtin_amdgcn_exp2f(g2 * LOG2E) : 0.f;  // e^(A - bc), in [e^-B, e^B]
         if (hh == 0) lsum += prow;
     };
-    auto pool_tile = [&](auto T_, auto Hh_, f32x16 (&Hp)[4]) __attribute__((always_inline)) {  // half a tile: 8 registers
-        constexpr int T = decltype(T_)::value, h8 = decltype(Hh_)::value;
+    auto p1_uop = [&](auto U_, int blk) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+        constexpr int u = decltype(U_)::value;
+        if constexpr (u < P1_FIN) {
+            // gate pair q = 16 tp + i: a = G[2 tp][i], b = G[2 tp + 1][i] (biases in).  Every multiply-add is written out (contraction off: a
+            // row's logit must be the same bits wherever the row sits -- pipelined step, drain, any block).  The accumulators live in the
+            // accumulator file and are read HERE: left to hipcc, all 64 reads of a block sit in one burst in front of the next block's MFMAs
+            constexpr int c = u & 1, q = 2 * (u / (2 * GU)) + c, j = (u % (2 * GU)) / 2, tp = q >> 4, i = q & 15;
+            if constexpr (j == 0) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(ga[c]) : "a"(G[2 * tp][i]));
+            if constexpr (j == 1) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(gb[c]) : "a"(G[2 * tp + 1][i]));
+            if constexpr (j == 2) xs[c] = __builtin_amdgcn_fmed3f(ga[c], -15.0f, 15.0f);
+            if constexpr (j == 3) xs[c] = xs[c] * (2.0f * LOG2E);
+            if constexpr (j == 4) ys[c] = gb[c] * -LOG2E;
+            if constexpr (j == 5) eE[c] = __builtin_amdgcn_exp2f(xs[c]);
+            if constexpr (j == 6) eF[c] = __builtin_amdgcn_exp2f(ys[c]);
+            // (w - E w = -numerator: the negations sit on E and on the product as source modifiers; a "-w" would be a loop invariant that
+            //  hipcc hoists into 32 more live registers)
+            if constexpr (j == 7) nn[c] = __builtin_fmaf(-eE[c], wcr[q], wcr[q]);
+            if constexpr (j == 8) t1[c] = eF[c] + 1.0f;
+            if constexpr (j == 9) dn[c] = __builtin_fmaf(eE[c], t1[c], t1[c]);
+            if constexpr (j == 10) rc[c] = __builtin_amdgcn_rcpf(dn[c]);
+            if constexpr (j == 11) gs = __builtin_fmaf(-nn[c], rc[c], q == 0 ? 0.f : gs);  // (pair order: 0, 1, 2, ..)
+        } else if constexpr (u == P1_FIN) {
+            finish(blk);
+        } else {
+            constexpr int T = (u - P1_POOL) >> 2, q4 = (u - P1_POOL) & 3;  // a quarter of a tile: 4 registers
 #pragma unroll
-        for (int i = 8 * h8; i < 8 * h8 + 8; ++i) pool[T][i] = __builtin_fmaf(prow, Hp[T][i], pool[T][i]);
-    };
-
-    // request j of the next block's upper half (byte offset vnext of the lane's row) into the idle set
-    auto load_hi = [&](auto J_, u32x4 (&xn)[KH], int vnext) __attribute__((always_inline)) {
-        constexpr int j = decltype(J_)::value;
-        xn[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, vnext + (KH + j) * 32, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    constexpr int NL2 = KH / 3, NLG = KH - NL2;  // requests placed in the gate product / between the gate pairs
-
-    // phase 1: H = b1 + W1 x^T over KS k-steps x 4 hidden tiles; a k-step of the lower half that is done with its chunk requests the next block's
-    auto phase1 = [&](f32x16 (&H)[4], u32x4 (&xhi)[KH], int vnext) __attribute__((always_inline)) {
-        {   // H = b1 (accumulator order: 16 floats per (tile, lane half))
-            const uint32_t a = cb1;
-            sfor<0, 4>([&](auto T_) __attribute__((always_inline)) {
-                constexpr int T = decltype(T_)::value;
-                f32x4 v0, v1, v2, v3;
-                const uint32_t a2 = a;
-                DSR128X4_WAIT(v0, v1, v2, v3, a2, T * 128, T * 128 + 16, T * 128 + 32, T * 128 + 48);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    H[T][i] = v0[i];
-                    H[T][4 + i] = v1[i];
-                    H[T][8 + i] = v2[i];
-                    H[T][12 + i] = v3[i];
-                }
-            });
+            for (int i = 4 * q4; i < 4 * q4 + 4; ++i) pool[T][i] = __builtin_fmaf(prow, Hp[T][i], pool[T][i]);
         }
-        u32x4 wfr[8];
-        constexpr int NSL = 4 * KS, PFD = 5;  // MFMA slots (k, T); fragments requested ahead
-        auto rd = [&](auto G_) __attribute__((always_inline)) {
-            constexpr int g = decltype(G_)::value;  // slot g = 4 k + T = the fragment's KiB index
-            u32x4& d = wfr[g & 7];
-            if constexpr (g < 48) {
-                const uint32_t a = fa;
-                DSR128(d, a, g * 1024);
-            } else {
-                const uint32_t a = fb;
-                DSR128(d, a, (g - 48) * 1024);
-            }
-        };
-        sfor<0, PFD>([&](auto G_) __attribute__((always_inline)) { rd(G_); });
+    };
+    auto p2_uop = [&](auto U_) __attribute__((always_inline)) {
+        constexpr int u = decltype(U_)::value, T = u / RU, j = u % RU;
+        if constexpr (j == 8) hf[2 * T] = pack8<0>(Hp[T]);
+        else if constexpr (j == 17) hf[2 * T + 1] = pack8<1>(Hp[T]);
+        else {
+            constexpr int e = j < 8 ? j : j - 1;
+            Hp[T][e] = fmaxf(H[T][e], 0.f);
+        }
+    };
+
+    // fragment read into the ring (slot g of a phase: fragment index frag0 + g)
+    u32x4 wfr[8];
+    auto rd1 = [&](auto G_) __attribute__((always_inline)) {  // phase 1: fragment g
+        constexpr int g = decltype(G_)::value;
+        u32x4& d = wfr[g & 7];
+        if constexpr (g < 64) {
+            const uint32_t a = fa;
+            DSR128(d, a, g * 1024);
+        } else {
+            const uint32_t a = fb;
+            DSR128(d, a, (g - 64) * 1024);
+        }
+    };
+    auto rd2 = [&](auto G_) __attribute__((always_inline)) {  // phase 2: gate fragment g
+        constexpr int g = decltype(G_)::value;
+        u32x4& d = wfr[g & 7];
+        const uint32_t a = fg;
+        DSR128(d, a, g * 1024);
+    };
+    constexpr int PFD = 5;  // fragments requested ahead of the MFMA that uses them
+
+    // phase 1 of a block: H = W1 x^T + b1: the bias k-step, then KS k-steps, 4 hidden tiles each.  A k-step that is done with its chunk
+    // requests the next block's in place.  With PIPE the gate arithmetic, the logit and the pooling of the block BEFORE
+    // (in G and Hp) ride in the gaps of the MFMA stream.
+    auto phase1 = [&](auto PIPE_, int vnext, int blk_prev) __attribute__((always_inline)) {
+        constexpr bool PIPE = decltype(PIPE_)::value;
+        constexpr int NSL = 4 * (KS + 1);
+        constexpr int BUD = (p1_total() + NSL - 1) / NSL > 24 ? (p1_total() + NSL - 1) / NSL : 24;  // cycles of vector work per slot
+        sfor<0, PFD>(rd1);
         sfor<0, NSL>([&](auto G_) __attribute__((always_inline)) {
-            constexpr int g = decltype(G_)::value, k = g >> 2, T = g & 3;
+            constexpr int g = decltype(G_)::value, k = (g >> 2) - 1, T = g & 3;
             if constexpr (g + PFD < NSL) {
-                rd(std::integral_constant<int, g + PFD>{});
+                rd1(std::integral_constant<int, g + PFD>{});
                 LGKM(PFD);
             } else {
                 LGKM(NSL - 1 - g);
             }
-            if constexpr (k < KH) {
-                H[T] = mfma32(wfr[g & 7], xlo[k], H[T]);
-                if constexpr (T == 3) xlo[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, vnext + k * 32, 0, 0);
+            if constexpr (k < 0) {
+                H[T] = mfma32(wfr[g & 7], ones, zero16);
             } else {
-                H[T] = mfma32(wfr[g & 7], xhi[k - KH], H[T]);
+                H[T] = mfma32(wfr[g & 7], x[k], H[T]);
+                if constexpr (T == 3) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, vnext + k * 32, 0, 0);
+            }
+            if constexpr (PIPE) {
+                constexpr int lo = g == 0 ? 0 : dealt(p1_cost, P1_NU, BUD, g - 1), hi = g == NSL - 1 ? P1_NU : dealt(p1_cost, P1_NU, BUD, g);
+                sfor<lo, hi>([&](auto U_) __attribute__((always_inline)) { p1_uop(U_, blk_prev); });
             }
             __builtin_amdgcn_sched_barrier(0);
         });
     };
 
-    // h1 = ReLU(H) in place (fp32, for the pooling one block later) and as the B operand of the gate product
-    auto relu_pack = [&](f32x16 (&H)[4]) __attribute__((always_inline)) {
-        sfor<0, 4>([&](auto T_) __attribute__((always_inline)) {
-            constexpr int T = decltype(T_)::value;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) H[T][i] = fmaxf(H[T][i], 0.f);
-            hf[2 * T] = pack8<0>(H[T]);
-            hf[2 * T + 1] = pack8<1>(H[T]);
-        });
-    };
-
-    // phase 2: G = gate bias + [Wa;Wb] h1^T: 8 k-steps x 4 gate tiles
-    auto phase2 = [&](u32x4 (&xn)[KH], int vnext) __attribute__((always_inline)) {
-        {
-            const uint32_t a = cgb;
-            sfor<0, 4>([&](auto T_) __attribute__((always_inline)) {
-                constexpr int T = decltype(T_)::value;
-                f32x4 v0, v1, v2, v3;
-                const uint32_t a2 = a;
-                DSR128X4_WAIT(v0, v1, v2, v3, a2, T * 128, T * 128 + 16, T * 128 + 32, T * 128 + 48);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    G[T][i] = v0[i];
-                    G[T][4 + i] = v1[i];
-                    G[T][8 + i] = v2[i];
-                    G[T][12 + i] = v3[i];
-                }
-            });
-        }
-        u32x4 wfr[8];
-        constexpr int PFD = 5;
-        auto rd = [&](auto G_) __attribute__((always_inline)) {
-            constexpr int g = decltype(G_)::value;  // slot g = 4 kk + t
-            u32x4& d = wfr[g & 7];
-            const uint32_t a = fg;
-            DSR128(d, a, g * 1024);
-        };
-        sfor<0, PFD>([&](auto G_) __attribute__((always_inline)) { rd(G_); });
-        sfor<0, 32>([&](auto G_) __attribute__((always_inline)) {
-            constexpr int g = decltype(G_)::value, kk = g >> 2, t = g & 3;
-            if constexpr (g + PFD < 32) {
-                rd(std::integral_constant<int, g + PFD>{});
+    // phase 2: G = [Wa;Wb] h1^T + gate bias: the bias k-step, then 8 k-steps, 4 gate tiles each.  The ReLU / packing of h1 rides along: tile
+    // 0 under the bias k-step, tile T + 1 under the two k-steps that consume tile T.
+    auto phase2 = [&]() __attribute__((always_inline)) {
+        constexpr int NSL = 36;
+        sfor<0, PFD>(rd2);
+        sfor<0, NSL>([&](auto G_) __attribute__((always_inline)) {
+            constexpr int g = decltype(G_)::value, kk = (g >> 2) - 1, t = g & 3;
+            if constexpr (g + PFD < NSL) {
+                rd2(std::integral_constant<int, g + PFD>{});
                 LGKM(PFD);
             } else {
-                LGKM(31 - g);
+                LGKM(NSL - 1 - g);
             }
-            G[t] = mfma32(wfr[g & 7], hf[kk], G[t]);
+            if constexpr (kk < 0) G[t] = mfma32(wfr[g & 7], ones, zero16);
+            else G[t] = mfma32(wfr[g & 7], hf[kk], G[t]);
+            // (24 cycles' worth a slot: the operand of k-step kk = 2 T + s is packed 80 (2 T + s + 1) cycles into the list, k-step kk starts at
+            //  slot 4 (kk + 1): always in time)
+            constexpr int lo = g == 0 ? 0 : dealt(p2_cost, P2_NU, 24, g - 1), hi = dealt(p2_cost, P2_NU, 24, g);
+            sfor<lo, hi>(p2_uop);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (g % (32 / NL2) == 0) load_hi(std::integral_constant<int, g / (32 / NL2)>{}, xn, vnext);
         });
     };
 
-    // gate arithmetic, logit, softmax weight and pooling of the block
-    auto gate_pool = [&](f32x16 (&Hp)[4], int blk, u32x4 (&xn)[KH], int vnext) __attribute__((always_inline)) {
-        sfor<0, 32>([&](auto Q_) __attribute__((always_inline)) {
-            constexpr int q = decltype(Q_)::value;
-            gate_q(Q_);
-            if constexpr (q % (32 / NLG) == 0) load_hi(std::integral_constant<int, NL2 + q / (32 / NLG)>{}, xn, vnext);
-        });
-        gate_finish(blk);
-        sfor<0, 8>([&](auto HH_) __attribute__((always_inline)) {
-            constexpr int ht = decltype(HH_)::value;
-            pool_tile(std::integral_constant<int, (ht >> 1)>{}, std::integral_constant<int, (ht & 1)>{}, Hp);
-        });
+    // gate arithmetic + pooling of the wave's last block: nothing left to hide them under
+    auto drain = [&](int blk) __attribute__((always_inline)) {
+        sfor<0, P1_NU>([&](auto U_) __attribute__((always_inline)) { p1_uop(U_, blk); });
     };
 
-    // one block: its upper half is in xr; the next block's goes to xn
-    auto step = [&](int s, u32x4 (&xr)[KH], u32x4 (&xn)[KH]) __attribute__((always_inline)) {
+    auto step = [&](auto PIPE_, int s) __attribute__((always_inline)) {
         const int blk = gw + s * p.nwaves;
-        const int vnext = s + 1 < nstep ? (blk + p.nwaves) * 32 * S0 * 2 + vrow : OOR;
-        phase1(HA, xr, vnext);
+        const int vnext = s + 1 < nstep && !p.no_traffic ? (blk + p.nwaves) * 32 * S0 * 2 + vrow : OOR;
+        phase1(PIPE_, vnext, blk - p.nwaves);
         if (s < 4) ASTAMP(3 + 3 * s);
-        relu_pack(HA);
-        phase2(xn, vnext);
+        phase2();
         if (s < 4) ASTAMP(4 + 3 * s);
-        gate_pool(HA, blk, xn, vnext);
-        if (s < 4) ASTAMP(5 + 3 * s);
     };
     ASTAMP(2);
-    {
-        int s = 0;
-        for (; s + 1 < nstep; s += 2) {
-            step(s, xa, xb);
-            step(s + 1, xb, xa);
-        }
-        if (s < nstep) step(s, xa, xb);
+    if (nstep > 0) {
+        step(std::false_type{}, 0);
+        for (int s = 1; s < nstep; ++s) step(std::true_type{}, s);
+        drain(gw + (nstep - 1) * p.nwaves);
     }
     ASTAMP(15);
     if (p.attention_only) return;
@@ -565,7 +587,10 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
     p.Y_prob = Y_prob;
     p.Y_hat = Y_hat;
     p.stamps = nullptr;
-#ifdef HIPT_DEBUG_STAMPS  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
+    p.no_traffic = 0;
+#ifdef HIPT_DEBUG_STAMPS
+    static const bool no_traffic = getenv("HIPT_ABMIL_NO_TRAFFIC") != nullptr;
+    p.no_traffic = no_traffic;  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
     static const bool want_stamps = getenv("HIPT_ABMIL_STAMPS") != nullptr;
     static unsigned long long* dbuf = nullptr;
     if (want_stamps && !dbuf) (void)hipMalloc(&dbuf, 256 * 24 * sizeof(unsigned long long));
