@@ -6,10 +6,14 @@
 //   * one 4-wave workgroup per CU (one wave per SIMD, the whole register file each); the weights are staged ONCE per workgroup
 //     into LDS as MFMA A-operand fragments of 1 KiB (W1: [k-step][hidden tile]; [Wa;Wb]: [k-step][gate tile], its k order
 //     permuted to the accumulator-as-operand order of the h1 tiles);
-//   * a WAVE owns 32-row blocks end to end (block b -> wave b mod #waves): no barrier, no LDS exchange in steady state.  The
-//     32 rows of a block are ONE B operand of v_mfma_f32_32x32x16_bf16 (row on the lane), loaded HBM -> registers in operand
-//     layout, re-loaded in place for the next block as soon as a k-step has used its chunk (a range-checked buffer: rows past
-//     the bag read as zero, no traffic);
+//   * a WAVE owns 32-row blocks end to end (block b -> wave b mod #waves): no barrier, no exchange between waves in steady state.
+//     A block's 24 KiB come HBM -> registers in WHOLE 128-byte lines (a wave instruction = 8 rows x 128 B: the lane that would
+//     feed the MFMA holds row = lane, so operand-layout loads are 32 rows x 32 B per instruction, and that scatter costs a third
+//     of the achievable HBM rate: 29.7 -> 24.9 us for the kernel's memory side alone); a block's worth of requests is always in
+//     flight in registers, re-requested in place as soon as a slice has been used.  Slices of 4 k-steps (32 rows x 128 B) pass
+//     through a 4.5 KiB LDS buffer of the wave (written in line layout, read back as B operands of v_mfma_f32_32x32x16_bf16, row
+//     on the lane; a wave's LDS operations execute in order, so there is no wait between the two) one slice ahead of the MFMAs.
+//     Rows past the bag read as zero through a range-checked buffer, no traffic;
 //   * h1^T = W1 x^T + b1 (4 hidden tiles x KS k-steps), ReLU, packed IN PLACE as the B operand of the gate product
 //     [a;b]^T = [Wa;Wb] h1^T (accumulator-as-operand: no data movement); the gate tiles hold a_j and b_j of a row in the same
 //     lane, so tanh * sigmoid * wc is lane-local and a row's logit is one cross-half add;
@@ -42,16 +46,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int S1 = 128, S2 = 64;
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int PSTRIDE = 2 + S1;  // floats per workgroup partial: (shift = 0, sum p, acc[128]) -- the layout hipt_clam_combine_launch reads
+// floats per workgroup partial.  Without the in-kernel combine: (shift = 0, sum p, acc[128]), the layout hipt_clam_combine_launch reads;
+// with it: (shift, sum p, -, -, acc[128]) -- 16-byte aligned sums, whole 16-byte loads in the merge
+constexpr int PSTRIDE = 2 + S1, PSTRIDE_F = 4 + S1;
 
 __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-// 16 bytes at an 8-byte-aligned offset through a buffer resource, sc1 (bypasses the L1: see the fused combine)
-__device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, int off) {
-    const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 16), hi = __builtin_amdgcn_raw_buffer_load_b64(r, off + 8, 0, 16);
-    const f32x2 l = __builtin_bit_cast(f32x2, lo), h = __builtin_bit_cast(f32x2, hi);
-    return f32x4{l[0], l[1], h[0], h[1]};
 }
 // sum over the 64 lanes without the LDS crossbar (ds_bpermute costs ~100 cycles a step, six dependent steps): quads and 16-lane rows by
 // DPP, the four row sums by readlane; every lane gets the result; a fixed order, like wave_sum's
@@ -79,6 +79,7 @@ __host__ __device__ __forceinline__ int gate_row(int t, int c) { return (t & 1) 
 __host__ __device__ constexpr int off_wab(int KS) { return 4 * (KS + 1) * 1024; }
 __host__ __device__ constexpr int off_cst(int KS) { return off_wab(KS) + 36 * 1024; }
 __host__ __device__ constexpr int image_bytes(int KS) { return off_cst(KS) + 4096; }
+constexpr int TB_BYTES = 32 * 144;  // a wave's transposition buffer, behind the image
 
 // LDS-DMA as inline asm: 16 bytes per lane to (wave-uniform LDS address in M0) + 16 lane.  hipcc must not know of these loads: with its
 // own builtin in flight it opens every step of the main loop with s_waitcnt vmcnt(0) (all 24 chunks of a block) instead of the counted
@@ -174,6 +175,29 @@ constexpr int p1_total() {
     return t;
 }
 
+// Phase 1's LDS queue, in order: per slot the fragment request for slot g + PFD, then (first half of a slice) one operation on the
+// transposition buffer.  lgkmcnt to wait for at slot g = the operations issued after the request of ITS fragment (4-bit counter: a
+// smaller number only waits longer).
+template <int KS>
+constexpr int p1_lgkm(int g, int PFD) {
+    constexpr int NSL = 4 * (KS + 1);
+    auto nA = [&](int s) { return s + PFD < NSL ? 1 : 0; };
+    auto nT = [&](int s) {
+        if (s < 4) return 0;
+        const int u = (s - 4) & 15;
+        return (u <= 5 || u == 9 || u == 13) ? 1 : 0;
+    };
+    int n = 0;
+    if (g >= PFD) {
+        n = nT(g - PFD);
+        for (int s = g - PFD + 1; s <= g; ++s) n += nA(s) + nT(s);
+    } else {
+        n = PFD - 1 - g;
+        for (int s = 0; s <= g; ++s) n += nA(s) + nT(s);
+    }
+    return n < 15 ? n : 15;
+}
+
 struct Abmil32Params {
     const bf16_t* bag;
     int N, nblocks, nwaves;
@@ -213,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.bag, 0, (int)((int64_t)p.N * S0 * 2), 0x00020000);
     constexpr int OOR = 0x7fff0000;                                     // (beyond any bag the launcher accepts)
-    const int vrow = r * (S0 * 2) + hh * 16;                            // lane (r, hh): row r of a block, 16-byte chunk 2 k + hh
+    const int vrow = (lane >> 3) * (S0 * 2) + (lane & 7) * 16;          // lane l: row l >> 3 of a group of 8, chunk l & 7 of a 128-byte line
 
     // ---- stage the weights: the image is the LDS content byte for byte, 1 KiB per LDS-DMA wave instruction ----
     {
@@ -225,13 +249,14 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     }
     // this wave's first block: requested behind the image, so that "all but the youngest KS" below means "the image has landed"
     // (the bag through a buffer resource that ends with it: a chunk of a row past the end reads as zero, no traffic)
-    // A block's 32 rows are ONE B operand per k-step, held in registers for the whole block and re-requested IN PLACE for the wave's next
-    // block as soon as the k-step is done with its chunk: a block's worth of requests is always in flight behind the arithmetic
-    u32x4 x[KS];
+    // The block in flight, in line layout: xc[4 i + j] = lane l's 16 bytes of row 8 j + (l >> 3), 128-byte line i, chunk l & 7
+    constexpr int NSLICE = KS / 4;
+    u32x4 xc[KS];
+    auto xoff = [](int m) { return (m & 3) * 8 * (S0 * 2) + (m >> 2) * 128; };
     {
         const int v0 = nstep > 0 && !p.no_traffic ? gw * 32 * S0 * 2 + vrow : OOR;  // (no block: out of range, zeros)
 #pragma unroll
-        for (int k = 0; k < KS; ++k) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + k * 32, 0, 0);
+        for (int m = 0; m < KS; ++m) xc[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + xoff(m), 0, 0);
     }
     // s_waitcnt vmcnt(KS) as the builtin (vmcnt = bits 15:14 | 3:0; expcnt, lgkmcnt: no wait): hipcc's own wait-count bookkeeping sees
     // it -- behind an opaque asm wait it would take every load as still in flight and open each step with vmcnt(0)
@@ -245,13 +270,18 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     // wc of this lane's 32 gate pairs, in pair order (tile pair tp, register i): kept in registers
     // (through asm reads: a visible LDS access makes hipcc wait for every load in flight, the first block's included)
     float wcr[32];
+    {
+        const uint32_t a = lbase + OFF_CST + hh * 64;  // [tile pair][lane half][16]: pair tp at + 128 tp
+        f32x4 v[8];
+        DSR128X4_WAIT(v[0], v[1], v[2], v[3], a, 0, 16, 32, 48);
+        DSR128X4_WAIT(v[4], v[5], v[6], v[7], a, 128, 144, 160, 176);
 #pragma unroll
-    for (int q4 = 0; q4 < 8; ++q4) {
-        const f32x4 v = lds_ld128(lbase + OFF_CST + (((q4 >> 2) * 2 + hh) * 16 + (q4 & 3) * 4) * 4);
-        wcr[4 * q4] = v[0];
-        wcr[4 * q4 + 1] = v[1];
-        wcr[4 * q4 + 2] = v[2];
-        wcr[4 * q4 + 3] = v[3];
+        for (int q4 = 0; q4 < 8; ++q4) {
+            wcr[4 * q4] = v[q4][0];
+            wcr[4 * q4 + 1] = v[q4][1];
+            wcr[4 * q4 + 2] = v[q4][2];
+            wcr[4 * q4 + 3] = v[q4][3];
+        }
     }
     const float bcv = p.bc[0];
     // the other operand of the bias k-steps: 1, 1, 1, 0, .. in the k-slots of lane half 0
@@ -281,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
         const unsigned s0 = sw[0], s1 = sw[1];  // (scalar copies first: bit-casting a vector element reads element 0, common.h)
         const float g2 = __builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1);
         const int row = blk * 32 + r;
-        const bool valid = row < p.N;
+        const bool valid = row < p.N && blk >= 0;
         if (valid && hh == 0) p.A_raw[row] = g2 + bcv;
         prow = valid ? __builtin_amdgcn_exp2f(g2 * LOG2E) : 0.f;  // e^(A - bc), in [e^-B, e^B]
         if (hh == 0) lsum += prow;
@@ -326,11 +356,33 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
         }
     };
 
+    // the wave's transposition buffer: 32 rows of 128 + 16 bytes (the padding spreads the rows over the banks for the operand reads)
+    const uint32_t tb = lbase + IMG_BYTES + w * TB_BYTES;
+    const uint32_t tbw = tb + (lane >> 3) * 144 + (lane & 7) * 16;  // line layout: + 8 j rows
+    const uint32_t tbr = tb + r * 144 + hh * 16;                     // operand layout: lane (r, hh), k-step kk of the slice: + 32 kk
+    u32x4 xr[4];     // the B operands of a slice's 4 k-steps; each is replaced by the next slice's as soon as its k-step is done
+    // slice i of the block in xc -> the buffer, and its registers re-requested for the wave's next block (the store has read them)
+    auto tb_write = [&](auto M_, int vnext) __attribute__((always_inline)) {
+        constexpr int m = decltype(M_)::value, j = m & 3;
+        const uint32_t a = tbw;
+        const u32x4 d = xc[m];  // (plain copies first: a generic lambda does not capture what is only an asm operand)
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "a"(d), "n"(j * 8 * 144) : "memory");
+        xc[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, vnext + xoff(m), 0, 0);
+    };
+    auto tb_read = [&](auto KK_) __attribute__((always_inline)) {
+        constexpr int kk = decltype(KK_)::value;
+        const uint32_t a = tbr;
+        u32x4 d;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(d) : "v"(a), "n"(kk * 32));
+        xr[kk] = d;
+    };
+
     // fragment read into the ring (slot g of a phase: fragment index frag0 + g)
-    u32x4 wfr[8];
+    constexpr int NWF = 6;  // ring entries: PFD in flight + the one in use
+    u32x4 wfr[NWF];
     auto rd1 = [&](auto G_) __attribute__((always_inline)) {  // phase 1: fragment g
         constexpr int g = decltype(G_)::value;
-        u32x4& d = wfr[g & 7];
+        u32x4& d = wfr[g % NWF];
         if constexpr (g < 64) {
             const uint32_t a = fa;
             DSR128(d, a, g * 1024);
@@ -341,34 +393,34 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     };
     auto rd2 = [&](auto G_) __attribute__((always_inline)) {  // phase 2: gate fragment g
         constexpr int g = decltype(G_)::value;
-        u32x4& d = wfr[g & 7];
+        u32x4& d = wfr[g % NWF];
         const uint32_t a = fg;
         DSR128(d, a, g * 1024);
     };
     constexpr int PFD = 5;  // fragments requested ahead of the MFMA that uses them
 
-    // phase 1 of a block: H = W1 x^T + b1: the bias k-step, then KS k-steps, 4 hidden tiles each.  A k-step that is done with its chunk
-    // requests the next block's in place.  With PIPE the gate arithmetic, the logit and the pooling of the block BEFORE
-    // (in G and Hp) ride in the gaps of the MFMA stream.
-    auto phase1 = [&](auto PIPE_, int vnext, int blk_prev) __attribute__((always_inline)) {
+    // phase 1 of a block: H = W1 x^T + b1: the bias k-step, then NSLICE slices of 4 k-steps, 4 hidden tiles each.  The transposition
+    // buffer holds the slice being multiplied until its last operand has been read (position 0 of the slice), then takes the next slice
+    // (positions 1 .. 4: stores + re-requests), whose operands replace this slice's one by one as their k-steps finish (positions 5, 9,
+    // 13 and position 0 of the next slice) -- in order in the wave's LDS queue, so no waits.  Under the last slice it is slice 0 of the
+    // wave's NEXT block (its lines were re-requested a block ago).  With PIPE the gate arithmetic, the logit and the pooling of the
+    // block BEFORE (in G and Hp) ride in the gaps of the MFMA stream.
+    auto phase1 = [&](auto PIPE_, int vnext, int vnext2, int blk_prev) __attribute__((always_inline)) {
         constexpr bool PIPE = decltype(PIPE_)::value;
         constexpr int NSL = 4 * (KS + 1);
         constexpr int BUD = (p1_total() + NSL - 1) / NSL > 24 ? (p1_total() + NSL - 1) / NSL : 24;  // cycles of vector work per slot
         sfor<0, PFD>(rd1);
         sfor<0, NSL>([&](auto G_) __attribute__((always_inline)) {
             constexpr int g = decltype(G_)::value, k = (g >> 2) - 1, T = g & 3;
-            if constexpr (g + PFD < NSL) {
-                rd1(std::integral_constant<int, g + PFD>{});
-                LGKM(PFD);
-            } else {
-                LGKM(NSL - 1 - g);
-            }
-            if constexpr (k < 0) {
-                H[T] = mfma32(wfr[g & 7], ones, zero16);
-            } else {
-                H[T] = mfma32(wfr[g & 7], x[k], H[T]);
-                if constexpr (T == 3) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, vnext + k * 32, 0, 0);
-            }
+            constexpr int sl = k < 0 ? -1 : k >> 2, u = g < 4 ? -1 : (g - 4) & 15;   // slice of this slot, position in it
+            if constexpr (g + PFD < NSL) rd1(std::integral_constant<int, g + PFD>{});
+            if constexpr (u == 0) tb_read(std::integral_constant<int, 3>{});
+            // (slices 1 .. of this block free their registers for the next block; slice 0 of the NEXT block frees them for the one after)
+            if constexpr (u >= 1 && u <= 4) tb_write(std::integral_constant<int, 4 * ((sl + 1) % NSLICE) + u - 1>{}, sl + 1 < NSLICE ? vnext : vnext2);
+            if constexpr (u == 5 || u == 9 || u == 13) tb_read(std::integral_constant<int, (u - 5) / 4>{});
+            LGKM(p1_lgkm<KS>(g, PFD));
+            if constexpr (k < 0) H[T] = mfma32(wfr[g % NWF], ones, zero16);
+            else H[T] = mfma32(wfr[g % NWF], xr[k & 3], H[T]);
             if constexpr (PIPE) {
                 constexpr int lo = g == 0 ? 0 : dealt(p1_cost, P1_NU, BUD, g - 1), hi = g == NSL - 1 ? P1_NU : dealt(p1_cost, P1_NU, BUD, g);
                 sfor<lo, hi>([&](auto U_) __attribute__((always_inline)) { p1_uop(U_, blk_prev); });
@@ -390,8 +442,8 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
             } else {
                 LGKM(NSL - 1 - g);
             }
-            if constexpr (kk < 0) G[t] = mfma32(wfr[g & 7], ones, zero16);
-            else G[t] = mfma32(wfr[g & 7], hf[kk], G[t]);
+            if constexpr (kk < 0) G[t] = mfma32(wfr[g % NWF], ones, zero16);
+            else G[t] = mfma32(wfr[g % NWF], hf[kk], G[t]);
             // (24 cycles' worth a slot: the operand of k-step kk = 2 T + s is packed 80 (2 T + s + 1) cycles into the list, k-step kk starts at
             //  slot 4 (kk + 1): always in time)
             constexpr int lo = g == 0 ? 0 : dealt(p2_cost, P2_NU, 24, g - 1), hi = dealt(p2_cost, P2_NU, 24, g);
@@ -408,15 +460,24 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     auto step = [&](auto PIPE_, int s) __attribute__((always_inline)) {
         const int blk = gw + s * p.nwaves;
         const int vnext = s + 1 < nstep && !p.no_traffic ? (blk + p.nwaves) * 32 * S0 * 2 + vrow : OOR;
-        phase1(PIPE_, vnext, blk - p.nwaves);
+        const int vnext2 = s + 2 < nstep && !p.no_traffic ? (blk + 2 * p.nwaves) * 32 * S0 * 2 + vrow : OOR;
+        phase1(PIPE_, vnext, vnext2, blk - p.nwaves);
         if (s < 4) ASTAMP(3 + 3 * s);
         phase2();
         if (s < 4) ASTAMP(4 + 3 * s);
     };
     ASTAMP(2);
     if (nstep > 0) {
-        step(std::false_type{}, 0);
-        for (int s = 1; s < nstep; ++s) step(std::true_type{}, s);
+        {   // the first block's slice 0 (later blocks: under the last slice of the block before)
+            const int v1 = nstep > 1 && !p.no_traffic ? (gw + p.nwaves) * 32 * S0 * 2 + vrow : OOR;
+            sfor<0, 4>([&](auto J_) __attribute__((always_inline)) { tb_write(J_, v1); });
+            sfor<0, 3>(tb_read);
+        }
+        // one loop body for every block: the first carries the (masked) vector work of a block that does not exist -- a separate plain
+        // first step costs hipcc ~70 registers spilled and reloaded around the loop
+#pragma unroll
+        for (int T = 0; T < 4; ++T) G[T] = Hp[T] = zero16;
+        for (int s = 0; s < nstep; ++s) step(std::true_type{}, s);
         drain(gw + (nstep - 1) * p.nwaves);
     }
     ASTAMP(15);
@@ -436,7 +497,9 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
         if (hh == 0) red[4 * 32 * RS + w * 32 + r] = lsum;
     }
     __syncthreads();
-    float* pw = p.partials + (int64_t)blockIdx.x * PSTRIDE;
+    const bool fused = p.ticket != nullptr;
+    float* pw = p.partials + (int64_t)blockIdx.x * (fused ? PSTRIDE_F : PSTRIDE);
+    float* pacc = pw + (fused ? 4 : 2);
     {
         // thread (half, col): rows [64 half, 64 half + 64) of column col, in row order; the two halves are added by half 0
         const int col = tid & 127, half = tid >> 7;
@@ -452,7 +515,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
         if (lane == 0) ex[256 + w] = l2;
         __syncthreads();
         // (agent-scope relaxed stores = sc1 stores: they leave the XCD's L2, the merging workgroup reads them with sc1 loads and no fence)
-        if (tid < S1) __hip_atomic_store(&pw[2 + tid], ex[tid] + ex[S1 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < S1) __hip_atomic_store(&pacc[tid], ex[tid] + ex[S1 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) {
             __hip_atomic_store(&pw[0], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every partial against the same shift
             __hip_atomic_store(&pw[1], (ex[256] + ex[257]) + (ex[258] + ex[259]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -462,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     //      applies the bag classifier, softmax and argmax.  Hand-off without fences (MI355X_MICROARCH.md, hand-off table row 1): sc1 stores,
     //      every storing wave waits vmcnt(0), workgroup barrier, ONE agent-scope atomic per workgroup; the workgroup whose add came
     //      last reads with sc1 loads after a workgroup barrier.  The ticket starts at zero and the last arriver puts it back.
-    if (!p.ticket) return;
+    if (!fused) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ASTAMP(16);
     __syncthreads();
@@ -477,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     if (!*flag) return;
     {
         const int Gn = gridDim.x;
-        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)p.partials, 0, Gn * PSTRIDE * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)p.partials, 0, Gn * PSTRIDE_F * 4, 0x00020000);
         constexpr int SC1 = 16;
         // 32 threads x 16 B cover the 128 sums of one partial, 8 partials per pass; all of a thread's share is requested at once
         // (rows past Gn are out of the buffer's range and read as zero); summed in partial order: deterministic
@@ -485,12 +548,20 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         f32x4 rowv[32];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) rowv[i] = ld4(prs, ((part + 8 * i) * PSTRIDE + 2 + 4 * c4) * 4);  // (rows 520 B apart: 8-byte aligned)
-        // the classifier rows this wave will need (classes w, w + 4): requested now, with the partials -- one round trip, not two
-        const int k0 = w, k1 = w + 4;
-        const float wc0a = k0 < p.C ? p.wcls[(int64_t)k0 * S1 + lane] : 0.f, wc0b = k0 < p.C ? p.wcls[(int64_t)k0 * S1 + lane + 64] : 0.f;
-        const float wc1a = k1 < p.C ? p.wcls[(int64_t)k1 * S1 + lane] : 0.f, wc1b = k1 < p.C ? p.wcls[(int64_t)k1 * S1 + lane + 64] : 0.f;
-        float lv = tid < Gn ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, tid * PSTRIDE * 4 + 4, 0, SC1)) : 0.f;
+        for (int i = 0; i < 32; ++i)
+            rowv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, ((part + 8 * i) * PSTRIDE_F + 4 + 4 * c4) * 4, 0, SC1));
+        float lv = tid < Gn ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, tid * PSTRIDE_F * 4 + 4, 0, SC1)) : 0.f;
+        // the classifier (<= 8 classes: wave 0 keeps all of it in registers, requested now, with the partials -- one round trip, not two)
+        constexpr int CF = 8;
+        const bool small_c = p.C <= CF;
+        float wca[CF], wcb[CF], bcl[CF];
+#pragma unroll
+        for (int k = 0; k < CF; ++k) {
+            const bool on = small_c && w == 0 && k < p.C;
+            wca[k] = on ? p.wcls[(int64_t)k * S1 + lane] : 0.f;
+            wcb[k] = on ? p.wcls[(int64_t)k * S1 + lane + 64] : 0.f;
+            bcl[k] = on ? p.bcls[k] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < 32; ++i) a += rowv[i];
         ASTAMP(18);
@@ -513,29 +584,64 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
         }
         __syncthreads();
         ASTAMP(19);
-        for (int k = w; k < p.C; k += 4) {
-            const float wa = k == k0 ? wc0a : k == k1 ? wc1a : p.wcls[(int64_t)k * S1 + lane];
-            const float wb = k == k0 ? wc0b : k == k1 ? wc1b : p.wcls[(int64_t)k * S1 + lane + 64];
-            float v = Ms[lane] * wa + Ms[lane + 64] * wb;
-            v = wave_sum_dpp(v);
-            if (lane == 0) Ls[k] = v + p.bcls[k];
-        }
-        __syncthreads();
-        if (tid == 0) {
+        if (small_c) {
+            if (w != 0) return;
+            const float m0 = Ms[lane], m1 = Ms[lane + 64];
+            float lg[CF];
             float lm = -INFINITY;
             int arg = 0;
-            for (int k = 0; k < p.C; ++k)
-                if (Ls[k] > lm) {
-                    lm = Ls[k];
-                    arg = k;
+#pragma unroll
+            for (int k = 0; k < CF; ++k) {
+                lg[k] = 0.f;
+                if (k < p.C) {  // (uniform)
+                    lg[k] = wave_sum_dpp(m0 * wca[k] + m1 * wcb[k]) + bcl[k];
+                    if (lg[k] > lm) {
+                        lm = lg[k];
+                        arg = k;
+                    }
                 }
-            float se = 0.f;
-            for (int k = 0; k < p.C; ++k) se += expf(Ls[k] - lm);
-            for (int k = 0; k < p.C; ++k) {
-                p.logits[k] = Ls[k];
-                p.Y_prob[k] = expf(Ls[k] - lm) / se;
             }
-            p.Y_hat[0] = arg;
+            float ev[CF], se = 0.f;
+#pragma unroll
+            for (int k = 0; k < CF; ++k) {
+                ev[k] = 0.f;
+                if (k < p.C) {
+                    ev[k] = expf(lg[k] - lm);
+                    se += ev[k];
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < CF; ++k)
+                    if (k < p.C) {
+                        p.logits[k] = lg[k];
+                        p.Y_prob[k] = ev[k] / se;
+                    }
+                p.Y_hat[0] = arg;
+            }
+        } else {
+            for (int k = w; k < p.C; k += 4) {
+                float v = Ms[lane] * p.wcls[(int64_t)k * S1 + lane] + Ms[lane + 64] * p.wcls[(int64_t)k * S1 + lane + 64];
+                v = wave_sum_dpp(v);
+                if (lane == 0) Ls[k] = v + p.bcls[k];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float lm = -INFINITY;
+                int arg = 0;
+                for (int k = 0; k < p.C; ++k)
+                    if (Ls[k] > lm) {
+                        lm = Ls[k];
+                        arg = k;
+                    }
+                float se = 0.f;
+                for (int k = 0; k < p.C; ++k) se += expf(Ls[k] - lm);
+                for (int k = 0; k < p.C; ++k) {
+                    p.logits[k] = Ls[k];
+                    p.Y_prob[k] = expf(Ls[k] - lm) / se;
+                }
+                p.Y_hat[0] = arg;
+            }
         }
         ASTAMP(20);
     }
@@ -544,7 +650,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
 template <int KS>
 int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, float* partials, int* n_partials,
            unsigned* ticket, float* M, float* logits, float* Y_prob, int64_t* Y_hat, hipStream_t st) {
-    constexpr int lds = image_bytes(KS);
+    constexpr int lds = image_bytes(KS) + 4 * TB_BYTES;
     constexpr int lds_alloc = lds > 72 * 1024 ? lds : 72 * 1024;  // (the reduction at the end uses 66.5 KiB of it)
     auto k = abmil32_kernel<KS>;
     static DevOnce once;

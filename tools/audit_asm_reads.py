@@ -33,6 +33,11 @@ for i, l in enumerate(src):
         if m:
             regs = set(range(int(m.group(2)), int(m.group(3)) + 1)) if m.group(2) else {int(m.group(4))}
             queue.append((i + 1, regs))
+        m = re.match(r"ds_read\w* a\[(\d+):(\d+)\],", t)  # (accumulator-file destination: registers 1000 + n)
+        if m:
+            queue.append((i + 1, set(range(1000 + int(m.group(1)), 1000 + int(m.group(2)) + 1))))
+        if re.match(r"ds_write", t):  # an asm store sits in the same in-order queue: counted, nothing lands in registers
+            queue.append((i + 1, set()))
         m = re.match(r"global_load\w* (v\[(\d+):(\d+)\]|v(\d+)),", t)
         if m and not t.startswith("global_load_lds"):  # (LDS-DMA: the first operand is the address, nothing lands in registers)
             regs = set(range(int(m.group(2)), int(m.group(3)) + 1)) if m.group(2) else {int(m.group(4))}
