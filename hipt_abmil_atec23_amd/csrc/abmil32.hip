@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     {
         const int v0 = nstep > 0 && !p.no_traffic ? gw * 32 * S0 * 2 + vrow : OOR;  // (no block: out of range, zeros)
 #pragma unroll
-        for (int m = 0; m < KS; ++m) xc[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + xoff(m), 0, 0);
+        for (int m = 0; m < KS; ++m) xc[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + xoff(m), 0, 2);
     }
     // s_waitcnt vmcnt(KS) as the builtin (vmcnt = bits 15:14 | 3:0; expcnt, lgkmcnt: no wait): hipcc's own wait-count bookkeeping sees
     // it -- behind an opaque asm wait it would take every load as still in flight and open each step with vmcnt(0)
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
         const uint32_t a = tbw;
         const u32x4 d = xc[m];  // (plain copies first: a generic lambda does not capture what is only an asm operand)
         asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "a"(d), "n"(j * 8 * 144) : "memory");
-        xc[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, vnext + xoff(m), 0, 0);
+        xc[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, vnext + xoff(m), 0, 2);
     };
     auto tb_read = [&](auto KK_) __attribute__((always_inline)) {
         constexpr int kk = decltype(KK_)::value;
@@ -467,6 +467,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
         if (s < 4) ASTAMP(4 + 3 * s);
     };
     ASTAMP(2);
+    if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 24 + 21] = __builtin_amdgcn_s_memtime();
     if (nstep > 0) {
         {   // the first block's slice 0 (later blocks: under the last slice of the block before)
             const int v1 = nstep > 1 && !p.no_traffic ? (gw + p.nwaves) * 32 * S0 * 2 + vrow : OOR;
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
         drain(gw + (nstep - 1) * p.nwaves);
     }
     ASTAMP(15);
+    if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 24 + 22] = __builtin_amdgcn_s_memtime();
     if (p.attention_only) return;
 
     // ---- this workgroup's partial: sum over the rows (= lanes) of every wave, then over the 4 waves, through LDS (weights are dead) ----
@@ -717,7 +719,12 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
             if (h[b * 24] < t0) t0 = h[b * 24];
         // per stamp: mean and maximum over the workgroups of (stamp - earliest start), us
         fprintf(stderr, "[abmil32 N=%d grid=%d] stamp: mean / max us since the first workgroup started (0 start, 1 weights staged, 2 loop, 3+3s phase 1, 4+3s gate GEMM, 5+3s gate+pool, 15 loop end, 16 partial stored, 17 ticket taken; last workgroup: 18 partials read, 19 M, 20 done)\n", N, grid);
-        for (int k2 = 0; k2 < 24; ++k2) {
+        {   // shader clock over the main loop: s_memtime ticks (stamps 21, 22) per 100 MHz tick (stamps 2, 15)
+            double f = 0;
+            for (int b = 0; b < grid; ++b) f += (double)(h[b * 24 + 22] - h[b * 24 + 21]) / (double)(h[b * 24 + 15] - h[b * 24 + 2]) * 0.1 / grid;
+            fprintf(stderr, "   shader clock in the main loop: %.2f GHz\n", f);
+        }
+        for (int k2 = 0; k2 < 21; ++k2) {
             double sum = 0, mx = 0;
             int n = 0;
             for (int b = 0; b < grid; ++b) {

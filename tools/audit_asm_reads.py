@@ -38,15 +38,19 @@ for i, l in enumerate(src):
             queue.append((i + 1, set(range(1000 + int(m.group(1)), 1000 + int(m.group(2)) + 1))))
         if re.match(r"ds_write", t):  # an asm store sits in the same in-order queue: counted, nothing lands in registers
             queue.append((i + 1, set()))
-        m = re.match(r"global_load\w* (v\[(\d+):(\d+)\]|v(\d+)),", t)
+        m = re.match(r"(?:global|buffer)_load\w* (v\[(\d+):(\d+)\]|v(\d+)),", t)
         if m and not t.startswith("global_load_lds"):  # (LDS-DMA: the first operand is the address, nothing lands in registers)
             regs = set(range(int(m.group(2)), int(m.group(3)) + 1)) if m.group(2) else {int(m.group(4))}
             gqueue.append((i + 1, regs))
-        m = re.match(r"global_load\w* a\[(\d+):(\d+)\],", t)  # (accumulator-file destination: registers 1000 + n below)
+        m = re.match(r"(?:global|buffer)_load\w* a\[(\d+):(\d+)\],", t)  # (accumulator-file destination: registers 1000 + n below)
         if m:
             gqueue.append((i + 1, set(range(1000 + int(m.group(1)), 1000 + int(m.group(2)) + 1))))
         if "XOP_FENCE" in t:
             gqueue = []
+        mk = re.search(r"XOP_KEEP (\d+)", t)  # a hand-written vmcnt wait that leaves only the youngest n asm loads in flight
+        if mk:
+            n = int(mk.group(1))
+            gqueue = gqueue[len(gqueue) - n:] if n > 0 else []
         for mm in re.finditer(r"lgkmcnt\((\d+)\)", t):
             n = int(mm.group(1))
             queue = queue[len(queue) - n:] if n > 0 else []
