@@ -527,6 +527,21 @@ def main():
         one = region[:1]
         model.streams = 1
         ex["batch1_regions_per_s"] = 1.0 / timed(lambda: model(one), 10)  # extract_features_fp.py:159-171: batch_size 1
+        if region.shape[0] >= 8:
+            # the same one-region loader batches through feature_store.extract_slide's loop, which gathers 8 of them per call
+            # (same files bit for bit: tests/test_gpu_parity.py::test_extract_slide_gathered_calls_write_the_same_bits)
+            import tempfile
+            from hipt_abmil_atec23_amd.feature_store import extract_slide
+            model.streams = args.streams
+            loader = [(region[i:i + 1], torch.tensor([[4096 * i, 0]])) for i in range(8)] * 2
+            with tempfile.TemporaryDirectory() as td:
+                extract_slide(model, loader[:8], td, "warm")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                extract_slide(model, loader, td, "timed")
+                torch.cuda.synchronize()
+                ex["batch1_loader_gathered_regions_per_s"] = len(loader) / (time.perf_counter() - t0)  # incl. the .pt write
+            model.streams = 1
         if not args.u8:
             model.set_compute_dtype("fp32")  # the reference's own precision (exact-fp32 MFMA kernels, 1e-4 parity mode)
             t32 = timed(lambda: model(one), 2, warm=1)

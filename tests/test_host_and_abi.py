@@ -186,6 +186,36 @@ def test_feature_store_roundtrip_and_subsampling(tmp_path):
     assert out.shape == (4, 4) and torch.equal(out[:, 0], torch.tensor([1., 1., 2., 2.]))
 
 
+def test_extract_slide_coalesces_batch_one_loader_batches(tmp_path):
+    """The reference's loader yields one region per batch (extract_features_fp.py:128, 159-171); extract_slide gathers
+    consecutive batches into calls of `coalesce` regions -- same files, same order, fewer calls; a batch of another shape or
+    type is never merged."""
+    from hipt_abmil_atec23_amd.feature_store import extract_slide
+    calls = []
+
+    def model(r):
+        calls.append(tuple(r.shape))
+        return r.float().mean(dim=(1, 2, 3)).unsqueeze(1).repeat(1, 4)
+
+    def loader(n, shape=(3, 8, 8), dtype=torch.float32):
+        return [(torch.full((1,) + shape, float(k), dtype=dtype), torch.tensor([[k, 7 * k]])) for k in range(n)]
+
+    one = torch.load(extract_slide(model, loader(11), str(tmp_path), "one_by_one", coalesce=1))
+    assert calls == [(1, 3, 8, 8)] * 11
+    calls.clear()
+    got = torch.load(extract_slide(model, loader(11), str(tmp_path), "gathered"))      # default: 8 regions per call
+    assert calls == [(8, 3, 8, 8), (3, 3, 8, 8)] and torch.equal(got, one)
+    calls.clear()
+    mixed = loader(3) + loader(2, shape=(3, 4, 4)) + loader(2, dtype=torch.uint8) + loader(1, dtype=torch.uint8)
+    out = torch.load(extract_slide(model, mixed, str(tmp_path), "mixed", coalesce=4))
+    assert calls == [(3, 3, 8, 8), (2, 3, 4, 4), (3, 3, 8, 8)] and out.shape == (8, 4)
+    assert torch.equal(out[:, 0], torch.tensor([0., 1., 2., 0., 1., 0., 1., 0.]))
+    calls.clear()
+    big = [(torch.ones(3, 3, 8, 8), torch.zeros(3, 2)), (torch.ones(6, 3, 8, 8), torch.zeros(6, 2)), (torch.ones(1, 3, 8, 8), torch.zeros(1, 2))]
+    torch.load(extract_slide(model, big, str(tmp_path), "big", coalesce=8))             # loader batches are never split
+    assert calls == [(9, 3, 8, 8), (1, 3, 8, 8)]
+
+
 def test_prepare_img_tensor_uint8_interleaved():
     from hipt_abmil_atec23_amd import HIPT_4K
     h = HIPT_4K(None, None, "cpu", "cpu")
