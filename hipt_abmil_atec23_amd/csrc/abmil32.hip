@@ -718,7 +718,7 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
         for (int b = 0; b < grid; ++b)
             if (h[b * 24] < t0) t0 = h[b * 24];
         // per stamp: mean and maximum over the workgroups of (stamp - earliest start), us
-        fprintf(stderr, "[abmil32 N=%d grid=%d] stamp: mean / max us since the first workgroup started (0 start, 1 weights staged, 2 loop, 3+3s phase 1, 4+3s gate GEMM, 5+3s gate+pool, 15 loop end, 16 partial stored, 17 ticket taken; last workgroup: 18 partials read, 19 M, 20 done)\n", N, grid);
+        fprintf(stderr, "[abmil32 N=%d grid=%d] stamp: mean / max us since the first workgroup started (0 start, 1 weights staged, 2 loop, 3+3s phase 1 of step s, 4+3s its gate GEMM, 15 loop end incl. the drain, 16 partial stored, 17 ticket taken; last workgroup: 18 partials read, 19 M, 20 done)\n", N, grid);
         {   // shader clock over the main loop: s_memtime ticks (stamps 21, 22) per 100 MHz tick (stamps 2, 15)
             double f = 0;
             for (int b = 0; b < grid; ++b) f += (double)(h[b * 24 + 22] - h[b * 24 + 21]) / (double)(h[b * 24 + 15] - h[b * 24 + 2]) * 0.1 / grid;

@@ -23,6 +23,10 @@ rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 echo "SQ pass done"
 rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_ACTIVE -d $REPO/gpurun_out/pmc_grbm_$TAG -o pmc -- $CMD > $REPO/gpurun_out/pmc_grbm_$TAG.log 2>&1
 echo "GRBM pass done"
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS -d $REPO/gpurun_out/pmc_lds_$TAG -o pmc -- $CMD > $REPO/gpurun_out/pmc_lds_$TAG.log 2>&1 || echo "LDS pass failed (counter names)"
+echo "LDS pass done"
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $REPO/gpurun_out/pmc_wait_$TAG -o pmc -- $CMD > $REPO/gpurun_out/pmc_wait_$TAG.log 2>&1 || echo "wait pass failed (counter names)"
+echo "wait pass done"
 cd $REPO
 # keep only the CSVs the summariser reads (the merge back is capped at 64 MiB)
 find gpurun_out -name "*.db" -delete 2>/dev/null || true

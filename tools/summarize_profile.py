@@ -4,7 +4,7 @@
     python tools/summarize_profile.py r01
 
 Reads   gpurun_out/prof_<tag>/**/_kernel_stats.csv          (--kernel-trace --stats)
-        gpurun_out/pmc_{fetch,write,sq,grbm}_<tag>/**/_counter_collection.csv   (separate --pmc passes)
+        gpurun_out/pmc_{fetch,write,sq,grbm,lds,wait}_<tag>/**/_counter_collection.csv   (separate --pmc passes)
 Writes  profiles/<tag>_kernel_stats.csv   our kernels only, per-kernel calls / total / average duration
         profiles/<tag>_pmc.csv            per-kernel medians of the counters
         profiles/<tag>_traffic.json       per-launch HBM bytes of the hot kernels, corrected as
@@ -51,7 +51,7 @@ if stats:
     print("wrote", f"profiles/{tag}_kernel_stats.csv", len(rows), "kernels")
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for kind in ("fetch", "write", "sq", "grbm"):
+for kind in ("fetch", "write", "sq", "grbm", "lds", "wait"):
     for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{kind}_{tag}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if ours(r["Kernel_Name"]):
