@@ -80,6 +80,8 @@ class HIPT_4K(torch.nn.Module):
         region = batch.to(d256, non_blocking=True).detach()
         region = region.contiguous() if u8 else region.float().contiguous()
         N.require_cuda(region, "HIPT_4K")
+        if region.data_ptr() % 16:  # a view that starts off the 16-byte grid (the kernels load 16 bytes at a time): one aligned copy
+            region = region.clone()
         per = w_256 * h_256
         nseq = nreg * per
         W, H = (region.shape[1], region.shape[2]) if hwc else (region.shape[2], region.shape[3])
@@ -91,6 +93,10 @@ class HIPT_4K(torch.nn.Module):
         if d256 == d4k:
             m256, m4k = self.model256, self.model4k
             pk256 = m256._packed_for(m256._pos_for(256, 256, 256))
+            # fewer regions than streams: the patches are spread over the streams (decided before anything is allocated or packed for
+            # the whole-region path: that path's `out` and ViT-4K image are not used there)
+            if int(self.streams) > nreg and nseq >= 32 * int(self.streams):
+                return self._run_patch_split(region, u8, hwc, nreg, w_256, h_256, W, H, pk256, d256, want_cls256)
             pk4k = m4k._packed_for(m4k._pos_for(per, w_256, h_256))
             out = torch.empty((nreg, pk4k.w.dim), dtype=torch.float32, device=d4k)
             cls256 = torch.empty((nseq, pk256.w.dim), dtype=torch.float32, device=d256) if want_cls256 else None
@@ -109,8 +115,6 @@ class HIPT_4K(torch.nn.Module):
                     N.call("hipt_hipt4k_forward", pk256.ref, pk4k.ref, N.ptr(region[lo:hi]), n, W, H, self.chunk, N.ptr(sub_cls),
                            N.ptr(out[lo:hi]), N.ptr(ws), ws.numel(), N.stream_ptr(d256))
 
-            if int(self.streams) > nreg and nseq >= 32 * int(self.streams):
-                return self._run_patch_split(region, u8, hwc, nreg, w_256, h_256, W, H, pk256, d256, want_cls256)
             parts = max(1, min(int(self.streams), nreg))
             if parts == 1:
                 launch(0, nreg, 0)
@@ -148,7 +152,8 @@ class HIPT_4K(torch.nn.Module):
         kind = (2 if hwc else 1) if u8 else 0
         cur = torch.cuda.current_stream(dev)
         # fp32 pixels and a patch embedding that reads them itself (csrc/embed32.hip): no copy in the compute dtype
-        px = (not u8) and N.lib().hipt_vit256_range_px_workspace_bytes(pk256.ref, C.byref(lay), 16, self.chunk) > 0
+        # (that kernel loads 16 bytes at a time: a region view that starts off a 16-byte boundary takes the converted copy instead)
+        px = (not u8) and region.data_ptr() % 16 == 0 and N.lib().hipt_vit256_range_px_workspace_bytes(pk256.ref, C.byref(lay), 16, self.chunk) > 0
         nb = 0 if px else N.lib().hipt_image_compute_bytes(pk256.ref, C.byref(lay), nseq, kind)
         img = region
         if nb:

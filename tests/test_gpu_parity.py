@@ -613,6 +613,28 @@ def test_extract_slide_to_feature_store_and_pool(hipt, tmp_path):
     assert logits.shape == (1, 2) and a_raw.shape == (1, 5) and abs(float(y_prob.sum()) - 1) < 1e-5
 
 
+def test_hipt4k_one_region_from_a_view_off_the_16_byte_grid(hipt):
+    """One region per call spreads its patches over the streams and embeds straight from the fp32 pixels with 16-byte loads;
+    a region view that starts 4 bytes off a 16-byte boundary must take the converted-copy route, not fail (and give the
+    same bits)."""
+    W = 2048
+    aligned = synth.hash_uniform_torch((1, 3, W, W), 17, device=DEV)
+    buf = torch.empty(3 * W * W + 4, dtype=torch.float32, device=DEV)
+    off = buf[1:1 + 3 * W * W].view(1, 3, W, W)
+    off.copy_(aligned)
+    assert aligned.data_ptr() % 16 == 0 and off.data_ptr() % 16 == 4
+    hipt.set_compute_dtype("bf16")
+    old = hipt.streams
+    hipt.streams = 2
+    try:
+        ref = hipt(aligned)
+        got = hipt(off)
+    finally:
+        hipt.streams = old
+        hipt.set_compute_dtype("fp32")
+    assert torch.equal(ref, got)
+
+
 def test_extract_slide_gathered_calls_write_the_same_bits(hipt, tmp_path):
     """Batch-1 loader batches gathered into one HIPT_4K call (feature_store.extract_slide) give bit for bit the features of
     the one-by-one loop, in fp32 and in bf16: a region's rows do not meet another region's anywhere on the path."""
