@@ -101,9 +101,10 @@ struct QkvAttnParams {
     int nseq;
     float sl2e;            // scale * log2(e)
     unsigned out_bytes;
-    int ngroups;           // groups of six workgroups (one head each) that walk the patches g, g + ngroups, ..
-    int xcd_groups;        // > 0: groups per XCD -- workgroup id -> XCD id % 8, slot id / 8: group xcd * xcd_groups + slot / 6, head slot % 6
-                           // (workgroups id and id + 8 share an XCD: the six heads of a patch then read its rows through ONE L2); 0: group id / 6
+    int nslots;            // workgroups per XCD: workgroup id -> XCD id % 8 (ids that differ by 8 share an XCD), slot id / 8
+    int px;                // patches per XCD: XCD x owns patches [x px, (x + 1) px); its work units (patch, head), head fastest, go round
+                           // its slots: slot j takes units j, j + nslots, .. -- the 32 units in flight on an XCD are 5-6 patches, whose
+                           // rows the six heads read through ONE L2 instead of from the fabric six times
     unsigned long long* stamps;  // diagnostic builds: per-workgroup cycle sums of the phases (8 per workgroup), or null
 };
 
@@ -127,7 +128,6 @@ struct QkvAttnParams {
         }                                                                       \
     } while (0)
 
-constexpr int NW = 8;  // waves per workgroup (two per SIMD, 256 registers each); a wave owns 32 tokens = one B operand
 
 // DBG (diagnostic builds only, HIPT_QKVATT_DBG): 1 = no weight DMA / ring syncs, 2 = no weight fragment reads, 4 = no attention
 // phase, 8 = no GEMM MFMAs, 16 = no [CLS]-query section, 32 = no exponentials, 64 = no operand loads -- timing ablations,
@@ -137,17 +137,16 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // this workgroup: ONE head of the patches of its group (kernel header: the six workgroups of a group share an XCD's L2)
+    // this workgroup's work units: (patch, head) pairs of its XCD (QkvAttnParams)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    auto unit_of = [&](int i, int& b_, int& h_) {  // the i-th unit of this workgroup; false: past the end
+        const int U = slot + p.nslots * i, bq = U / HEADS;
+        h_ = U - HEADS * bq;
+        b_ = xcd * p.px + bq;
+        return bq < p.px && b_ < p.nseq;
+    };
     int hs, g0;
-    if (p.xcd_groups > 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        hs = slot % HEADS;
-        g0 = xcd * p.xcd_groups + slot / HEADS;
-    } else {
-        hs = blockIdx.x % HEADS;
-        g0 = blockIdx.x / HEADS;
-    }
-    const int gstep = p.ngroups;
+    const bool any = unit_of(0, g0, hs);
 
     // ---- one-time LDS contents (no DMA in flight yet: plain stores) ----
     {
@@ -168,16 +167,21 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     const uint32_t lbase = lds_addr(smem);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.out_bytes, 0x00020000);
 
-    // ---- weight stream: the six units of head hs, round and round; unit n into ring slot n % 3; wave w moves pieces w, w + 8, w + 16 ----
-    int iU = 0, islot = 0;
+    // ---- weight stream: the six ring units of a work unit's head, work unit after work unit; ring unit n into ring slot n % 3; wave w moves
+    //      pieces w, w + 8, w + 16 ----
+    int iU = 0, islot = 0, ihs = hs, iwork = 0;  // ring unit / slot / head / work unit being requested
     auto issue_unit = [&]() __attribute__((always_inline)) {
-        const char* src = p.wpk + (size_t)(hs * 6 + iU) * UNIT + lane * 16;
+        const char* src = p.wpk + (size_t)(ihs * 6 + iU) * UNIT + lane * 16;
         char* dst = smem + islot * UNIT;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if constexpr ((DBG & 1) == 0) glds16(src + (w + 8 * j) * 1024, dst + (w + 8 * j) * 1024);
-        iU = iU + 1 == 6 ? 0 : iU + 1;
         islot = islot + 1 == 3 ? 0 : islot + 1;
+        if (++iU == 6) {  // on to the next work unit's head (past the last one: any head -- pieces nobody consumes)
+            iU = 0;
+            int nb_, nh_;
+            if (unit_of(++iwork, nb_, nh_)) ihs = nh_;
+        }
     };
     auto cls_dma = [&](int b, int par) __attribute__((always_inline)) {  // (wave 0) the [CLS] row of patch b -> LDS
         const char* src = p.qkv_cls + (size_t)b * (3 * D * 2) + lane * 16;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                    "+v"(xop[22]), "+v"(xop[23])::"memory")
 
     // ---- merge of the eight [CLS]-query partials of one patch: one wave, lane = output dimension ----
-    auto merge_cls = [&](int b, int pq) __attribute__((always_inline)) {
+    auto merge_cls = [&](int b, int hs, int pq) __attribute__((always_inline)) {
         int ln = lane;  // (opaque copy: see the patch loop)
         asm volatile("" : "+v"(ln));
         const uint32_t base = lbase + OFF_CLSP + pq * 8 * CLSP_W, obase = base + 16 + ln * 4;
@@ -246,8 +250,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
 
     QSTAMP_DECL;
     int pq = 0;          // parity of the patch counter: which [CLS] partial buffer / [CLS] row buffer
-    int prev_b = -1;     // patch whose partials wait for their merge
-    if (g0 >= p.nseq) return;  // (uniform: a workgroup without patches)
+    int prev_b = -1, prev_hs = 0;  // work unit whose partials wait for their merge
+    if (!any) return;  // (uniform: a workgroup without work)
     if (w == 0) cls_dma(g0, 0);
     issue_unit();
     issue_unit();
@@ -261,7 +265,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
 
     constexpr int PF = 7;          // weight fragments requested ahead of the MFMA that uses them (8 register sets)
     const f32x16 Z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int b = g0; b < p.nseq; b += gstep, pq ^= 1) {
+    int b = g0, nb = 0, nhs = 0, last_wi = 0;
+    bool nvalid = unit_of(1, nb, nhs);
+    for (int wi = 0;; ++wi, pq ^= 1) {
         // Per-lane addresses are re-derived per patch from an opaque copy of the lane id: left loop-invariant, hipcc hoists a
         // dozen of them out of the loop, spills them across the attention phase and reloads them inside the ring phases --
         // and every scratch reload waits vmcnt(0), i.e. for the weight stream.
@@ -344,8 +350,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                         // behind the first barrier of a patch every wave has left the previous patch's attention: its [CLS] partials are
                         // complete (merge them), the K / V images are free, and the other [CLS] row buffer is free (fetch the next
                         // patch's row)
-                        if (prev_b >= 0 && w == ((prev_b / gstep) & 7)) merge_cls(prev_b, pq ^ 1);
-                        if (w == 0 && b + gstep < p.nseq) cls_dma(b + gstep, pq ^ 1);
+                        if (prev_b >= 0 && w == ((wi - 1) & 7)) merge_cls(prev_b, prev_hs, pq ^ 1);
+                        if (w == 0 && nvalid) cls_dma(nb, pq ^ 1);
                     }
                 }
                 if constexpr (s == 23) {
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
             O[0][0] = __builtin_bit_cast(float, qop[0][0][0]);
             O[1][0] = __builtin_bit_cast(float, qop[1][1][3]);
             l = 1.f;
-            load_xop(b + gstep < p.nseq ? b + gstep : b);
+            load_xop(nvalid ? nb : b);
         } else {
         // ================= the [CLS] query against this wave's keys (wave 0: + the [CLS] key) =================
         // (first, while few registers are live: the partial is merged behind the next patch's first barrier)
@@ -587,8 +593,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         // tile kt + 1 run under the four MFMAs of tile kt, and in the second half the operands of the NEXT patch are requested
         // into the registers the spent score tiles leave (unconditionally -- past the last patch the current one again)
         {
-            const int nb = b + gstep < p.nseq ? b + gstep : b;
-            const int64_t Rn = (int64_t)nb * NTOK + 1 + 32 * w + r;
+            const int nb2 = nvalid ? nb : b;
+            const int64_t Rn = (int64_t)nb2 * NTOK + 1 + 32 * w + r;
             const char* x0 = p.xn + (Rn >> 4) * 12288 + (Rn & 15) * 16 + hh * 256;
             const char* x1 = x0 + 4096;
             const char* x2 = x0 + 8192;
@@ -646,11 +652,20 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         }
         QSTAMP(6);
         prev_b = b;
+        prev_hs = hs;
+        if (!nvalid) {
+            pq ^= 1;
+            last_wi = wi;
+            break;
+        }
+        b = nb;
+        hs = nhs;
+        nvalid = unit_of(wi + 2, nb, nhs);
     }
-    // ---- the last patch's [CLS] partials ----
+    // ---- the last work unit's [CLS] partials ----
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (prev_b >= 0 && w == ((prev_b / gstep) & 7)) merge_cls(prev_b, pq ^ 1);
+    if (prev_b >= 0 && w == (last_wi & 7)) merge_cls(prev_b, prev_hs, pq ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (continuous stream: pieces of units nobody consumes)
     if (QST_ON(p.stamps) && tid == 0)
         for (int k = 0; k < 8; ++k) p.stamps[(size_t)blockIdx.x * 8 + k] = st_sum[k];
@@ -706,17 +721,12 @@ int hipt_qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b
     p.sl2e = scale * 1.4426950408889634f;
     p.out_bytes = (unsigned)((int64_t)nseq * NTOK * D * 2);
     p.stamps = nullptr;
-    // groups of six workgroups: with whole XCDs to fill (8 XCDs x (CUs / 8 / 6) groups: 40 groups = 240 of 256 CUs on MI355X) the six
-    // heads of a patch are placed on one XCD, so that its rows come through ONE L2 instead of from the fabric six times
-    const int ncu = once.ncu[dev], per_xcd = (ncu / 8) / HEADS;
-    if (per_xcd > 0 && nseq >= 8 * per_xcd) {
-        p.xcd_groups = per_xcd;
-        p.ngroups = 8 * per_xcd;
-    } else {
-        p.xcd_groups = 0;
-        p.ngroups = nseq < ncu / HEADS ? nseq : (ncu / HEADS > 0 ? ncu / HEADS : 1);
-    }
-    const int grid = p.ngroups * HEADS;
+    // every CU gets a workgroup; the (patch, head) units of an eighth of the patches go round the workgroups of one XCD (QkvAttnParams)
+    const int ncu = once.ncu[dev];
+    p.px = (nseq + 7) / 8;
+    const int per = ncu / 8 > 0 ? ncu / 8 : 1;
+    p.nslots = p.px * HEADS < per ? p.px * HEADS : per;
+    const int grid = 8 * p.nslots;
 #ifdef HIPT_DEBUG_STAMPS  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
     static const bool want_stamps = getenv("HIPT_QKVATT_STAMPS") != nullptr;
     static unsigned long long* dbuf = nullptr;
@@ -742,7 +752,7 @@ int hipt_qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h, dbuf, (size_t)grid * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const double heads = (double)((nseq + p.ngroups - 1) / p.ngroups);
+        const double heads = (double)((p.px * HEADS + p.nslots - 1) / p.nslots);
         for (int b = 0; b < grid; ++b)
             for (int k = 0; k < 8; ++k) ph[k] += (double)h[b * 8 + k] / grid / heads;
         fprintf(stderr, "[qkv_attention nseq=%d grid=%d] cycles per (patch, head) (wave 0): GEMM units %.0f | [CLS] k/v + barrier %.0f | [CLS] query %.0f | scores %.0f | "
