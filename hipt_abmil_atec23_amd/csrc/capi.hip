@@ -256,10 +256,24 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
     q.A = x; q.lda = D; q.ln_w = b.ln1_w; q.ln_b = b.ln1_b; q.W = b.qkv_w; q.wpk = b.qkv_pk; q.N = 3 * D; q.bias = b.qkv_b;
     q.out = s.qkv; q.ldc = 3 * D;
     q.counter = (int*)s.hid + 16;
+    const void* att_rows = nullptr;  // [nseq, D] bf16: the attention output of the [CLS] tokens
     if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue (bf16 operands in s.att)
         q.A = s.att; q.ln_w = q.ln_b = nullptr;
         q.img = x_img ? 1 : 0;  // (x and the operands s.att change layout together)
-        {
+        const bool fuse = x_img && b.qkv_att_pk && hipt_qkv_attn_supported(w->dtype, D, w->heads, w->ntok) && !hipt_env_on("HIPT_NO_FUSED_ATTN");
+        if (fuse) {
+            // The fused kernel's [CLS]-only form: K and V of every token are computed per (patch, head) and consumed in place by the one
+            // query of the patch; q | k | v of the [CLS] rows themselves from the side GEMM, as in the other blocks.  Output: the
+            // attention rows of the [CLS] tokens, compact, in the (unused) qkv slot.
+            char* qa = (char*)s.hid + 4096 + al256((size_t)nseq * D * 4);
+            char* qcls = qa + al256((size_t)nseq * D * 2);
+            PROF(PC_LASTCLS, hipt_gather_cls_bf16_launch(s.att, qa, nseq, w->ntok, D, st, 1));
+            q.M = nseq; q.A = qa; q.out = qcls; q.img = 0; q.ldc = 3 * D;
+            q.counter = (int*)s.hid + 32;
+            PROF(PC_LASTCLS, hipt_seqgemm_launch(q, false, 0, st));
+            PROF(PC_LASTCLS, hipt_qkv_attn_cls_launch(s.att, b.qkv_att_pk, b.qkv_b, qcls, s.qkv, nseq, attn_scale(w), st));
+            att_rows = s.qkv;
+        } else {
             // Only token 0 of a sequence asks a question in this block: K and V for every row (columns 384.. of the QKV Linear: the
             // weight image of an N tile is the 98 304 bytes of its rows, so the tail of the image IS the [K; V] matrix), Q for the
             // [CLS] rows alone -- their operands gathered into the free hidden slot, a [nseq, 384] GEMM scattered to rows s * ntok
@@ -280,9 +294,12 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
         PROF(PC_QKV, hipt_seqgemm_launch(q, true, 0, st));
     }
     // (the [CLS]-row launches of the pruned block are booked apart: the per-kernel categories then hold full-size launches only)
-    PROF(PC_LASTCLS, hipt_attn_cls_launch(s.qkv, s.att, nullptr, nseq, w->ntok, w->heads, D / w->heads, attn_scale(w), st));
+    if (!att_rows) {
+        PROF(PC_LASTCLS, hipt_attn_cls_launch(s.qkv, s.att, nullptr, nseq, w->ntok, w->heads, D / w->heads, attn_scale(w), st));
+        att_rows = s.att;
+    }
     PROF(PC_OTHER, hipt_gather_cls_launch(x, xc, nseq, (int64_t)w->ntok * D, D, st, x_img ? 1 : 0));
-    q.M = nseq; q.A = s.att; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
+    q.M = nseq; q.A = att_rows; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
     q.counter = (int*)s.hid + 32;
     PROF(PC_LASTCLS, hipt_seqgemm_launch(q, false, 0, st));
     MlpParams m;

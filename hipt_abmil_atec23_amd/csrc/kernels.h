@@ -142,6 +142,7 @@ bool hipt_qkv_attn_supported(int dtype, int D, int heads, int ntok);
 size_t hipt_qkv_attn_packed_bytes();
 int hipt_qkv_attn_pack_launch(const void* qkv_w, void* packed, hipStream_t st);
 int hipt_qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b, const void* qkv_cls, void* out_img, int nseq, float scale, hipStream_t st);
+int hipt_qkv_attn_cls_launch(const void* xn_img, const void* wpk, const float* qkv_b, const void* qkv_cls, void* out_rows, int nseq, float scale, hipStream_t st);
 
 // attention of the [CLS] query only (bf16, head dim 64): out[B, heads*64] bf16 and/or probs[B, heads, ntok] fp32 (either may be null)
 int hipt_attn_cls_launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads, int dh, float scale, hipStream_t st);

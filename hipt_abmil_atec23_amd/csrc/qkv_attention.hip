@@ -132,8 +132,12 @@ struct QkvAttnParams {
 // DBG (diagnostic builds only, HIPT_QKVATT_DBG): 1 = no weight DMA / ring syncs, 2 = no weight fragment reads, 4 = no attention
 // phase, 8 = no GEMM MFMAs, 16 = no [CLS]-query section, 32 = no exponentials, 64 = no operand loads -- timing ablations,
 // the results are garbage
-template <int DBG>
+// CLSONLY: the [CLS]-pruned last block (capi.hip, run_last_block_cls): only token 0 of a patch asks a question there, so a work unit is the K
+// and V products of its head (4 of the 6 ring units), the [CLS] query against them, and ONE output row per patch, written compact [nseq, 384]
+// -- K and V of the block never reach HBM either (they were 0.8 GB written and 2.3 GB fetched by the one-query attention kernel).
+template <int DBG, bool CLSONLY = false>
 __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p) {
+    constexpr int NU = CLSONLY ? 4 : 6, NG = 24 * NU;  // ring units / GEMM steps of a work unit
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         for (int j = 0; j < 3; ++j)
             if constexpr ((DBG & 1) == 0) glds16(src + (w + 8 * j) * 1024, dst + (w + 8 * j) * 1024);
         islot = islot + 1 == 3 ? 0 : islot + 1;
-        if (++iU == 6) {  // on to the next work unit's head (past the last one: any head -- pieces nobody consumes)
+        if (++iU == NU) {  // on to the next work unit's head (past the last one: any head -- pieces nobody consumes)
             iU = 0;
             int nb_, nh_;
             if (unit_of(++iwork, nb_, nh_)) ihs = nh_;
@@ -244,7 +248,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         }
         const int64_t R = (int64_t)b * NTOK;  // the [CLS] row; column 64 hs + lane = chunk 8 hs + (lane >> 3), element lane & 7
         const int kc = 8 * hs + (ln >> 3);
-        bf16_t* dst = (bf16_t*)(p.out + (R >> 4) * 12288 + (kc >> 2) * 1024 + (kc & 3) * 256 + (R & 15) * 16) + (ln & 7);
+        bf16_t* dst = CLSONLY ? (bf16_t*)p.out + (int64_t)b * D + 64 * hs + ln
+                              : (bf16_t*)(p.out + (R >> 4) * 12288 + (kc >> 2) * 1024 + (kc & 3) * 256 + (R & 15) * 16) + (ln & 7);
         *dst = (bf16_t)(o / L);
     };
 
@@ -290,7 +295,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
             f32x4 bq[4];
             f32x16 acc;
             uint32_t sa = fa + cslot * UNIT, sn = sa;  // fragment base of the unit being consumed / of the next one
-            XOP_FENCE(8);  // (the eight youngest vector-memory operations are the previous patch's output stores: let them fly)
+            if constexpr (CLSONLY) XOP_FENCE(0);
+            else XOP_FENCE(8);  // (the eight youngest vector-memory operations are the previous patch's output stores: let them fly)
             sfor<0, PF>([&](auto G_) __attribute__((always_inline)) {
                 constexpr int g = decltype(G_)::value;
                 u32x4& d = wf[g & 7];
@@ -298,12 +304,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                 if constexpr ((DBG & 2) == 0) DSR128(d, a, g * 1024);
                 else d = xop[g];
             });
-            sfor<0, 144>([&](auto G_) __attribute__((always_inline)) {
+            sfor<0, NG>([&](auto G_) __attribute__((always_inline)) {
                 constexpr int g = decltype(G_)::value, u = g / 24, s = g % 24;
                 // LDS operations younger than fragment g at its wait: the PF fragments behind it, and -- during the first PF
                 // steps of a unit -- the bias reads of this unit and the K / V writes of the unit before (in-order queue)
                 constexpr int wprev = u == 0 ? 0 : (u <= 2 ? 2 : (u <= 4 ? 4 : 0));
-                constexpr int ahead = g + PF < 144 ? PF : 143 - g;
+                constexpr int ahead = g + PF < NG ? PF : NG - 1 - g;
                 if constexpr (s == 0) {
                     const uint32_t ba = lbase + OFF_BIAS + ((hs * 6 + u) * 2 + hh) * 64;
                     f32x4 &b0v = bq[0], &b1v = bq[1], &b2v = bq[2], &b3v = bq[3];
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                     DSR128(b2v, ba, 32);
                     DSR128(b3v, ba, 48);
                 }
-                if constexpr (g + PF < 144 && (DBG & 2) == 0) {
+                if constexpr (g + PF < NG && (DBG & 2) == 0) {
                     u32x4& d = wf[(g + PF) & 7];
                     if constexpr (s + PF < 24) {
                         const uint32_t a = sa;
@@ -394,6 +400,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
             });
         }
         QSTAMP(0);
+        // (the operands of the next work unit: requested here, landing under the [CLS] query; fenced at the head of the next unit)
+        if constexpr (CLSONLY) load_xop(nvalid ? nb : b);
         // ---- the [CLS] token's key and value of this head: K image tile 8 row 0, V image row 256 ----
         // (the row was fetched a patch ago; its q | k | v lie at 0 | 768 | 1536 bytes)
         if (w == 0 && r == 0) {  // lanes 0 and 32: the two lane halves of row 0; fragment f = (d tile f >> 1, k-step f & 1):
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
 
         f32x16 O[2];
         float l = 0.f;
-        if constexpr ((DBG & 4) != 0) {
+        if constexpr ((DBG & 4) != 0 && !CLSONLY) {
             O[0] = O[1] = Z16;
             O[0][0] = __builtin_bit_cast(float, qop[0][0][0]);
             O[1][0] = __builtin_bit_cast(float, qop[1][1][3]);
@@ -526,6 +534,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         };
         cls_query();
         QSTAMP(2);
+        if constexpr (!CLSONLY) {
         // ================= attention of this wave's 32 queries =================
         f32x16 S[9];
         float m;
@@ -634,10 +643,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
+        }  // (!CLSONLY)
         }
         QSTAMP(5);
         // store: registers 4 q ..+3 of tile t = dims 32 t + 8 q + 4 hh ..+3 = chunk 8 hs + 4 t + q, bytes 8 hh ..+7
-        {
+        if constexpr (!CLSONLY) {
             l += __shfl_xor(l, 32, 64);
             const float inv = 1.0f / l;
 #pragma unroll
@@ -684,7 +694,8 @@ int hipt_qkv_attn_pack_launch(const void* qkv_w, void* packed, hipStream_t st) {
     return HIPT_OK;
 }
 
-int hipt_qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b, const void* qkv_cls, void* out_img, int nseq, float scale, hipStream_t st) {
+static int qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b, const void* qkv_cls, void* out_img, int nseq, float scale, bool cls_only,
+                           hipStream_t st) {
     HIPT_CHECK_ARG(xn_img && wpk && qkv_b && qkv_cls && out_img && nseq > 0, "qkv_attention: null / empty argument");
     HIPT_CHECK_ARG(((int64_t)nseq * NTOK) % 16 == 0, "qkv_attention: activation images need whole 16-row fragments (nseq * 257 %% 16 == 0)");
     HIPT_CHECK_ARG((int64_t)nseq * NTOK * D * 2 < ((int64_t)1 << 32) - 65536, "qkv_attention: output image beyond 4 GiB");
@@ -693,7 +704,8 @@ int hipt_qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b
     static DevOnce once;
     HIPT_CUR_DEVICE(dev);
     if (!once.done[dev]) {
-        bool ok = hipFuncSetAttribute((const void*)qkv_attn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+        bool ok = hipFuncSetAttribute((const void*)qkv_attn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess &&
+                  hipFuncSetAttribute((const void*)qkv_attn_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
 #ifdef HIPT_DEBUG_STAMPS
 #define QKV_DBG_LIST(X) X(1) X(2) X(3) X(4) X(7) X(8) X(12) X(16) X(32) X(48) X(64) X(15)
 #define QKV_SETATTR(n) ok = ok && hipFuncSetAttribute((const void*)qkv_attn_kernel<n>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
@@ -719,7 +731,7 @@ int hipt_qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b
     p.out = (char*)out_img;
     p.nseq = nseq;
     p.sl2e = scale * 1.4426950408889634f;
-    p.out_bytes = (unsigned)((int64_t)nseq * NTOK * D * 2);
+    p.out_bytes = (unsigned)((int64_t)nseq * (cls_only ? 1 : NTOK) * D * 2);
     p.stamps = nullptr;
     // every CU gets a workgroup; the (patch, head) units of an eighth of the patches go round the workgroups of one XCD (QkvAttnParams)
     const int ncu = once.ncu[dev];
@@ -738,12 +750,13 @@ int hipt_qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b
 #endif
 #ifdef HIPT_DEBUG_STAMPS
     static const int dbg = getenv("HIPT_QKVATT_DBG") ? atoi(getenv("HIPT_QKVATT_DBG")) : 0;
-    auto k = qkv_attn_kernel<0>;
-#define QKV_PICK(n) if (dbg == n) k = qkv_attn_kernel<n>;
+    auto k = cls_only ? qkv_attn_kernel<0, true> : qkv_attn_kernel<0>;
+#define QKV_PICK(n) if (dbg == n && !cls_only) k = qkv_attn_kernel<n>;
     QKV_DBG_LIST(QKV_PICK)
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS_BYTES, st, p);
 #else
-    hipLaunchKernelGGL(qkv_attn_kernel<0>, dim3(grid), dim3(512), LDS_BYTES, st, p);
+    if (cls_only) hipLaunchKernelGGL((qkv_attn_kernel<0, true>), dim3(grid), dim3(512), LDS_BYTES, st, p);
+    else hipLaunchKernelGGL(qkv_attn_kernel<0>, dim3(grid), dim3(512), LDS_BYTES, st, p);
 #endif
     HIPT_CHECK_LAUNCH();
 #ifdef HIPT_DEBUG_STAMPS
@@ -761,4 +774,13 @@ int hipt_qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b
     }
 #endif
     return HIPT_OK;
+}
+
+int hipt_qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b, const void* qkv_cls, void* out_img, int nseq, float scale, hipStream_t st) {
+    return qkv_attn_launch(xn_img, wpk, qkv_b, qkv_cls, out_img, nseq, scale, false, st);
+}
+
+// the [CLS]-pruned block: out = the attention output of token 0 of every patch, compact [nseq, 384] bf16
+int hipt_qkv_attn_cls_launch(const void* xn_img, const void* wpk, const float* qkv_b, const void* qkv_cls, void* out_rows, int nseq, float scale, hipStream_t st) {
+    return qkv_attn_launch(xn_img, wpk, qkv_b, qkv_cls, out_rows, nseq, scale, true, st);
 }
