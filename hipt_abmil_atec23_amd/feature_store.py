@@ -68,8 +68,9 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
     call leaves the GPU a third idle (tile quantisation + launch latency of the small kernels: 175 regions/s against 285 at
     8+ regions per call).  Consecutive loader batches of the same shape and type are therefore gathered until ``coalesce``
     regions are at hand and go through ``model`` in ONE call; features and coordinates are appended in loader order, and a
-    region's features do not depend on what else is in the call (rows are independent through every kernel; tested bit for
-    bit), so the saved files are the ones the one-by-one loop writes.  ``coalesce <= 1`` restores the one-by-one loop."""
+    region's features do not depend on what else is in the call (rows are independent through every kernel), so the saved
+    files are the ones the one-by-one loop writes -- bit for bit for 4096 x 4096 regions (any patch count that is a multiple
+    of 16: both calls then take the same kernels; tested), to the bf16 bar otherwise.  ``coalesce <= 1`` restores the one-by-one loop."""
     w = FeatureWriter(feat_dir, slide_id)
     held: list = []  # (regions, coords) waiting for company
 

@@ -637,10 +637,12 @@ def test_hipt4k_one_region_from_a_view_off_the_16_byte_grid(hipt):
 
 def test_extract_slide_gathered_calls_write_the_same_bits(hipt, tmp_path):
     """Batch-1 loader batches gathered into one HIPT_4K call (feature_store.extract_slide) give bit for bit the features of
-    the one-by-one loop, in fp32 and in bf16: a region's rows do not meet another region's anywhere on the path."""
+    the one-by-one loop, in fp32 and in bf16: a region's rows do not meet another region's anywhere on the path.  (Regions of
+    16 patches: like a 4096 x 4096 region's 256, a multiple of 16, so that a call of one region and a call of four take the
+    same kernels -- the activation-image path needs whole 16-row fragments; other sizes agree to the bf16 bar only.)"""
     from hipt_abmil_atec23_amd.feature_store import extract_slide
     g = torch.Generator().manual_seed(11)
-    regions = torch.randint(0, 256, (5, 512, 512, 3), dtype=torch.uint8, generator=g).to(DEV)
+    regions = torch.randint(0, 256, (5, 1024, 1024, 3), dtype=torch.uint8, generator=g).to(DEV)
     batches = [(regions[i:i + 1], torch.tensor([[4096 * i, 0]])) for i in range(5)]
     for dt in ("fp32", "bf16"):
         hipt.set_compute_dtype(dt)
