@@ -859,6 +859,47 @@ def test_clam_sb_bf16_hipt_big_stream_kernel():
     assert torch.equal(a_sub[0], a_raw[0, :1000])  # rows are independent
 
 
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 97, 4 * 32 * 7 + 5])
+def test_clam_stream_kernel_ragged_bags_many_classes_and_the_bound(n):
+    """abmil32_kernel's edges: bags of less than one block, one block +- a row, a bag that leaves waves of the last workgroup
+    without a block; 9 classes (the general classifier of the in-kernel merge, > 8); and a module whose logit bound is too large
+    for the fixed-shift softmax must take the general kernels and agree with the streaming result of its rescaled twin."""
+    from hipt_abmil_atec23_amd import CLAM_SB
+    m = CLAM_SB(gate=True, size_arg="hipt_384", dropout=0.0, k_sample=1, n_classes=9).eval().to(DEV).set_compute_dtype("bf16")
+    sd = synth.make_state_dict(synth.clam_param_specs((384, 128, 64)), 384)
+    own = m.state_dict()
+    for k, v in sd.items():
+        if k in own and own[k].shape == v.shape:
+            own[k].copy_(v.to(DEV))
+    h = synth.hash_uniform_torch((n, 384), 70 + n, device=DEV)
+    with torch.no_grad():
+        logits, y_prob, y_hat, a_raw, res = m(h, return_features=True)
+        a_only = m(h, attention_only=True)
+    p = {k: v.detach().float().cpu().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    w1, b1 = p["attention_net.0.weight"], p["attention_net.0.bias"]
+    wa, ba = p["attention_net.2.attention_a.0.weight"], p["attention_net.2.attention_a.0.bias"]
+    wb, bb = p["attention_net.2.attention_b.0.weight"], p["attention_net.2.attention_b.0.bias"]
+    wc, bc = p["attention_net.2.attention_c.weight"], p["attention_net.2.attention_c.bias"]
+    wcl, bcl = p["classifiers.weight"], p["classifiers.bias"]
+    x = h.bfloat16().double().cpu().numpy()
+    r16 = lambda t: torch.from_numpy(t).bfloat16().double().numpy()
+    h1 = np.maximum(x @ r16(w1).T + b1, 0)
+    A = (np.tanh(r16(h1) @ r16(wa).T + ba) * (1 / (1 + np.exp(-(r16(h1) @ r16(wb).T + bb))))) @ wc.T + bc
+    pw = np.exp(A[:, 0] - A[:, 0].max())
+    M = (pw / pw.sum()) @ h1
+    lg = M @ wcl.T + bcl
+    assert md(a_raw, A.T) < 4e-2 and rel_l2(res["features"], M[None]) < 3e-3 and md(logits, lg[None]) < 2e-3, n
+    assert torch.equal(a_only, a_raw) and int(y_hat) == int(lg.argmax()) and abs(float(y_prob.sum()) - 1) < 1e-6
+    # a bound beyond the fixed-shift range: the same module with wc scaled up takes the general kernels
+    big = CLAM_SB(gate=True, size_arg="hipt_384", dropout=0.0, k_sample=1, n_classes=9).eval().to(DEV).set_compute_dtype("bf16")
+    big.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        big.attention_net[2].attention_c.weight.mul_(4.0)  # sum |wc| ~ 166
+        _, _, _, a_big, _ = big(h)
+    assert big._pack(h.device).logit_bound > 60
+    assert md(a_big, (A - bc).T * 4 + bc) < 0.2
+
+
 def test_clam_sb_training_shapes_outside_the_training_kernels_keep_autograd():
     """A gated CLAM_SB the training kernels do not take (9 classes > 8) must still train on the GPU: dropout active and
     gradients flowing through the PyTorch-op sequence, not a silent fall-through to the inference kernel."""
