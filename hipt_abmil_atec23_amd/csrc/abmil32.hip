@@ -505,9 +505,16 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     {
         // thread (half, col): rows [64 half, 64 half + 64) of column col, in row order; the two halves are added by half 0
         const int col = tid & 127, half = tid >> 7;
-        float a = 0.f;
-#pragma unroll 16
-        for (int j = 0; j < 64; ++j) a += red[(half * 64 + j) * RS + col];
+        // (four chains of 16, added in a fixed order: one chain of 64 is 64 dependent additions behind their LDS reads)
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            a0 += red[(half * 64 + j) * RS + col];
+            a1 += red[(half * 64 + 16 + j) * RS + col];
+            a2 += red[(half * 64 + 32 + j) * RS + col];
+            a3 += red[(half * 64 + 48 + j) * RS + col];
+        }
+        const float a = (a0 + a1) + (a2 + a3);
         float l2 = 0.f;
         if (col < 64) l2 = red[4 * 32 * RS + half * 64 + col];
         l2 = wave_sum_dpp(l2);  // (waves 0, 1: half 0; waves 2, 3: half 1; only the waves with col < 64 hold values)
@@ -608,7 +615,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
             for (int k = 0; k < CF; ++k) {
                 ev[k] = 0.f;
                 if (k < p.C) {
-                    ev[k] = expf(lg[k] - lm);
+                    ev[k] = __builtin_amdgcn_exp2f((lg[k] - lm) * LOG2E);  // (<= 0: no range issue; 1 ulp of v_exp_f32)
                     se += ev[k];
                 }
             }
