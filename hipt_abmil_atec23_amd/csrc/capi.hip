@@ -179,10 +179,8 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
                 char* qa = (char*)s.hid + 4096 + al256((size_t)nseq * D * 4);   // (the hidden slot is free on this path; its head holds tile queues)
                 char* qcls = qa + al256((size_t)nseq * D * 2);                   // [nseq, 3 D] bf16 + 1 KiB the kernel's row DMA may read past the end
                 PROF(PC_CLSROWS, hipt_gather_cls_bf16_launch(s.att, qa, nseq, w->ntok, D, st, 1));
-                q.M = nseq; q.A = qa; q.ln_w = q.ln_b = nullptr; q.out = qcls; q.img = 0;
-                q.counter = (int*)s.hid + 32;
-                PROF(PC_CLSROWS, hipt_seqgemm_launch(q, false, 0, st));
-                q.M = M; q.counter = (int*)s.hid + 16;
+                // (nseq rows are a handful of the streaming kernel's 192-row tiles -- 11 CUs for 2 048 patches; the generic GEMM tiles N as well)
+                PROF(PC_CLSROWS, linear(qa, D, b.qkv_w, D, b.qkv_b, nullptr, qcls, 3 * D, nseq, 3 * D, D, dt, 0, st));
                 PROF(PC_QKVATT, hipt_qkv_attn_launch(s.att, b.qkv_att_pk, b.qkv_b, qcls, s.qkv, nseq, scale, st));
                 att_out = s.qkv;
             } else if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue
@@ -268,9 +266,8 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
             char* qa = (char*)s.hid + 4096 + al256((size_t)nseq * D * 4);
             char* qcls = qa + al256((size_t)nseq * D * 2);
             PROF(PC_LASTCLS, hipt_gather_cls_bf16_launch(s.att, qa, nseq, w->ntok, D, st, 1));
-            q.M = nseq; q.A = qa; q.out = qcls; q.img = 0; q.ldc = 3 * D;
-            q.counter = (int*)s.hid + 32;
-            PROF(PC_LASTCLS, hipt_seqgemm_launch(q, false, 0, st));
+            PROF(PC_LASTCLS, linear(qa, D, b.qkv_w, D, b.qkv_b, nullptr, qcls, 3 * D, nseq, 3 * D, D, w->dtype, 0, st));
+            q.img = 0;
             PROF(PC_LASTCLS, hipt_qkv_attn_cls_launch(s.att, b.qkv_att_pk, b.qkv_b, qcls, s.qkv, nseq, attn_scale(w), st));
             att_rows = s.qkv;
         } else {
