@@ -296,9 +296,8 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
         att_rows = s.att;
     }
     PROF(PC_OTHER, hipt_gather_cls_launch(x, xc, nseq, (int64_t)w->ntok * D, D, st, x_img ? 1 : 0));
-    q.M = nseq; q.A = att_rows; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
-    q.counter = (int*)s.hid + 32;
-    PROF(PC_LASTCLS, hipt_seqgemm_launch(q, false, 0, st));
+    // (nseq rows: the generic GEMM tiles N as well -- see the side GEMM of the fused blocks)
+    PROF(PC_LASTCLS, linear(att_rows, D, b.proj_w, D, b.proj_b, nullptr, s.xn, D, nseq, D, D, w->dtype, 0, st));
     MlpParams m;
     memset(&m, 0, sizeof(m));
     m.x = xc; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;

@@ -871,8 +871,9 @@ int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     // of another stream (HIPT_4K spreads its regions over streams: +1.4 % regions/s at 8 regions per stream).
     const int tiles = (p.M + TMR - 1) / TMR;
     const int rem = tiles % ncu;
-    // (and a launch of at most four tiles -- the [CLS] rows of the pruned last block at one region per call -- is all 16-row tiles)
-    const int tail_tiles = tiles <= 4 ? tiles : ((tiles > ncu && tiles <= 4 * ncu + ncu / 8 && rem > 0 && rem <= ncu / 8) ? rem : 0);
+    // (and a launch of at most an eighth of a round -- the [CLS] rows of the pruned last block: 2 tiles at one region per call, 16 at
+    //  eight -- is all 16-row tiles: 8x the CUs, each with a pass over the weights and a fraction of the row phases)
+    const int tail_tiles = tiles <= ncu / 8 ? tiles : ((tiles > ncu && tiles <= 4 * ncu + ncu / 8 && rem > 0 && rem <= ncu / 8) ? rem : 0);
     p.full_tiles = tiles - tail_tiles;
     const int tail_rows = p.M - p.full_tiles * TMR;
     p.ntiles = p.full_tiles + (tail_rows > 0 ? (tail_rows + 15) / 16 : 0);
