@@ -340,7 +340,8 @@ def main():
     # itself, so the launch replays) and replayed between ONE HIP-event pair on the stream they run on -- no host time between the
     # launches, no event record per launch.  Rotating bags (5 x 77 MB > Infinity Cache).
     abmil_graph = None
-    if not dry and args.steps and rank == 0 and not args.no_extras:
+    # (single-process runs only: with a process group alive, RCCL's watchdog thread may touch the runtime while a capture is open)
+    if not dry and args.steps and world == 1 and not args.no_extras:
         try:
             KG, REP = 20, 5
             gs = torch.cuda.Stream()
