@@ -39,7 +39,7 @@ for i, l in enumerate(src):
         if re.match(r"ds_write", t):  # an asm store sits in the same in-order queue: counted, nothing lands in registers
             queue.append((i + 1, set()))
         m = re.match(r"(?:global|buffer)_load\w* (v\[(\d+):(\d+)\]|v(\d+)),", t)
-        if m and not t.startswith("global_load_lds"):  # (LDS-DMA: the first operand is the address, nothing lands in registers)
+        if m and not t.startswith("global_load_lds") and not t.endswith(" lds"):  # (LDS-DMA: the first operand is the address, nothing lands in registers)
             regs = set(range(int(m.group(2)), int(m.group(3)) + 1)) if m.group(2) else {int(m.group(4))}
             gqueue.append((i + 1, regs))
         m = re.match(r"(?:global|buffer)_load\w* a\[(\d+):(\d+)\],", t)  # (accumulator-file destination: registers 1000 + n below)
