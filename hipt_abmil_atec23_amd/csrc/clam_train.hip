@@ -215,12 +215,78 @@ __device__ void topk_block(const float* __restrict__ a, int N, float sign, int k
 }
 
 // =====================================================================================================================
+// F2 for long bags: statistics and pooling over many workgroups (grid = row blocks x branches), then F2 proper with prepooled = 1
+// =====================================================================================================================
+constexpr int POOL_SPLIT_N = 4096, POOL_ROWS = 512;
+
+__global__ void clam_pool_init(float* __restrict__ stats, float* __restrict__ M, int K, int S1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) {
+        stats[2 * i] = -INFINITY;
+        stats[2 * i + 1] = 0.f;
+    }
+    if (i < K * S1) M[i] = 0.f;
+}
+
+// max of floats through integer atomics: non-negative values order like signed ints, negative ones reversed like unsigned ints
+// (the slot starts at -inf)
+__device__ __forceinline__ void atomic_max_f32(float* p, float v) {
+    if (v >= 0.f) atomicMax((int*)p, __float_as_int(v));
+    else atomicMin((unsigned*)p, __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(256) void clam_pool_max(const float* __restrict__ A_raw, int N, float* __restrict__ stats) {
+    __shared__ float red[8];
+    const int k = blockIdx.y, r0 = blockIdx.x * POOL_ROWS;
+    const float* a = A_raw + (int64_t)k * N;
+    float mx = -INFINITY;
+    for (int i = r0 + threadIdx.x; i < min(N, r0 + POOL_ROWS); i += 256) mx = fmaxf(mx, a[i]);
+    mx = block_max(mx, red);
+    if (threadIdx.x == 0) atomic_max_f32(&stats[2 * k], mx);
+}
+
+// sum exp(a - max) and sum exp(a - max) h1 over this block's rows: thread = (row group, column), row groups folded through LDS
+__global__ __launch_bounds__(256) void clam_pool_sum(const float* __restrict__ A_raw, const float* __restrict__ h1, int N, int S1,
+                                                     float* __restrict__ stats, float* __restrict__ M) {
+    __shared__ float part[256];
+    __shared__ float red[8];
+    const int k = blockIdx.y, r0 = blockIdx.x * POOL_ROWS, r1 = min(N, r0 + POOL_ROWS), tid = threadIdx.x;
+    const float* a = A_raw + (int64_t)k * N;
+    const float mx = stats[2 * k];
+    float se = 0.f;
+    for (int i = r0 + tid; i < r1; i += 256) se += expf(a[i] - mx);
+    se = block_sum(se, red);
+    if (tid == 0) atomicAdd(&stats[2 * k + 1], se);
+    int CW = 1;
+    while (CW < S1 && CW < 256) CW <<= 1;
+    const int RG = 256 / CW, c0 = tid % CW, rg = tid / CW;
+    for (int cb = 0; cb < S1; cb += CW) {
+        const int c = cb + c0;
+        float acc = 0.f;
+        if (c < S1)
+            for (int i = r0 + rg; i < r1; i += RG) acc = __builtin_fmaf(expf(a[i] - mx), h1[(int64_t)i * S1 + c], acc);
+        __syncthreads();
+        part[tid] = acc;
+        __syncthreads();
+        if (rg == 0 && c < S1) {
+            float sum = 0.f;
+            for (int q = 0; q < RG; ++q) sum += part[q * CW + c0];
+            atomicAdd(&M[(int64_t)k * S1 + c], sum);
+        }
+    }
+}
+
+// =====================================================================================================================
 // F2: softmax statistics, pooling, classifier(s), top-k ids + gathered rows.  ONE workgroup (K <= 8 branches in turn).
 // =====================================================================================================================
+// Long bags (N > POOL_SPLIT_N rows: CLAM_MB / CLAM_SB inference through this path, e.g. 100 000 rows) spread the softmax statistics and
+// the pooling over workgroups first (clam_pool_init / clam_pool_max / clam_pool_sum below: one workgroup would take ~1 ms per branch); this
+// kernel then only normalises M (prepooled).  Their sums are added with fp32 atomics, like the backward's row reductions of long bags:
+// training-sized bags (15 - 100 rows) keep the single-workgroup, bit-reproducible order.
 __global__ __launch_bounds__(256) void clam_train_pool(TrainDims d, TrainW w, const float* __restrict__ A_raw, const float* __restrict__ h1,
                                                        float* __restrict__ stats, float* __restrict__ M, float* __restrict__ logits,
                                                        float* __restrict__ Y_prob, int64_t* __restrict__ Y_hat, int k_sel,
-                                                       int64_t* __restrict__ ids, float* __restrict__ h1_sel) {
+                                                       int64_t* __restrict__ ids, float* __restrict__ h1_sel, int prepooled) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [256] column partials | [8] red | [8] redi | [KMAX] logits
     float* part = sm;
     float* red = sm + 256;
@@ -232,6 +298,15 @@ __global__ __launch_bounds__(256) void clam_train_pool(TrainDims d, TrainW w, co
     const int RG = 256 / CW, c0 = tid % CW, rg = tid / CW;
     for (int k = 0; k < K; ++k) {
         const float* a = A_raw + (int64_t)k * N;
+        if (prepooled) {  // stats[2k] = max, stats[2k+1] = sum exp, M[k] = sum exp(a - max) h1: normalise
+            const float inv = 1.0f / stats[2 * k + 1];
+            for (int c = tid; c < S1; c += 256) M[(int64_t)k * S1 + c] *= inv;
+            if (k_sel > 0) {
+                topk_block(a, N, 1.0f, k_sel, ids + (int64_t)(2 * k) * k_sel, red, redi);
+                topk_block(a, N, -1.0f, k_sel, ids + (int64_t)(2 * k + 1) * k_sel, red, redi);
+            }
+            continue;
+        }
         float mx = -INFINITY;
         for (int i = tid; i < N; i += 256) mx = fmaxf(mx, a[i]);
         mx = block_max(mx, red);
@@ -621,8 +696,16 @@ int hipt_clam_train_forward(const hipt_clam_train_weights* w, const float* bag, 
     }
     hipLaunchKernelGGL(clam_train_fwd_rows, dim3((N + TR - 1) / TR), dim3(256), lds, st, bag, d, p, m1, ma, mb, h1, t, s, A_raw);
     HIPT_CHECK_LAUNCH();
+    const int prepooled = N > POOL_SPLIT_N ? 1 : 0;
+    if (prepooled) {
+        const int K = w->n_att, G = (N + POOL_ROWS - 1) / POOL_ROWS;
+        hipLaunchKernelGGL(clam_pool_init, dim3((K * w->s1 + 255) / 256), dim3(256), 0, st, stats, M, K, w->s1);
+        hipLaunchKernelGGL(clam_pool_max, dim3(G, K), dim3(256), 0, st, A_raw, N, stats);
+        hipLaunchKernelGGL(clam_pool_sum, dim3(G, K), dim3(256), 0, st, A_raw, h1, N, w->s1, stats, M);
+        HIPT_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(clam_train_pool, dim3(1), dim3(256), (256 + 16 + KMAX) * sizeof(float), st, d, p, A_raw, h1, stats, M, logits, Y_prob, Y_hat, k_sample,
-                       topk_ids, h1_sel);
+                       topk_ids, h1_sel, prepooled);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }

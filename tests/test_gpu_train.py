@@ -134,6 +134,34 @@ def test_clam_mb_eval_forward_vs_reference_golden():
     assert np.array_equal(y_hat.cpu().numpy(), g["Y_hat"])
 
 
+def test_clam_mb_long_bag_pools_over_many_workgroups():
+    """CLAM_MB's forward is the training kernels' forward; a slide-sized bag (N > 4096) spreads the softmax statistics and the
+    pooling over workgroups (fp32 atomics, like the backward of long bags).  Against the module's own PyTorch-op forward on the
+    same device, with the instance branch's top-k, and timed: one workgroup took ~1 ms per branch at 100 000 rows."""
+    import time
+    m = make((192, 128, 64), 193, 3, True, 8, True).eval()
+    h = synth.hash_uniform_torch((60000, 192), 26, device=DEV)
+    label = torch.tensor([1], device=DEV)
+    with torch.no_grad():
+        ref = m._torch_forward(h, label, True, True, False)
+        got = m(h, label=label, instance_eval=True, return_features=True)
+        for _ in range(3):
+            m(h, return_features=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            m(h, return_features=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+    print(f"CLAM_MB fp32 forward, 60000 x 192, 3 branches: {dt * 1e3:.2f} ms per call")
+    lg, yp, yh, a_raw, res = got
+    lr, ypr, yhr, ar, rr = ref
+    assert md(a_raw, ar.cpu().numpy()) < 1e-4 and md(lg, lr.cpu().numpy()) < 1e-4 and md(yp, ypr.cpu().numpy()) < 1e-5
+    assert md(res["features"], rr["features"].cpu().numpy()) < 1e-4 and int(yh) == int(yhr)
+    assert abs(float(res["instance_loss"]) - float(rr["instance_loss"])) < 1e-4
+    assert dt < 3e-3
+
+
 def test_topk_rows_on_device_matches_torch_topk():
     a = synth.hash_uniform_torch((3, 1000), 9, device=DEV)
     a[1, 17] = a[1, 500]  # a tie: lowest index first
