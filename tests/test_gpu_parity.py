@@ -857,6 +857,15 @@ def test_clam_sb_bf16_hipt_big_stream_kernel():
     assert md(a_raw, r["A_raw"]) < 4e-2 and rel_l2(res["features"], r["M"]) < 2e-3 and md(logits, r["logits"]) < 1e-3
     assert np.array_equal(y_hat.cpu().numpy(), r["Y_hat"]) and abs(float(y_prob.sum()) - 1.0) < 1e-6
     assert torch.equal(a_sub[0], a_raw[0, :1000])  # rows are independent
+    # a bag long enough that every wave runs several blocks (three slices per block: the odd-slice-count form of the pipeline)
+    n2 = 70001
+    hc = synth.hash_uniform_torch((n2, 192), 16, device=DEV)
+    with torch.no_grad():
+        logits, y_prob, y_hat, a_raw, res = m(hc, return_features=True)
+    r = O.clam_sb_forward(hc.cpu().numpy().astype(np.float64), {k: v.astype(np.float64) for k, v in p.items()})
+    print(f"CLAM_SB hipt_big bf16 {n2}x192 vs fp64 oracle: A_raw max abs {md(a_raw, r['A_raw']):.2e}, M rel-L2 {rel_l2(res['features'], r['M']):.2e}, "
+          f"logits max abs {md(logits, r['logits']):.2e}")
+    assert md(a_raw, r["A_raw"]) < 4e-2 and rel_l2(res["features"], r["M"]) < 2e-3 and md(logits, r["logits"]) < 1e-3
 
 
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 97, 4 * 32 * 7 + 5])
