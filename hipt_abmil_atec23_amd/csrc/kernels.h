@@ -90,9 +90,9 @@ int hipt_seqgemm_pack_launch(const void* W, int N, int K, void* packed, hipStrea
 // Fused MLP sub-block (mlp.hip): x <- x + y1 + fc2(GELU(fc1(LN2(x + y1))))
 struct MlpParams {
     float* x;            // fp32 [M, D] residual stream, updated in place
-    const void* y1;      // bf16 [M, D] attention-branch output still to be added (or null); fold: the attention OUTPUT (before proj), as an image
-    const float* bproj;  // (fold) proj bias [D]
-    int fold;            // (mlp32.hip, image forms, wpk packed WITH the proj matrix) 1: the kernel applies proj itself: y1 = att . Wp^T + bproj
+    const void* y1;      // bf16 [M, D] attention-branch output still to be added (or null)
+    const float* bproj;  // (unused: the proj-folding experiment of round 2 lives in tools/experiments/mlp32_r3.hip)
+    int fold;            // (must be 0)
     const float* ln_w;
     const float* ln_b;
     float ln_eps;
@@ -123,9 +123,7 @@ int hipt_mlp_launch(const MlpParams& p, hipStream_t st);  // dispatches to the p
 // holds, so that a DMA piece reads 1 KiB of consecutive bytes instead of 8 row segments of 128 B (2.4x the L2 -> LDS rate).
 bool hipt_mlp32_supported(int dtype, int D, int hidden);
 int hipt_mlp32_launch(const MlpParams& p, hipStream_t st);
-// (wproj != null: the proj matrix [D, D] as six more units behind the fc1 / fc2 units: D * D * 2 more bytes; only the
-//  experiment builds -- HIPT_EXPERIMENTS -- have a kernel that reads them)
-int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st, const void* wproj = nullptr);
+int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);
 
 int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, const float* b, void* out, int out_dtype,
                           int64_t out_stride, int rows, int D, float eps, hipStream_t st);

@@ -1,18 +1,21 @@
 // FUSED MLP SUB-BLOCK for D = 384 (ViT-256) on 32x32x16 MFMAs:   x <- x + y1 + fc2( GELU( fc1( LN2(x + y1) ) ) )
 //   (Block.forward second half, HIPT_4K/vision_transformer.py:151 with Mlp.forward :98-104.)
 //
-// Same data flow, ring protocol and phase order as mlp_pipe.hip (one 4-wave workgroup owns 128 rows; LN2(x+y1) as MFMA operand
-// fragments, fc1 half-chunk accumulators -> GELU -> re-packed in registers as the fc2 operand, the [128, 384] fc2 accumulator:
-// all in registers at one wave per SIMD; only weights stream through a 3 x 48 KiB LDS-DMA ring; phases A0(c) B1(c-1) A1(c)
-// B0(c) so that a half's GELU hides under the two phases that follow its fc1).  What changes is the MFMA shape:
-//   * v_mfma_f32_32x32x16_bf16 instead of 16x16x32.  The kernel is ISSUE-bound, not MFMA-bound: per 128 MFMA cycles a wave
-//     also has to issue ~70 cycles of GELU arithmetic, ~70 of LDS-DMA pieces and its fragment reads, and a 16x16x32 MFMA
-//     holds the SIMD's vector issue for 8 of its 16 cycles (64 of 128 left), a 32x32x16 for 8 of its 32 (96 of 128 left).
+// One 4-wave workgroup owns 128 rows; every wave its 32 rows end to end, all in registers at one wave per SIMD: LN2(x + y1) as MFMA
+// operand fragments, fc1 half-chunk accumulators -> GELU -> re-packed in registers as the fc2 operand, the [32, 384] fc2 accumulator.
+// Only weights stream through a 3 x 48 KiB LDS-DMA ring; phases A0(c) B1(c-1) A1(c) B0(c) so that a half's GELU hides under the two
+// phases that follow its fc1.
+//   * v_mfma_f32_32x32x16_bf16.  The kernel is ISSUE-bound, not MFMA-bound: per 128 MFMA cycles a wave also has to issue ~70 cycles
+//     of GELU arithmetic, ~70 of LDS-DMA pieces and its fragment reads; a 32x32x16 MFMA holds the SIMD's vector issue for 8 of its
+//     32 cycles (96 of 128 left; a 16x16x32 for 8 of 16).
 //   * a wave's 32 rows are ONE B operand (column = row): lane l = 32 h + 16 m + li holds row (fragment m, li) and, per 16-deep
-//     k-step, 8 k values of half h.  The row phases still load / normalise in the 16-row fragment layout of the activation
-//     images (lane (li, g) owns chunks g + 4c of BOTH fragments); twelve v_permlane16_swap per chunk pair turn that into the
-//     32-row operand: k-step 2c + p of lane half h carries k = 32 c + 16 h + 8 p + (0..7) -- the weight image is built for
-//     exactly that order, so no data is moved for it.
+//     k-step, 8 k values of half h.
+//   * round 4: the row phase works in the ACCUMULATOR layout.  A lane loads its row's x and y1 as the 16-byte / 8-byte pieces the
+//     fc2 accumulator tiles hold (columns 32 O + 8 q + 4 h + e), takes LayerNorm-2 there (the two h-lanes of a row hold all of it),
+//     packs the normalised values straight into the fc1 operand -- k-step 2 O + p of lane half h carries columns 32 O + 16 p +
+//     8 (j >> 2) + 4 h + (j & 3), the order the weight image is built for -- and SEEDS the fc2 accumulators with v = x + y1.  The
+//     epilogue adds b2, stores, and applies the next block's LayerNorm-1: x and y1 are read ONCE per launch (round 3 re-read them
+//     in the epilogue: 1.21 of 3.99 GB per 8-region launch; tools/experiments/mlp32_r3.hip keeps that kernel for A/B runs).
 //   * weights as A operand: one fragment = 32 output units x 16 k = 1 KiB = one ds_read_b128 per lane; the packed image stores
 //     the fragments of a ring unit in consumption order, each as 64 x 16 consecutive bytes: every LDS read is conflict-free by
 //     construction, every DMA piece is 1 KiB of consecutive bytes.
@@ -32,7 +35,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int D = 384, NCH = 12, NKS = 24, NOT = 12, TMR = 128;   // NKS: 16-deep k-steps of fc1; NOT: 32-wide output tiles
+constexpr int D = 384, NKS = 24, NOT = 12, TMR = 128;   // NKS: 16-deep k-steps of fc1; NOT: 32-wide output tiles
 constexpr int UNIT = 48 * 1024;                                    // ring unit = one phase = 48 fragments of 1 KiB
 
 template <int DBG = 0>
@@ -52,7 +55,7 @@ __device__ __forceinline__ void mma32(f32x16& acc, const u32x4& a, const u32x4& 
         if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
-enum { KA = 0, KB = 1, KP = 2 };  // phase kind: fc1 half / fc2 half / (FOLD) proj: output tiles 2 H, 2 H + 1 of the attention branch
+enum { KA = 0, KB = 1 };  // phase kind: fc1 half / fc2 half
 
 // Ring unit `pos` of a tile pass: positions A0(0) A1(0) B0(0) | A0(c) B1(c-1) A1(c) B0(c) ... | B1(n-1)
 __device__ __forceinline__ void unit_of(int pos, int nchunk, bool& is_a, int& c, int& h) {
@@ -104,23 +107,9 @@ __global__ void mlp32_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* _
 
 // IMG / XIN: fragment-blocked activation images (kernels.h, "activation images") -- IMG: y1 is read and x / xn_out are written as
 // images; XIN: x is read as an image.  Row-major otherwise.  Weights always come from the packed image p.wpk (format 1).
-// The six proj units (FOLD), stored behind the fc1 / fc2 units: unit u = output tiles 2 u, 2 u + 1 of the attention branch, fragments as in
-// an fc1 unit: fragment 4 gg + 2 p + U: element j = Wp[32 (2 u + U) + r][32 gg + 16 p + 8 (j >> 2) + 4 h + (j & 3)].
-__global__ void mlp32_pack_proj_kernel(const bf16_t* __restrict__ wp, u32x4* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte lane chunk
-    if (i >= 6 * (UNIT / 16)) return;
-    const int u = i / (UNIT / 16), o = i % (UNIT / 16), frag = o >> 6, lane = o & 63, r = lane & 31, h = lane >> 5;
-    const int gg = frag >> 2, pp = (frag >> 1) & 1, U = frag & 1;
-    const bf16_t* row = wp + (int64_t)(32 * (2 * u + U) + r) * D + 32 * gg + 16 * pp + 4 * h;
-    const u32x2 lo = *(const u32x2*)row, hi = *(const u32x2*)(row + 8);
-    out[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-}
-
 // DBG (tools/mlp_probe.hip only): 1 = no weight DMA / ring syncs, 2 = GELU replaced by a plain pack, 4 = no MFMAs, 8 = no LDS
 // fragment reads.
-// FOLD: the attention branch's proj Linear runs here too (p.y1 = the attention output image [M, 384] bf16, six more weight units, p.bproj):
-// see the row phase below.
-template <bool IMG = false, bool XIN = false, int DBG = 0, bool FOLD = false>
+template <bool IMG = false, bool XIN = false, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gam = (float*)(smem + 3 * UNIT);
@@ -129,27 +118,21 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     float* b1s = b2s + D;                  // [hidden]
     int* tile_s = (int*)(b1s + p.hidden);  // [2] tile handed to this workgroup, double-buffered by parity
     float* gam1 = (float*)(tile_s + 4);    // next block's LayerNorm-1 (gamma | beta), if p.xn_out
-    float* bps = gam1 + 2 * D;             // proj bias (FOLD)
-    float* pfj = bps + D;                  // [64] where the L2-prefetch loads below drop their dwords (never read)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, g = lane >> 4;        // the row phases' 16-row fragment view: lane (li, g) owns chunks g + 4c
-    const int h = lane >> 5, m = (lane >> 4) & 1;   // the MFMA view: lane = 32 h + 16 m + li holds row (fragment m, li), k half h
     const int nchunk = p.hidden / 128;
-    const int upt_mlp = 4 * nchunk;               // fc1 / fc2 units of a tile pass
-    const int upt = upt_mlp + (FOLD ? 6 : 0);     // ring units (phases) per tile pass: FOLD: six proj units first
+    const int upt = 4 * nchunk;                   // ring units (phases) per tile pass
 
     // ---- weight DMA: unit pos of the image = 48 pieces of 1 KiB, byte for byte what its ring slot holds; wave w issues pieces
     // 12 w .. 12 w + 11.  An LDS-DMA instruction takes its LDS base from M0, and it is WRITING M0 that makes a piece expensive
     // (tools/issue_mix_probe.hip: +36 cycles per piece with a new M0, +2 with the same M0 and the piece selected by the instruction's
     // immediate offset, which is added to the LDS and to the global address alike): four consecutive pieces share one M0.
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, (2 * p.hidden * D + (FOLD ? D * D : 0)) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, 2 * p.hidden * D * 2, 0x00020000);
     const uint32_t ilane = (uint32_t)(12 * wave * 1024 + lane * 16);
     int ioff = 0, islot = 0, ipos = 0;
     auto set_issue = [&](int pos, int slot) {
-        // (the image: fc1 / fc2 units in pass order, then the six proj units -- kernels without FOLD never see those)
-        ioff = (FOLD ? (pos < 6 ? upt_mlp + pos : pos - 6) : pos) * UNIT;
+        ioff = pos * UNIT;
         islot = slot;
     };
     auto dma_piece = [&](auto T_) __attribute__((always_inline)) {
@@ -158,23 +141,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(smem + islot * UNIT + (12 * wave + (t & ~3)) * 1024), 16, ilane, ioff + (t & ~3) * 1024, (t & 3) * 1024, 0);
     };
 
-    // ---- L2 prefetch of a tile's row-phase inputs.  The row phases are latency: one wave per SIMD waits 4-5 us for 36 KiB from HBM,
-    // twice before the first phase and again in the epilogue (13 + 13 us of a 97 us tile with the matrix pipes idle).  Touching one
-    // dword of every 128-byte line from inside a chunk phase a few microseconds earlier turns those waits into L2 hits.  The loads are
-    // LDS-DMA (no destination register to keep alive), all into one 256-byte scratch line; rows past the tile's end are out of the
-    // resource's range and dropped.  Nine instructions per wave: line (4 k + wave) * 64 + lane of x (k < 6) and of y1 (k < 3).
-    auto prefetch_rows = [&](int t_row0, int t_nrows) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)t_row0 * D), 0, t_nrows * D * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ry =
-            __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.y1 + (int64_t)t_row0 * D), 0, p.y1 ? t_nrows * D * 2 : 0, 0x00020000);
-        const uint32_t vo = (uint32_t)(wave * 8192 + lane * 128);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (LDS_AS void*)pfj, 4, vo, k * 32768, 0, 0);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (LDS_AS void*)pfj, 4, vo, k * 32768, 0, 0);
-    };
     constexpr int NRD = (DBG & 16) ? 2 : 4;  // fragment reads per group
-    constexpr int NPF = 9;  // (the counted wait of a phase that prefetches)
 
     for (int i = tid; i < D; i += 256) {
         gam[i] = p.ln_w[i];
@@ -184,7 +151,6 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
             gam1[i] = p.ln_next_w[i];
             gam1[D + i] = p.ln_next_b[i];
         }
-        if constexpr (FOLD) bps[i] = p.bproj[i];
     }
     for (int i = tid; i < p.hidden; i += 256) b1s[i] = p.b1[i];
     // (the tile queue resets itself: a launch makes grid + ntiles fetches, the one that draws the last number stores 0 -- nobody
@@ -201,13 +167,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
 
     const uint32_t lbase = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
     const uint32_t fbase = lbase + lane * 16;                                         // + slot * UNIT + fragment * 1024
-    const uint32_t b1base = (uint32_t)(uintptr_t)(LDS_AS char*)b1s + 16 * h;          // b1[Hb + 32 U + 8 q + 4 h ..]: + (Hb + 32 U + 8 q) * 4
     const uint32_t tsbase = (uint32_t)(uintptr_t)(LDS_AS char*)tile_s;
-    const uint32_t gbase = (uint32_t)(uintptr_t)(LDS_AS char*)gam + 32 * g;           // (row phases: 16-row fragment view)
-    const uint32_t b2base = (uint32_t)(uintptr_t)(LDS_AS char*)b2s + 16 * h;          // b2[32 O + 8 q + 4 h ..]: + (32 O + 8 q) * 4
-    const uint32_t g1base = (uint32_t)(uintptr_t)(LDS_AS char*)gam1 + 16 * h;         // next LN-1 gamma (beta: + D * 4)
-    const uint32_t g2base = (uint32_t)(uintptr_t)(LDS_AS char*)gam + 16 * h;          // (FOLD) LN-2 gamma in accumulator column order (beta: + D * 4)
-    const uint32_t bpbase = (uint32_t)(uintptr_t)(LDS_AS char*)bps + 16 * h;          // (FOLD) proj bias
 
     // ---- prime the ring: units 0 and 1 of the pass ----
     int cons = 0;  // units consumed since kernel start (slot = cons % 3)
@@ -242,17 +202,23 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     typedef std::integral_constant<int, 1> I1;
 
     f32x4 bq[2][4];  // fc1 bias an A phase starts from: tile U, quad q: b1[off + 32 U + 8 q + 4 h + e], read one phase ahead
-    auto bias_rd = [&](int off) __attribute__((always_inline)) {  // 8 reads, no wait: covered by the next counted wait
-        const uint32_t a = b1base + off * 4;
+    // (offset = a compile-time part, which rides in the instructions' immediates, + a run-time part: hipcc keeps every distinct
+    //  b1base + constant in a register of its own across the tile loop, spills it, and reloads it inside a ring phase -- where the
+    //  reload's vmcnt(0) waits for the LDS-DMA in flight)
+    auto bias_rd = [&](auto OFFC_, int offd) __attribute__((always_inline)) {  // 8 reads, no wait: covered by the next counted wait
+        constexpr int oc = decltype(OFFC_)::value * 4;
+        int ln;  // (b1[.. + 4 h ..]: the lane half from a fresh lane id -- two instructions -- rather than from a register kept, and spilled)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        const uint32_t a = (uint32_t)(uintptr_t)(LDS_AS char*)b1s + ((ln >> 5) << 4) + offd * 4;
         f32x4 &q0 = bq[0][0], &q1 = bq[0][1], &q2 = bq[0][2], &q3 = bq[0][3], &q4 = bq[1][0], &q5 = bq[1][1], &q6 = bq[1][2], &q7 = bq[1][3];
-        DSR128(q0, a, 0);
-        DSR128(q1, a, 32);
-        DSR128(q2, a, 64);
-        DSR128(q3, a, 96);
-        DSR128(q4, a, 128);
-        DSR128(q5, a, 160);
-        DSR128(q6, a, 192);
-        DSR128(q7, a, 224);
+        DSR128(q0, a, oc + 0);
+        DSR128(q1, a, oc + 32);
+        DSR128(q2, a, oc + 64);
+        DSR128(q3, a, oc + 96);
+        DSR128(q4, a, oc + 128);
+        DSR128(q5, a, oc + 160);
+        DSR128(q6, a, oc + 192);
+        DSR128(q7, a, oc + 224);
     };
 
     for (int seq = 0; tile < p.ntiles; ++seq) {
@@ -275,11 +241,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
 
         u32x4 X[NKS];  // the fc1 B operand: k-step s = 2 c + p, lane half h: columns 32 c + 16 p + 8 (j >> 2) + 4 h + (j & 3)
 
-        f32x16 acc2[NOT];
-#pragma unroll
-        for (int o = 0; o < NOT; ++o)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc2[o][e] = 0.f;
+        f32x16 acc2[NOT];    // the fc2 accumulators, seeded by the row phase with v = x + y1
         f32x16 acc1[2][2];   // [half][tile U]: hidden (reg & 3) + 8 (reg >> 2) + 4 h of tile U for this lane's row
         u32x4 hf[2][2][2];   // [half][tile U][k-step s']: the GELU'd, bf16-packed registers 8 s' .. 8 s' + 7 of acc1[half][U]
         // one 2-element GELU: unit u (0..15) of half GH -> one 32-bit word of the fc2 operand fragments
@@ -297,13 +259,12 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         // ---- one phase: 12 groups of 4 MFMAs on the unit in slot cons % 3 ----
         // KIND/H: fc1 half H (into acc1[H][.], started from the bias in bq) or fc2 half H (operand hf[H][.][.])
         // GH/GSEC: GELU units of half GH, first (0) or second (1) eight, one per group 4..11; GH = -1: none
-        // NB/nb: the NEXT phase is an fc1 phase and starts from the bias at b1s offset nb (read with the cross-phase prefetch).
-        //     NB = -1: last phase of the tile, nothing is prefetched (the row phases in between need the registers)
-        //     PF: 1 = this phase also prefetches this tile's rows for the epilogue, 2 = the next tile's rows (groups 5 / 6, behind
-        //     the phase's DMA pieces: the wait at group 11 leaves exactly the NPF prefetch loads in flight)
-        auto phase = [&](auto KIND_, auto H_, auto GH_, auto GSEC_, auto NB_, int nb, auto PF_) __attribute__((always_inline)) {
+        // NB/nb: NB > 0: the NEXT phase is an fc1 phase and starts from the bias at b1s offset NB + nb (read with the cross-phase
+        //     prefetch).  NB = 0: no bias read.  NB = -1: last phase of the tile, nothing is prefetched (the row phases in between
+        //     need the registers)
+        auto phase = [&](auto KIND_, auto H_, auto GH_, auto GSEC_, auto NB_, int nb) __attribute__((always_inline)) {
             constexpr int kind = decltype(KIND_)::value, hh = decltype(H_)::value, gh = decltype(GH_)::value;
-            constexpr int gsec = decltype(GSEC_)::value, needb = decltype(NB_)::value, pf = decltype(PF_)::value;
+            constexpr int gsec = decltype(GSEC_)::value, needb = decltype(NB_)::value;
             const uint32_t sa = fbase + (cons % 3) * UNIT;
             const uint32_t sn = fbase + ((cons + 1) % 3) * UNIT;
             sfor<0, 12>([&](auto G_) __attribute__((always_inline)) {
@@ -312,10 +273,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                 // (1) fragment reads one group ahead
                 if constexpr (gg == 11) {
                     if constexpr ((DBG & 1) == 0) {
-                        if constexpr (pf != 0)
-                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPF) : "memory");
-                        else
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of the next unit have landed
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of the next unit have landed
                         __builtin_amdgcn_s_barrier();                     // ... everyone's; unit cons-1 is no longer read
                     }
                     set_issue(ipos, (cons + 2) % 3);
@@ -325,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                     } else {
                         rd_frag(NS{}, I0{}, sn);
                         if constexpr (needb > 0) {
-                            bias_rd(nb);
+                            bias_rd(std::integral_constant<int, (needb > 0 ? needb : 0)>{}, nb);
                             LGKM(8 + NRD);
                         } else {
                             LGKM(NRD);
@@ -362,14 +320,9 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                         mma32<DBG>(acc1[hh][0], wA[set][2], X[2 * gg + 1]);
                         mma32<DBG>(acc1[hh][1], wA[set][3], X[2 * gg + 1]);
                     }
-                } else if constexpr (kind == KB) {
+                } else {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) mma32<DBG>(acc2[gg], wA[set][t], hf[hh][t >> 1][t & 1]);
-                } else {  // KP: as an fc1 group, into the (still idle) fc2 accumulators of output tiles 2 hh, 2 hh + 1
-                    mma32<DBG>(acc2[2 * hh], wA[set][0], X[2 * gg]);
-                    mma32<DBG>(acc2[2 * hh + 1], wA[set][1], X[2 * gg]);
-                    mma32<DBG>(acc2[2 * hh], wA[set][2], X[2 * gg + 1]);
-                    mma32<DBG>(acc2[2 * hh + 1], wA[set][3], X[2 * gg + 1]);
                 }
                 if constexpr (gg == 11) {
                     dma_piece(std::integral_constant<int, 0>{});
@@ -378,8 +331,6 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                     dma_piece(std::integral_constant<int, 2 + 2 * gg>{});
                     dma_piece(std::integral_constant<int, 3 + 2 * gg>{});
                 }
-                if constexpr (pf == 1 && gg == 5) prefetch_rows(row0, nrows);
-                if constexpr (pf == 2 && gg == 5) prefetch_rows(row0_next, nrows_next);
                 if constexpr (gh >= 0 && gg >= 4) {
                     gelu_unit(std::integral_constant<int, (gh >= 0 ? gh : 0)>{}, std::integral_constant<int, 8 * gsec + gg - 4>{});
                 }
@@ -390,242 +341,133 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         typedef std::integral_constant<int, -1> IM1;
         typedef std::integral_constant<int, KA> TA;
         typedef std::integral_constant<int, KB> TB;
-        typedef std::integral_constant<int, KP> TP;
-#ifdef MLP32_PREFETCH  // (experiment, off: see prefetch_rows)
-        typedef std::integral_constant<int, 1> PFA;
-        typedef std::integral_constant<int, 2> PFB;
-#else
-        typedef I0 PFA;
-        typedef I0 PFB;
-#endif
+        typedef std::integral_constant<int, 64> I64;
+        typedef std::integral_constant<int, 128> I128;
 
-        // 16-row fragments (chunk g + 4 c of fragments 0 / 1 per lane) -> the 32-row B operand X
-        auto to_operand = [&](u32x4 (&af)[2][NCH]) __attribute__((always_inline)) {
-            // 16-row fragments -> the 32-row B operand.  Lane (li, g = 2 h + m) holds chunks 2 h + m + 4 c of BOTH fragments; it needs
-        // fragment m only, chunks 2 h + 4 c (E) and 2 h + 1 + 4 c (O).  Lanes l and l ^ 16 (m = 0 / 1, same h) hold each other's
-        // missing chunks: one v_permlane16_swap per dword (odd 16-lane rows of the first operand <-> even rows of the second)
-        // leaves E in the first and O in the second for every lane.  k-step 2 c + p then carries k = 32 c + 16 h + 8 p + (0..7).
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            u32x4 e4, o4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const auto sw = __builtin_amdgcn_permlane16_swap(af[0][c][e], af[1][c][e], false, false);
-                e4[e] = sw[0];
-                o4[e] = sw[1];
-            }
-            // ... and lanes l and l ^ 32 trade 4-column groups, so that the operand's k order is the column order of an accumulator
-            // tile (lane half h: columns 8 q + 4 h + (0..3) of every 32): after the 16-lane swap half h holds columns 16 h + (0..15)
-            // of the 32 as e4 = [G, G + 1], o4 = [G + 2, G + 3] (G = 4 h, groups of 4 columns); it keeps its even groups and
-            // takes the other half's: k-step 2 c = [G0 | G2] (h = 0) / [G1 | G3] (h = 1), k-step 2 c + 1 = [G4 | G6] / [G5 | G7].
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const auto s0 = __builtin_amdgcn_permlane32_swap(e4[e], e4[2 + e], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(o4[e], o4[2 + e], false, false);
-                e4[e] = s0[0];
-                e4[2 + e] = s0[1];
-                o4[e] = s1[0];
-                o4[2 + e] = s1[1];
-            }
-            X[2 * c] = u32x4{e4[0], e4[1], o4[0], o4[1]};
-            X[2 * c + 1] = u32x4{e4[2], e4[3], o4[2], o4[3]};
-        }
+        // where this lane's row lives (row phase and epilogue; formed where it is used: kept across the chunk phases the pointers
+        // would be spilled, and a scratch reload inside a ring phase waits for the LDS-DMA in flight).  rb: float / element offset of
+        // the row's columns 4 h.. (row-major forms), fb: of its 16-row fragment (image forms: whole fragments only -- the launcher
+        // guarantees M % 16 == 0 -- so a fragment past the tile's end has no live row: it re-reads fragment 0, never stored)
+        // (everything lane-dependent is derived from an OPAQUE copy of the lane id: loop-invariant addresses would be hoisted out of
+        //  the tile loop, live through the chunk phases, and be spilled there)
+        auto row_base = [&](int t_row0, int t_nrows, int& li_, int& h_, int64_t& rb, int64_t& fb, bool& live) __attribute__((always_inline)) {
+            int ln;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+            li_ = ln & 15;
+            h_ = ln >> 5;
+            const int m_ = (ln >> 4) & 1;
+            const int r = wave * 32 + m_ * 16 + li_;
+            live = r < t_nrows;
+            rb = (int64_t)(t_row0 + (live ? r : 0)) * D + 4 * h_;
+            fb = (int64_t)(t_row0 + (live ? wave * 32 + m_ * 16 : 0)) * D;
         };
-        if constexpr (!FOLD) {
-            // ---- activations: v = x + y1 -> LN2 -> operand fragments (16-row fragment view, as mlp_pipe.hip) ----
-            u32x4 af[2][NCH];
-#pragma unroll
-            for (int mf = 0; mf < 2; ++mf) {
-                int r = (wave * 2 + mf) * 16 + li;
-                r = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
-                // image forms: whole fragments only (the launcher guarantees M % 16 == 0); a fragment past the tile's end
-                // re-reads fragment 0 of the tile (never stored)
-                const int fr = (wave * 2 + mf) * 16 < nrows ? (wave * 2 + mf) * 16 : 0;
-                // x: row-major: row r, floats (g + 4c) * 8 + 4hh;  image: fragment base + c * 512 + hh * 256 + lane * 4
-                const float* xr = XIN ? p.x + (int64_t)(row0 + fr) * D + lane * 4 : p.x + (int64_t)(row0 + r) * D + g * 8;
-                constexpr int xc_ = XIN ? 512 : 32, xh_ = XIN ? 256 : 4;
-                f32x4 v[NCH][2];
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    v[c][0] = *(const f32x4*)(xr + c * xc_);
-                    v[c][1] = *(const f32x4*)(xr + c * xc_ + xh_);
-                }
-                if (p.y1) {
-                    // y1 (bf16): row-major: row r, elements (g + 4c) * 8;  image: fragment base + c * 512 + lane * 8
-                    const bf16_t* yr = IMG ? (const bf16_t*)p.y1 + (int64_t)(row0 + fr) * D + lane * 8 : (const bf16_t*)p.y1 + (int64_t)(row0 + r) * D + g * 8;
-                    constexpr int yc_ = IMG ? 512 : 32;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        const bf16x8 y = __builtin_bit_cast(bf16x8, *(const u32x4*)(yr + c * yc_));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[c][0][e] += (float)y[e];
-                            v[c][1][e] += (float)y[4 + e];
-                        }
-                    }
-                }
-                if (HIPT_STAMPS_ON(p.stamps)) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (mf == 0) { PSTAMP(5); } else { PSTAMP(7); }
-                }
-                if (mf == 0 && tid == 0) {
-                    asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
-                    if (nt_req == last_fetch) *p.counter = 0;
-                }
-                ln_rows_lds<D, NCH>(v, gbase, p.ln_eps, af[mf]);
-                if (mf == 0) PSTAMP(6);
-                if (mf == 0) {
-                    // park the finished fragment in the accumulator file (idle during the row phase) while the other one
-                    // is loaded and normalised: left alone, hipcc sends it to scratch and the reloads stall the first phase
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        u32x4& a2 = af[0][c];
-                        asm volatile("" : "+a"(a2));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+        // both lanes of a row (l, l ^ 32) get lo + hi, summed in that order (no LDS crossbar, no lane-id register)
+        auto row_sum = [&](float v) __attribute__((always_inline)) -> float {
+#pragma clang fp contract(off)
+            const uint32_t u = __builtin_bit_cast(uint32_t, v);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            return __builtin_bit_cast(float, (uint32_t)sw[0]) + __builtin_bit_cast(float, (uint32_t)sw[1]);
+        };
+
+        // ---- row phase: v = x + y1 in the ACCUMULATOR layout.  Lane (h, m, li) holds row 32 w + 16 m + li and, per output tile O and
+        // quad q, columns 32 O + 8 q + 4 h + (0..3): the 16-byte pieces of the fp32 row (or image), the 8-byte pieces of the bf16
+        // one.  The two h-lanes of a row hold all of it, so LayerNorm-2 takes ONE cross-lane step; the normalised values packed to
+        // bf16 ARE the fc1 operand (the fc1 weight image lists k in the accumulator's column order: mlp32_pack_kernel); and v seeds
+        // the fc2 accumulators, so the epilogue never re-reads x and y1 (round 3 did: 1.21 of the 3.99 GB per 8-region launch).
+        // All 96 loads of a lane (36 KiB per wave) are in flight together: one memory latency per tile instead of two.
+        {
+#pragma clang fp contract(off)
+            const float* xl;
+            const bf16_t* yr;
+            uint32_t g2base;  // LN-2 gamma in accumulator column order: gam[32 O + 8 q + 4 h ..] at + (32 O + 8 q) * 4 (beta: + D * 4)
+            {
+                int64_t rb, fb;
+                bool live;
+                int li_, h_;
+                row_base(row0, nrows, li_, h_, rb, fb, live);
+                xl = XIN ? p.x + fb + 256 * h_ + 4 * li_ : p.x + rb;
+                yr = IMG ? (const bf16_t*)p.y1 + fb + 8 * li_ + 4 * h_ : (const bf16_t*)p.y1 + rb;
+                g2base = (uint32_t)(uintptr_t)(LDS_AS char*)gam + 16 * h_;
             }
-            PSTAMP(12);
-            to_operand(af);
-        } else {
+            constexpr int xlo_ = XIN ? 512 : 32, xlq_ = XIN ? 64 : 8, yo_ = IMG ? 512 : 32, yq_ = IMG ? 128 : 8;
+            f32x4 xv[NOT][4];
+            u32x2 yv[NOT][4];
+#pragma unroll
+            for (int O = 0; O < NOT; ++O)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xv[O][q] = *(const f32x4*)(xl + xlo_ * O + xlq_ * q);
+            if (p.y1) {
+#pragma unroll
+                for (int O = 0; O < NOT; ++O)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) yv[O][q] = *(const u32x2*)(yr + yo_ * O + yq_ * q);
+            } else {
+#pragma unroll
+                for (int O = 0; O < NOT; ++O)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) yv[O][q] = u32x2{0u, 0u};
+            }
             if (tid == 0) {
                 asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
                 if (nt_req == last_fetch) *p.counter = 0;
             }
-            // ---- FOLD: y1 = proj(att) is computed here instead of read.  (1) the attention output tile (bf16 image) is itself
-            // an operand: its 16-byte chunks are the fragment layout; (2) six phases on the proj units into acc2 (idle until the
-            // first fc2 phase): acc2[O][4 q + e] = column 32 O + 8 q + 4 h + e of this lane's row; (3) v = acc2 + b_proj + x becomes
-            // the residual stream (stored as its image: the epilogue re-reads it instead of x and y1) and, LayerNorm-2'd, the fc1
-            // operand -- whose k order IS the accumulator's column order.
-            {
-                u32x4 af[2][NCH];
+            // (packed fp32 arithmetic: no MFMA runs beside the row phases, and it halves their vector instructions)
+            f32x2 rs2 = {0.f, 0.f};
+            sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+                constexpr int O = decltype(O_)::value;
 #pragma unroll
-                for (int mf = 0; mf < 2; ++mf) {
-                    const int fr = (wave * 2 + mf) * 16 < nrows ? (wave * 2 + mf) * 16 : 0;
-                    const bf16_t* yr = (const bf16_t*)p.y1 + (int64_t)(row0 + fr) * D + lane * 8;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) af[mf][c] = *(const u32x4*)(yr + c * 512);
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x4 y = __builtin_bit_cast(bf16x4, yv[O][q]);
+                    f32x2 a = {xv[O][q][0], xv[O][q][1]}, b = {xv[O][q][2], xv[O][q][3]};
+                    a = a + f32x2{(float)y[0], (float)y[1]};
+                    b = b + f32x2{(float)y[2], (float)y[3]};
+                    rs2 = rs2 + a;
+                    rs2 = rs2 + b;
+                    xv[O][q] = f32x4{a[0], a[1], b[0], b[1]};
                 }
-                to_operand(af);
-            }
-            // the residual rows of this tile, in the accumulator's layout: output tiles 0..5 are requested now and land under the proj
-            // phases (their 96 registers are free until the first fc1 phase), tiles 6..11 when those are being added
-            constexpr int xlo_ = XIN ? 512 : 32, xlq_ = XIN ? 64 : 8;
-            // (pointers are formed where they are used, from values that are live anyway: kept across the phases they would be spilled,
-            //  and a scratch reload inside a ring phase waits for the LDS-DMA in flight)
-            auto x_ptrs = [&](const float*& xl, float*& xs, bool& live) __attribute__((always_inline)) {
-                int li2 = li;
-                asm volatile("" : "+v"(li2));
-                const int r = wave * 32 + m * 16 + li2;
-                live = r < nrows;
-                const int frr = wave * 32 + m * 16;
-                const int64_t rb = (int64_t)(row0 + (live ? r : 0)) * D + 4 * h, fb = (int64_t)(row0 + (live ? frr : 0)) * D;
-                xl = XIN ? p.x + fb + 256 * h + 4 * li2 : p.x + rb;
-                xs = p.x + fb + 256 * h + 4 * li2;
-            };
-            f32x4 xa[6][4], xb[6][4];
-            {
-                const float* xl;
-                float* xs;
-                bool live;
-                x_ptrs(xl, xs, live);
+            });
+            const float rs = row_sum(rs2[0] + rs2[1]);
+            const float mean = rs * (1.0f / D);
+            const f32x2 mean2 = {mean, mean};
+            f32x2 qs2 = {0.f, 0.f};
 #pragma unroll
-                for (int O = 0; O < 6; ++O)
+            for (int O = 0; O < NOT; ++O)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) xa[O][q] = *(const f32x4*)(xl + xlo_ * O + xlq_ * q);
-            }
-            rd_frag(I0{}, I0{}, fbase + (cons % 3) * UNIT);
-            phase(TP{}, I0{}, IM1{}, I0{}, I0{}, 0, I0{});
-            phase(TP{}, I1{}, IM1{}, I0{}, I0{}, 0, I0{});
-            phase(TP{}, std::integral_constant<int, 2>{}, IM1{}, I0{}, I0{}, 0, I0{});
-            phase(TP{}, std::integral_constant<int, 3>{}, IM1{}, I0{}, I0{}, 0, I0{});
-            phase(TP{}, std::integral_constant<int, 4>{}, IM1{}, I0{}, I0{}, 0, I0{});
-            phase(TP{}, std::integral_constant<int, 5>{}, IM1{}, I0{}, IM1{}, 0, I0{});
-            {
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 a = f32x2{xv[O][q][0], xv[O][q][1]} - mean2, b = f32x2{xv[O][q][2], xv[O][q][3]} - mean2;
+                    qs2 = __builtin_elementwise_fma(a, a, qs2);
+                    qs2 = __builtin_elementwise_fma(b, b, qs2);
+                }
+            const float qs = row_sum(qs2[0] + qs2[1]);
+            const float rstd = 1.0f / sqrtf(qs * (1.0f / D) + p.ln_eps);
+            const f32x2 rstd2 = {rstd, rstd};
+            sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
-                const float* xl;
-                float* xs;
-                bool live;
-                x_ptrs(xl, xs, live);
-                // every old value of the tile is loaded (and waited for) before the first store: converting in place (row-major in,
-                // image out: the first block of a forward) a lane's stores land where OTHER lanes' loads read
+                constexpr int O = decltype(O_)::value;
+                f32x4 gq[4], bqv[4];
+                const uint32_t ga = g2base;
+                f32x4 &g0 = gq[0], &g1 = gq[1], &g2 = gq[2], &g3 = gq[3], &b0 = bqv[0], &b1_ = bqv[1], &b2_ = bqv[2], &b3 = bqv[3];
+                DSR128X4_WAIT(g0, g1, g2, g3, ga, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
+                DSR128X4_WAIT(b0, b1_, b2_, b3, ga, D * 4 + O * 128, D * 4 + O * 128 + 32, D * 4 + O * 128 + 64, D * 4 + O * 128 + 96);
+                uint32_t w[8];
+                f32x16 t;
 #pragma unroll
-                for (int O = 0; O < 6; ++O)
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 va = {xv[O][q][0], xv[O][q][1]}, vb = {xv[O][q][2], xv[O][q][3]};
+                    const f32x2 ya = __builtin_elementwise_fma((va - mean2) * rstd2, f32x2{gq[q][0], gq[q][1]}, f32x2{bqv[q][0], bqv[q][1]});
+                    const f32x2 yb = __builtin_elementwise_fma((vb - mean2) * rstd2, f32x2{gq[q][2], gq[q][3]}, f32x2{bqv[q][2], bqv[q][3]});
+                    w[2 * q] = pack_bf16x2(ya[0], ya[1]);
+                    w[2 * q + 1] = pack_bf16x2(yb[0], yb[1]);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) xb[O][q] = *(const f32x4*)(xl + xlo_ * (6 + O) + xlq_ * q);
-                sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
-#pragma clang fp contract(off)
-                    constexpr int O = decltype(O_)::value;
-                    f32x4 bb[4];
-                    const uint32_t ba = bpbase;
-                    f32x4 &r0_ = bb[0], &r1_ = bb[1], &r2_ = bb[2], &r3_ = bb[3];
-                    DSR128X4_WAIT(r0_, r1_, r2_, r3_, ba, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
-                    f32x16 t = acc2[O];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) t[4 * q + e] = (t[4 * q + e] + bb[q][e]) + (O < 6 ? xa[O < 6 ? O : 0][q][e] : xb[O < 6 ? 0 : O - 6][q][e]);
-                    asm volatile("" : "+a"(t));  // back to the accumulator file at once (left to hipcc, the sums go to scratch)
-                    acc2[O] = t;
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                // (one output tile at a time from here on: the accumulators live in the accumulator file, arithmetic needs them in arch
-                //  VGPRs, and hipcc, left alone, fetches all 192 at once and spills)
-                float rs = 0.f;
-                sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
-#pragma clang fp contract(off)
-                    constexpr int O = decltype(O_)::value;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = {acc2[O][4 * q], acc2[O][4 * q + 1], acc2[O][4 * q + 2], acc2[O][4 * q + 3]};
-                        if (live) *(f32x4*)(xs + 512 * O + 64 * q) = v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) rs += v[e];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                rs += __shfl_xor(rs, 32, 64);
-                const float mean = rs * (1.0f / D);
-                float qs = 0.f;
-                sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
-#pragma clang fp contract(off)
-                    constexpr int O = decltype(O_)::value;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const float a = acc2[O][e] - mean;
-                        qs = __builtin_fmaf(a, a, qs);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                qs += __shfl_xor(qs, 32, 64);
-                const float rstd = 1.0f / sqrtf(qs * (1.0f / D) + p.ln_eps);
-                sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
-#pragma clang fp contract(off)
-                    constexpr int O = decltype(O_)::value;
-                    f32x4 gq[4], bqv[4];
-                    const uint32_t ga = g2base;
-                    f32x4 &g0 = gq[0], &g1 = gq[1], &g2 = gq[2], &g3 = gq[3], &b0 = bqv[0], &b1_ = bqv[1], &b2_ = bqv[2], &b3 = bqv[3];
-                    DSR128X4_WAIT(g0, g1, g2, g3, ga, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
-                    DSR128X4_WAIT(b0, b1_, b2_, b3, ga, D * 4 + O * 128, D * 4 + O * 128 + 32, D * 4 + O * 128 + 64, D * 4 + O * 128 + 96);
-                    uint32_t w[8];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float y[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc2[O][4 * q + e] - mean) * rstd, gq[q][e], bqv[q][e]);
-                        w[2 * q] = pack_bf16x2(y[0], y[1]);
-                        w[2 * q + 1] = pack_bf16x2(y[2], y[3]);
-                    }
-                    X[2 * O] = u32x4{w[0], w[1], w[2], w[3]};      // k-step 2 O: columns 8 q + 4 h + e of the 32, q = 0, 1
-                    X[2 * O + 1] = u32x4{w[4], w[5], w[6], w[7]};  // k-step 2 O + 1: q = 2, 3
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-#pragma unroll
-                for (int o = 0; o < NOT; ++o)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc2[o][e] = 0.f;
-            }
+                    for (int e = 0; e < 4; ++e) t[4 * q + e] = xv[O][q][e];
+                }
+                X[2 * O] = u32x4{w[0], w[1], w[2], w[3]};      // k-step 2 O: columns 8 q + 4 h + e of the 32, q = 0, 1
+                X[2 * O + 1] = u32x4{w[4], w[5], w[6], w[7]};  // k-step 2 O + 1: q = 2, 3
+                asm volatile("" : "+a"(t));  // the seed goes to the accumulator file at once
+                acc2[O] = t;
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
         PSTAMP(2);
         if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
@@ -639,11 +481,11 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         // first fragments and bias of the pass (asm reads land asynchronously: nothing but the first phase may sit
         // between them and their counted wait -- in particular not the row phases, where the compiler moves registers)
         rd_frag(I0{}, I0{}, fbase + (cons % 3) * UNIT);
-        bias_rd(0);
+        bias_rd(I0{}, 0);
         // chunk 0 (peeled: no runtime branches around phases inside the steady-state loop).  Its half-0 GELUs have
         // only A1(0) to hide in: the second eight run bare.
-        phase(TA{}, I0{}, IM1{}, I0{}, I1{}, 64, I0{});
-        phase(TA{}, I1{}, I0{}, I0{}, I0{}, 0, I0{});
+        phase(TA{}, I0{}, IM1{}, I0{}, I64{}, 0);
+        phase(TA{}, I1{}, I0{}, I0{}, I0{}, 0);
         sfor<8, 16>([&](auto U_) __attribute__((always_inline)) { gelu_unit(I0{}, U_); });
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -663,19 +505,19 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
             nrows_next = (tile_next < p.ntiles && nrows_next > 0) ? nrows_next : 0;  // (no next tile: an empty range, every load dropped)
             row0_next = nrows_next > 0 ? row0_next : 0;
         }
-        phase(TB{}, I0{}, I1{}, I0{}, I1{}, 128, I0{});
+        phase(TB{}, I0{}, I1{}, I0{}, I128{}, 0);
         for (int c = 1; c < nchunk - 1; ++c) {
-            phase(TA{}, I0{}, I1{}, I1{}, I0{}, 0, I0{});             // A0(c)   + second eight GELUs of half 1 of chunk c-1
-            phase(TB{}, I1{}, I0{}, I0{}, I1{}, c * 128 + 64, I0{});  // B1(c-1) + first eight of half 0 of chunk c
-            phase(TA{}, I1{}, I0{}, I1{}, I0{}, 0, I0{});             // A1(c)   + second eight of half 0
-            phase(TB{}, I0{}, I1{}, I0{}, I1{}, (c + 1) * 128, I0{});  // B0(c) + first eight of half 1
+            phase(TA{}, I0{}, I1{}, I1{}, I0{}, 0);             // A0(c)   + second eight GELUs of half 1 of chunk c-1
+            phase(TB{}, I1{}, I0{}, I0{}, I64{}, c * 128);    // B1(c-1) + first eight of half 0 of chunk c
+            phase(TA{}, I1{}, I0{}, I1{}, I0{}, 0);             // A1(c)   + second eight of half 0
+            phase(TB{}, I0{}, I1{}, I0{}, I128{}, c * 128);   // B0(c) + first eight of half 1
         }
         {   // the last chunk (peeled): its first two phases also request the rows of the epilogue and of the next tile's row phase
             const int c = nchunk - 1;
-            phase(TA{}, I0{}, I1{}, I1{}, I0{}, 0, PFA{});
-            phase(TB{}, I1{}, I0{}, I0{}, I1{}, c * 128 + 64, PFB{});
-            phase(TA{}, I1{}, I0{}, I1{}, I0{}, 0, I0{});
-            phase(TB{}, I0{}, I1{}, I0{}, I1{}, 0, I0{});
+            phase(TA{}, I0{}, I1{}, I1{}, I0{}, 0);
+            phase(TB{}, I1{}, I0{}, I0{}, I64{}, c * 128);
+            phase(TA{}, I1{}, I0{}, I1{}, I0{}, 0);
+            phase(TB{}, I0{}, I1{}, I0{}, I128{}, -128);  // (a bias nobody uses: the wait counts stay those of the loop body)
         }
         LGKM(0);  // (the last B0 read a bias nobody uses: let it land before its registers are re-used ...
         {         //  ... and keep those registers allocated up to here: a fake use AFTER the wait)
@@ -685,93 +527,67 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         // tail: second eight of the last half 1, then B1(last); its prefetch is the next tile's A0(0)
         sfor<8, 16>([&](auto U_) __attribute__((always_inline)) { gelu_unit(I1{}, U_); });
         __builtin_amdgcn_sched_barrier(0);
-        phase(TB{}, I1{}, IM1{}, I0{}, IM1{}, 0, I0{});
+        phase(TB{}, I1{}, IM1{}, I0{}, IM1{}, 0);
         PSTAMP(3);
         if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
 
-        // ---- epilogue: x <- x + y1 + acc2 + b2 (this workgroup owns its rows: in place, no other reader).
+        // ---- epilogue: x <- acc2 + b2 (acc2 started from v = x + y1: nothing is re-read).  This workgroup owns its rows: in place.
         //      Lane (h, m, li) holds row 32 w + 16 m + li; acc2[O][4 q + e] is output column 32 O + 8 q + 4 h + e.
         //      Images: chunk-of-8 index 4 O + q = g' + 4 c' with g' = q, c' = O, half h, image lane 16 q + li.
+        //      (row-major in, image out -- the first block of a forward -- converts in place: a wave's 32 rows are the bytes of its two
+        //       fragments, and every old value was loaded in the row phase)
         {
 #pragma clang fp contract(off)
-            const int r = wave * 32 + m * 16 + li;
-            const bool live = r < nrows;
-            const int fr = wave * 32 + m * 16;  // (image forms: stored only when live, i.e. fr < nrows)
-            const int64_t rb = (int64_t)(row0 + (live ? r : 0)) * D + 4 * h, fb = (int64_t)(row0 + (live ? fr : 0)) * D;
+            int64_t rb, fb;
+            bool live;
+            int li_, h_;
+            row_base(row0, nrows, li_, h_, rb, fb, live);
+            const uint32_t b2base = (uint32_t)(uintptr_t)(LDS_AS char*)b2s + 16 * h_;   // b2[32 O + 8 q + 4 h ..]: + (32 O + 8 q) * 4
+            const uint32_t g1base = (uint32_t)(uintptr_t)(LDS_AS char*)gam1 + 16 * h_;  // next LN-1 gamma (beta: + D * 4)
             // float / element offsets of piece (O, q): row-major rb + 32 O + 8 q; fp32 image fb + 512 O + 256 h + 64 q + 4 li;
             // bf16 image fb + 512 O + 128 q + 8 li + 4 h
-            // (FOLD: the row phase left v = x + y1 where x was, as an image: that is what is re-read, and there is no y1)
-            constexpr bool XI = XIN || FOLD;
-            const float* xl = XI ? p.x + fb + 256 * h + 4 * li : p.x + rb;
-            float* xs = IMG ? p.x + fb + 256 * h + 4 * li : p.x + rb;
-            const bf16_t* yr = IMG ? (const bf16_t*)p.y1 + fb + 8 * li + 4 * h : (const bf16_t*)p.y1 + rb;
-            constexpr int xlo_ = XI ? 512 : 32, xlq_ = XI ? 64 : 8, xso_ = IMG ? 512 : 32, xsq_ = IMG ? 64 : 8, yo_ = IMG ? 512 : 32, yq_ = IMG ? 128 : 8;
-            float rs = 0.f;
-            // three output tiles at a time: their old x (12 x 16 B) and y1 (12 x 8 B) pieces are requested one batch ahead.
-            // Converting in place (row-major in, image out: the first block of a forward) a lane's stores land where OTHER lanes'
-            // loads read: there every old value of the tile is loaded, and waited for, before the first store.
-            f32x4 xv[XI != IMG ? NOT : 6][4];
-            u32x2 yv[6][4];
-            auto ld_batch = [&](auto B_) __attribute__((always_inline)) {
-                constexpr int b = decltype(B_)::value, s0 = (b & 1) * 3;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int O = 3 * b + i;
-                        if constexpr (XI == IMG) xv[s0 + i][q] = *(const f32x4*)(xl + xlo_ * O + xlq_ * q);
-                        yv[s0 + i][q] = (!FOLD && p.y1) ? *(const u32x2*)(yr + yo_ * O + yq_ * q) : u32x2{0u, 0u};
-                    }
-            };
-            if constexpr (XI != IMG) {
-#pragma unroll
-                for (int O = 0; O < NOT; ++O)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) xv[O][q] = *(const f32x4*)(xl + xlo_ * O + xlq_ * q);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            ld_batch(I0{});
-            sfor<0, 4>([&](auto B_) __attribute__((always_inline)) {
+            float* xs = IMG ? p.x + fb + 256 * h_ + 4 * li_ : p.x + rb;
+            constexpr int xso_ = IMG ? 512 : 32, xsq_ = IMG ? 64 : 8, yo_ = IMG ? 512 : 32, yq_ = IMG ? 128 : 8;
+            f32x2 rs2 = {0.f, 0.f};
+            sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
-                constexpr int b = decltype(B_)::value, s0 = (b & 1) * 3;
-                if constexpr (b < 3) ld_batch(std::integral_constant<int, b + 1>{});
-                sfor<0, 3>([&](auto I_) __attribute__((always_inline)) {
-#pragma clang fp contract(off)
-                    constexpr int i = decltype(I_)::value, O = 3 * b + i, xi = (XI != IMG) ? O : s0 + i;
-                    f32x4 bb[4];
-                    const uint32_t ba = b2base;
-                    f32x4 &r0_ = bb[0], &r1_ = bb[1], &r2_ = bb[2], &r3_ = bb[3];
-                    DSR128X4_WAIT(r0_, r1_, r2_, r3_, ba, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
+                constexpr int O = decltype(O_)::value;
+                f32x4 bb[4];
+                const uint32_t ba = b2base;
+                f32x4 &r0_ = bb[0], &r1_ = bb[1], &r2_ = bb[2], &r3_ = bb[3];
+                DSR128X4_WAIT(r0_, r1_, r2_, r3_, ba, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
+                f32x16 t = acc2[O];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bf16x4 y = __builtin_bit_cast(bf16x4, yv[s0 + i][q]);
-                        f32x4 v;
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 a = f32x2{t[4 * q], t[4 * q + 1]} + f32x2{bb[q][0], bb[q][1]};
+                    const f32x2 b = f32x2{t[4 * q + 2], t[4 * q + 3]} + f32x2{bb[q][2], bb[q][3]};
+                    rs2 = rs2 + a;
+                    rs2 = rs2 + b;
+                    const f32x4 v = {a[0], a[1], b[0], b[1]};
+                    if (live) *(f32x4*)(xs + xso_ * O + xsq_ * q) = v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ((acc2[O][4 * q + e] + bb[q][e]) + xv[xi][q][e]) + (float)y[e];
-                        if (live) *(f32x4*)(xs + xso_ * O + xsq_ * q) = v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            acc2[O][4 * q + e] = v[e];
-                            rs += v[e];
-                        }
-                    }
-                });
+                    for (int e = 0; e < 4; ++e) t[4 * q + e] = v[e];
+                }
+                acc2[O] = t;
+                __builtin_amdgcn_sched_barrier(0);
             });
             if (p.xn_out) {
                 // LayerNorm-1 of the next block on the finished row (the two h-lanes of a row hold all of it), as bf16
-                rs += __shfl_xor(rs, 32, 64);
+                const float rs = row_sum(rs2[0] + rs2[1]);
                 const float mean = rs * (1.0f / D);
-                float qs = 0.f;
+                const f32x2 mean2 = {mean, mean};
+                f32x2 qs2 = {0.f, 0.f};
 #pragma unroll
                 for (int O = 0; O < NOT; ++O)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const float a = acc2[O][e] - mean;
-                        qs = __builtin_fmaf(a, a, qs);
+                    for (int e = 0; e < 16; e += 2) {
+                        const f32x2 a = f32x2{acc2[O][e], acc2[O][e + 1]} - mean2;
+                        qs2 = __builtin_elementwise_fma(a, a, qs2);
                     }
-                qs += __shfl_xor(qs, 32, 64);
+                const float qs = row_sum(qs2[0] + qs2[1]);
                 const float rstd = 1.0f / sqrtf(qs * (1.0f / D) + p.ln_eps);
-                bf16_t* nr = IMG ? (bf16_t*)p.xn_out + fb + 8 * li + 4 * h : (bf16_t*)p.xn_out + rb;
+                const f32x2 rstd2 = {rstd, rstd};
+                bf16_t* nr = IMG ? (bf16_t*)p.xn_out + fb + 8 * li_ + 4 * h_ : (bf16_t*)p.xn_out + rb;
                 sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
                     constexpr int O = decltype(O_)::value;
@@ -782,14 +598,15 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                     DSR128X4_WAIT(b0, b1_, b2_, b3, ga, D * 4 + O * 128, D * 4 + O * 128 + 32, D * 4 + O * 128 + 64, D * 4 + O * 128 + 96);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float y[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc2[O][4 * q + e] - mean) * rstd, gq[q][e], bqv[q][e]);
+                        const f32x2 va = {acc2[O][4 * q], acc2[O][4 * q + 1]}, vb = {acc2[O][4 * q + 2], acc2[O][4 * q + 3]};
+                        const f32x2 ya = __builtin_elementwise_fma((va - mean2) * rstd2, f32x2{gq[q][0], gq[q][1]}, f32x2{bqv[q][0], bqv[q][1]});
+                        const f32x2 yb = __builtin_elementwise_fma((vb - mean2) * rstd2, f32x2{gq[q][2], gq[q][3]}, f32x2{bqv[q][2], bqv[q][3]});
                         u32x2 o2;
-                        o2[0] = pack_bf16x2(y[0], y[1]);
-                        o2[1] = pack_bf16x2(y[2], y[3]);
+                        o2[0] = pack_bf16x2(ya[0], ya[1]);
+                        o2[1] = pack_bf16x2(yb[0], yb[1]);
                         if (live) *(u32x2*)(nr + yo_ * O + yq_ * q) = o2;
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 });
             }
         }
@@ -806,7 +623,7 @@ bool hipt_mlp32_supported(int dtype, int D_, int hidden) {
     return dtype == HIPT_BF16 && D_ == 384 && hidden % 128 == 0 && hidden >= 256 && hidden <= 1536;
 }
 
-int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D_, int hidden, void* packed, hipStream_t st, const void* wproj) {
+int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D_, int hidden, void* packed, hipStream_t st) {
     if (!(D_ == 384 && hidden % 128 == 0 && hidden >= 256 && hidden <= 1536)) {
         hipt_set_error("mlp32 pack: unsupported D=%d hidden=%d", D_, hidden);
         return HIPT_E_UNSUPPORTED;
@@ -814,45 +631,25 @@ int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D_, int hidden, v
     const int64_t chunks = (int64_t)(hidden / 128) * 4 * (UNIT / 16);
     hipLaunchKernelGGL(mlp32_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const bf16_t*)w1, (const bf16_t*)w2, hidden, (u32x4*)packed);
     HIPT_CHECK_LAUNCH();
-    if (wproj) {
-        hipLaunchKernelGGL(mlp32_pack_proj_kernel, dim3((6 * (UNIT / 16) + 255) / 256), dim3(256), 0, st, (const bf16_t*)wproj, (u32x4*)packed + chunks);
-        HIPT_CHECK_LAUNCH();
-    }
     return HIPT_OK;
 }
 
 template <int DBG>
 int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     MlpParams p = p_in;
-    const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4 + D * 4 + 256;
-    if (!p.wpk || p.wpk_fmt != 1 || (p.img & 2 && !(p.img & 1)) || (p.img && p.M % 16 != 0) || (p.fold && (!(p.img & 1) || !p.y1 || !p.bproj))) {
-        hipt_set_error("mlp32: needs its packed weights; activation images need M %% 16 == 0 and img in {0, 1, 3}; fold needs images (img=%d, M=%d, fold=%d)", p.img,
+    const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4;
+    if (!p.wpk || p.wpk_fmt != 1 || (p.img & 2 && !(p.img & 1)) || (p.img && p.M % 16 != 0) || p.fold) {
+        hipt_set_error("mlp32: needs its packed weights; activation images need M %% 16 == 0 and img in {0, 1, 3}; no proj folding (img=%d, M=%d, fold=%d)", p.img,
                        p.M, p.fold);
         return HIPT_E_BADARG;
     }
-#ifdef HIPT_EXPERIMENTS  // proj folded into the MLP (break-even): tools/mlp_probe.hip builds it, the library does not
-    auto k = p.fold ? (p.img == 3 ? mlp32_kernel<true, true, DBG, true> : mlp32_kernel<true, false, DBG, true>)
-             : p.img == 3 ? mlp32_kernel<true, true, DBG>
-             : p.img == 1 ? mlp32_kernel<true, false, DBG>
-                          : mlp32_kernel<false, false, DBG>;
-#else
-    if (p.fold) {
-        hipt_set_error("mlp32: the proj-folding kernel exists only in experiment builds (HIPT_EXPERIMENTS)");
-        return HIPT_E_UNSUPPORTED;
-    }
     auto k = p.img == 3 ? mlp32_kernel<true, true, DBG> : p.img == 1 ? mlp32_kernel<true, false, DBG> : mlp32_kernel<false, false, DBG>;
-#endif
     static DevOnce once;
     HIPT_CUR_DEVICE(dev);
     if (!once.done[dev]) {
         if (hipFuncSetAttribute((const void*)mlp32_kernel<true, true, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)mlp32_kernel<true, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)mlp32_kernel<false, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess
-#ifdef HIPT_EXPERIMENTS
-            || hipFuncSetAttribute((const void*)mlp32_kernel<true, true, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)mlp32_kernel<true, false, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess
-#endif
-        ) {
+            hipFuncSetAttribute((const void*)mlp32_kernel<false, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(mlp32) failed");
             return HIPT_E_LAUNCH;
         }
@@ -904,18 +701,15 @@ int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
             if (h[b * 16 + 11] < t0) t0 = h[b * 16 + 11];
             if (h[b * 16 + 10] > t4) t4 = h[b * 16 + 10];
         }
-        double pro = 0, chunks = 0, epi = 0, ghz = 0, pp[5] = {0, 0, 0, 0, 0};
+        double pro = 0, chunks = 0, epi = 0, ghz = 0;
         for (int b = 0; b < grid; ++b) {
             pro += (double)(h[b * 16 + 2] - h[b * 16 + 0]) * 0.01 / grid;
             chunks += (double)(h[b * 16 + 3] - h[b * 16 + 2]) * 0.01 / grid;
             epi += (double)(h[b * 16 + 4] - h[b * 16 + 3]) * 0.01 / grid;
-            const int ix[6] = {0, 5, 6, 7, 12, 2};
-            for (int i = 0; i < 5; ++i) pp[i] += (double)(h[b * 16 + ix[i + 1]] - h[b * 16 + ix[i]]) * 0.01 / grid;
             ghz += (double)(h[b * 16 + 9] - h[b * 16 + 8]) / (double)(h[b * 16 + 3] - h[b * 16 + 2]) * 0.1 / grid;
         }
         fprintf(stderr, "[mlp32 dbg=%d hidden=%d grid=%d tiles=%d(+%d)] total %.1f us | tile %d of each workgroup: rows+LN %.1f, chunks %.1f (%.2f GHz), epilogue %.1f\n",
                 DBG, p.hidden, grid, p.full_tiles, p.ntiles - p.full_tiles, (double)(t4 - t0) * 0.01, PSTAMP_SEQ, pro, chunks, ghz, epi);
-        if (!p.fold) fprintf(stderr, "    rows+LN: loads 0 %.1f, LN 0 %.1f, loads 1 %.1f, LN 1 %.1f, to operand %.1f\n", pp[0], pp[1], pp[2], pp[3], pp[4]);
     }
 #endif
     return HIPT_OK;

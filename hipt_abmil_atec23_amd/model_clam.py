@@ -14,8 +14,11 @@ on-device top-k of the instance branch), two backward (rows; weight gradients), 
 ``CLAM_MB`` alike.  Only the pieces the caller supplies as Python callables stay PyTorch ops: the instance classifiers'
 ``Linear(S1, 2)`` on the 2k gathered rows and ``instance_loss_fn`` (``SmoothTop1SVM`` in the reference's scripts).
 Outside the HIP path, by design: the ungated ``Attn_Net`` variant (``gate=False``; SURVEY.md allows the fallback) and
-tensors on the CPU in training mode (PyTorch ops, so that ``main.py`` still runs where there is no GPU).
-There is no CPU path for the HIP inference forwards: a CPU bag raises.
+bags that live on the CPU -- training or not -- which run the module's PyTorch-op sequence on the CPU: the reference picks
+the CPU itself where no GPU is visible (``relocate``, models/model_clam.py:102-106; SURVEY.md 8b "CPU tensors -> CPU
+restatement"), so ``main.py`` / ``eval.py`` still run there.  That is a property of where the CALLER put the tensors, never a
+fallback: a bag on a HIP device always takes the kernels, and a missing library raises (``NativeLibraryError``).  The ViTs
+have no CPU path at all.
 """
 from __future__ import annotations
 
@@ -122,8 +125,8 @@ class Attn_Net_Gated(nn.Module):
 
     def forward(self, x):
         dropout_on = self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in self.modules())
-        if self.attention_c.out_features != 1 or dropout_on or _needs_autograd(self, x):
-            return self._torch_forward(x)  # training / multi-branch (CLAM_MB): PyTorch ops on the same device
+        if self.attention_c.out_features != 1 or dropout_on or _needs_autograd(self, x) or not x.is_cuda:
+            return self._torch_forward(x)  # training / multi-branch (CLAM_MB) / a CPU tensor: PyTorch ops on the same device
         N.require_cuda(x, "Attn_Net_Gated")
         w = self._pack(x.device)
         if x.dim() < 1 or x.shape[-1] != w.s1:
@@ -453,7 +456,9 @@ class CLAM_SB(nn.Module):
             return self._train_forward(h, label, instance_eval, return_features, attention_only)
         # whatever the training kernels do not take (ungated head, CPU tensors, > 8 classes, widths beyond their LDS) keeps the
         # PyTorch-op sequence as soon as dropout is active or a gradient is needed: the inference kernels have neither
-        if not self._gate or dropout_on or _needs_autograd(self, h) or self._multi:
+        # ... and so does a bag the caller keeps on the CPU (the reference's relocate() chooses the CPU where there is no GPU,
+        # models/model_clam.py:102-106): PyTorch ops on the CPU.  A bag on a HIP device never comes this way.
+        if not self._gate or dropout_on or _needs_autograd(self, h) or self._multi or not h.is_cuda:
             return self._torch_forward(h, label, instance_eval, return_features, attention_only)
         N.require_cuda(h, "CLAM_SB")
         if h.dim() != 2 or h.shape[0] == 0:

@@ -3,6 +3,7 @@ keeps the reference's state-dict / constructor / import-path contract, and CPU i
 (there is no CPU execution path in the product)."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -33,6 +34,90 @@ def test_struct_layouts_match_header():
     assert C.sizeof(N.ImageLayout) == 4 * 4 + 3 * 8
     assert C.sizeof(N.ClamWeights) == 6 * 4 + 8 * 8 + 8 + 8 and N.ClamWeights.logit_bound.offset == 6 * 4 + 8 * 8
     assert N.VitWeights.ln_eps.offset == 28 and N.VitWeights.attn_scale.offset == 32 and N.VitWeights.embed_w.offset == 40
+
+
+def test_struct_layouts_match_the_c_header_as_gcc_sees_it(tmp_path):
+    """sizeof / offsetof of every ABI struct from include/hipt_abmil.h itself (compiled by gcc) against the ctypes mirror."""
+    import ctypes as C
+    import subprocess
+
+    structs = {"hipt_clam_weights": N.ClamWeights, "hipt_vit_weights": N.VitWeights, "hipt_block_weights": N.BlockWeights,
+               "hipt_image_layout": N.ImageLayout}
+    lines = []
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "hipt_abmil.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_integration_md_binding_is_the_current_abi():
+    """INTEGRATION.md section 3 shows the stand-alone ctypes binding a maintainer would copy: its code block must run against the
+    built library and declare hipt_clam_weights exactly as the header / the shipped binding do (it was one ABI behind)."""
+    import ctypes as C
+
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 3. Binding the C ABI directly"):]
+    block = sec[sec.index("```python") + len("```python"):]
+    block = block[:block.index("```")]
+    N.lib()  # (torch first, then the library: the load order the document states)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        exec(compile(block, "INTEGRATION.md#3", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    doc_cls = ns["ClamWeights"]
+    assert C.sizeof(doc_cls) == C.sizeof(N.ClamWeights)
+    assert [(n, getattr(doc_cls, n).offset, getattr(doc_cls, n).size) for n, _ in doc_cls._fields_] == \
+           [(n, getattr(N.ClamWeights, n).offset, getattr(N.ClamWeights, n).size) for n, _ in N.ClamWeights._fields_]
+    assert ns["lib"].hipt_abi_version() == N.ABI_VERSION
+    assert callable(ns["clam_sb_forward"])
+
+
+def test_asm_read_audit_is_clean_and_part_of_the_build():
+    """Every hot kernel relies on inline-asm loads whose destinations hipcc must not touch before a hand-counted wait (a hit is a
+    wrong result or a GPU memory fault).  The Makefile audits the .s of every object as it is built and refuses to link on a hit;
+    this test re-runs that verdict (make re-builds anything stale first) and checks the audit sees the in-flight reads at all."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "hipt_abmil_atec23_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "-j", "8", "audit"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for f in ("mlp32", "qkv_attention", "abmil32", "embed32", "seqgemm_pipe"):
+        assert f"{f}.hip: violations: 0" in r.stdout, r.stdout
+    # the checker itself: a register of an asm load still in flight across a loop back-edge, touched at the loop head
+    syn = """_Z3fooPv:
+.LBB0_1:
+	v_mov_b32_e32 v9, v5
+	;;#ASMSTART
+	s_waitcnt vmcnt(0) ; XOP_FENCE
+	;;#ASMEND
+	;;#ASMSTART
+	global_load_dwordx4 v[4:7], v[0:1], off
+	;;#ASMEND
+	s_cbranch_scc1 .LBB0_1
+	;;#ASMSTART
+	s_waitcnt vmcnt(0) ; XOP_FENCE
+	;;#ASMEND
+	s_endpgm
+.Lfunc_end0:
+"""
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        f.write(syn)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_reads.py"), f.name], capture_output=True, text=True)
+    os.unlink(f.name)
+    assert r.returncode == 1 and "violations: 1" in r.stdout, r.stdout
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -103,7 +188,7 @@ def test_clam_state_dict_contract_and_demo_checkpoint_keys():
         assert hasattr(m, attr)
 
 
-def test_cpu_inputs_raise_and_training_path_is_torch():
+def test_cpu_inputs_vits_raise_clam_runs_torch_ops_on_the_cpu():
     from hipt_abmil_atec23_amd import CLAM_SB, HIPT_4K
     from hipt_abmil_atec23_amd.vision_transformer import vit_small
     with pytest.raises(RuntimeError, match="HIP device"):
@@ -111,10 +196,26 @@ def test_cpu_inputs_raise_and_training_path_is_torch():
     h = HIPT_4K(None, None, "cpu", "cpu")
     with pytest.raises(RuntimeError, match="HIP device"):
         h(torch.zeros(1, 3, 256, 256))
+    # CLAM modules on CPU tensors run the PyTorch-op sequence on the CPU, as the reference does where relocate() finds no GPU
+    # (models/model_clam.py:102-106); checked against the numpy oracle.  No native call is made.
+    from hipt_abmil_atec23_amd import CLAM_MB, Attn_Net_Gated
+    from oracle import hipt_oracle as O
+    sc = synth.clam_param_specs((192, 128, 64))
     c = CLAM_SB(size_arg="hipt_big").eval()
+    c.load_state_dict(synth.make_state_dict(sc, 7))
+    hb = synth.hash_uniform_torch((40, 192), 11)
+    calls = N.calls
     with torch.no_grad():
-        with pytest.raises(RuntimeError, match="HIP device"):
-            c(torch.zeros(5, 192))
+        logits, y_prob, y_hat, a_raw, _ = c(hb)
+        a_only = c(hb, attention_only=True)
+        g = Attn_Net_Gated(L=384, D=128).eval()
+        a_g, x_g = g(torch.zeros(3, 384))
+        mb = CLAM_MB(size_arg="hipt_big", n_classes=3).eval()
+        out_mb = mb(hb)
+    ref = O.clam_sb_forward(hb.numpy(), synth.make_params_np(sc, 7))
+    assert np.abs(a_raw.numpy() - ref["A_raw"]).max() < 1e-5 and np.abs(logits.numpy() - ref["logits"]).max() < 1e-5
+    assert int(y_hat) == int(np.asarray(ref["Y_hat"]).reshape(-1)[0]) and torch.equal(a_only, a_raw) and a_g.shape == (3, 1) and out_mb[0].shape == (1, 3)
+    assert N.calls == calls
     # differentiable forward (main.py trains this module) is the documented PyTorch-ops training path
     logits, y_prob, y_hat, a_raw, res = c(torch.randn(20, 192), label=torch.tensor([1]), instance_eval=True)
     (logits.sum() + res["instance_loss"]).backward()

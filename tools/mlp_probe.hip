@@ -24,6 +24,12 @@ int hipt_mlp_pipe_launch(const MlpParams&, hipStream_t) { return -1; }
 #include "../hipt_abmil_atec23_amd/csrc/mlp32.hip"
 #define LAUNCH(DBG, p) hipt_mlp32_launch_dbg<DBG>(p, 0)
 #define hipt_mlp_pack_launch hipt_mlp32_pack_launch
+#elif defined(PROBE_32R3)  // round 3's mlp32 (row phases in the 16-row fragment layout, epilogue re-reads x and y1; proj folding); -DPROBE_32R3
+#define HIPT_EXPERIMENTS
+#include "experiments/mlp32_r3.hip"
+#define PROBE_32
+#define LAUNCH(DBG, p) hipt_mlp32_launch_dbg<DBG>(p, 0)
+#define hipt_mlp_pack_launch hipt_mlp32_pack_launch
 #else  // the pipelined D = 384 kernel (mlp_pipe.hip)
 #include "experiments/mlp_pipe.hip"
 #define LAUNCH(DBG, p) hipt_mlp_pipe_launch_dbg<DBG>(p, 0)
@@ -73,7 +79,7 @@ static float bf2f(uint16_t b) {
     return f;
 }
 
-#ifdef PROBE_CO
+#if 1
 // activation images (kernels.h): 16-row fragments; fp32: col 32 O + 8 q + 4 h + e of row li at 512 O + 256 h + 64 q + 4 li + e; bf16: 512 O + 128 q + 8 li + 4 h + e
 static size_t img_f32(int r, int c) { const int f = r / 16, li = r % 16, O = c / 32, q = (c / 8) & 3, h = (c / 4) & 1, e = c & 3; return (size_t)f * 16 * 384 + 512 * O + 256 * h + 64 * q + 4 * li + e; }
 static size_t img_bf16(int r, int c) { const int f = r / 16, li = r % 16, O = c / 32, q = (c / 8) & 3, h = (c / 4) & 1, e = c & 3; return (size_t)f * 16 * 384 + 512 * O + 128 * q + 8 * li + 4 * h + e; }
@@ -106,19 +112,22 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&g, D * 4));
     CK(hipMalloc(&bt, D * 4));
 #ifdef PROBE_CO
+    const int img_mode = 3;
+#else
+    const int img_mode = (check && getenv("PROBE_IMG")) ? atoi(getenv("PROBE_IMG")) : 0;  // check: 0 row-major, 1 = y1 / out images, 3 = x in as well
+#endif
     std::vector<float> hxi(hx.size());
     std::vector<uint16_t> hyi(hy.size());
-    for (int r = 0; r < M; ++r)
-        for (int c = 0; c < D; ++c) {
-            hxi[img_f32(r, c)] = hx[(size_t)r * D + c];
-            hyi[img_bf16(r, c)] = hy[(size_t)r * D + c];
-        }
-    CK(hipMemcpy(x, hxi.data(), hx.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(y, hyi.data(), hy.size() * 2, hipMemcpyHostToDevice));
-#else
-    CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(y, hy.data(), hy.size() * 2, hipMemcpyHostToDevice));
-#endif
+    if (img_mode) {
+        if (M % 16) { printf("image forms need M %% 16 == 0\n"); return 1; }
+        for (int r = 0; r < M; ++r)
+            for (int c = 0; c < D; ++c) {
+                hxi[img_f32(r, c)] = hx[(size_t)r * D + c];
+                hyi[img_bf16(r, c)] = hy[(size_t)r * D + c];
+            }
+    }
+    CK(hipMemcpy(x, img_mode == 3 ? hxi.data() : hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(y, img_mode ? hyi.data() : hy.data(), hy.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(w1, hw1.data(), hw1.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(w2, hw2.data(), hw2.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(b1, hb1.data(), H * 4, hipMemcpyHostToDevice));
@@ -142,17 +151,20 @@ int main(int argc, char** argv) {
 #endif
     }
 #endif
-#ifdef PROBE_CO
-    void* xn_co;
-    CK(hipMalloc(&xn_co, hy.size() * 2));
-    p.img = 3; p.xn_out = xn_co; p.ln_next_w = (float*)g; p.ln_next_b = (float*)bt;
+    void* xn_co = nullptr;
+#if defined(PROBE_CO) || defined(PROBE_32)
+    if (check) {  // the chained LayerNorm output is checked too
+        CK(hipMalloc(&xn_co, hy.size() * 2));
+        CK(hipMemset(xn_co, 0xff, hy.size() * 2));
+        p.img = img_mode; p.xn_out = xn_co; p.ln_next_w = (float*)g; p.ln_next_b = (float*)bt;
+    }
 #endif
     if (getenv("PROBE_IMG") && !check) {  // as inside the pipeline: activation images + the next block's LayerNorm-1 output
         void* xn;
         CK(hipMalloc(&xn, hy.size() * 2));
         p.img = 3; p.xn_out = xn; p.ln_next_w = (float*)g; p.ln_next_b = (float*)bt;
     }
-#ifdef PROBE_32
+#ifdef PROBE_32R3
     if (argc > 1 && strcmp(argv[1], "checkfold") == 0) {
         // the proj Linear folded in: p.y1 = the attention output as a bf16 image, x row-major in / image out; the host evaluates
         // v = x + att . Wp^T + bp, then the MLP on the bf16 operands, in fp64
@@ -223,16 +235,14 @@ int main(int argc, char** argv) {
         CK(hipDeviceSynchronize());
         std::vector<float> out((size_t)M * D);
         CK(hipMemcpy(out.data(), x, out.size() * 4, hipMemcpyDeviceToHost));
-#ifdef PROBE_CO
         std::vector<uint16_t> hxn((size_t)M * D);
-        CK(hipMemcpy(hxn.data(), xn_co, hxn.size() * 2, hipMemcpyDeviceToHost));
-        {
+        if (xn_co) CK(hipMemcpy(hxn.data(), xn_co, hxn.size() * 2, hipMemcpyDeviceToHost));
+        if (img_mode) {
             std::vector<float> t(out);
             for (int r = 0; r < M; ++r)
                 for (int c = 0; c < D; ++c) out[(size_t)r * D + c] = t[img_f32(r, c)];
         }
         double maxerr_n = 0;
-#endif
         double maxerr = 0;
         long nbad = 0, nnan = 0;
         int first_bad_row = -1, first_bad_col = -1;
@@ -259,8 +269,7 @@ int main(int argc, char** argv) {
                 if (e > maxerr) maxerr = e;
                 if (e > 2e-2) { ++nbad; if (first_bad_row < 0) { first_bad_row = r; first_bad_col = n; } }
             }
-#ifdef PROBE_CO
-            {   // the chained LayerNorm of the next block, from the kernel's own fp32 output
+            if (xn_co) {   // the chained LayerNorm of the next block, from the kernel's own fp32 output
                 double mu = 0, va = 0;
                 for (int n = 0; n < D; ++n) mu += out[(size_t)r * D + n];
                 mu /= D;
@@ -268,21 +277,20 @@ int main(int argc, char** argv) {
                 const double rs = 1.0 / sqrt(va / D + 1e-6);
                 for (int n = 0; n < D; ++n) {
                     const double ref = (out[(size_t)r * D + n] - mu) * rs * hg[n] + hbt[n];
-                    const double e = fabs(bf2f(hxn[img_bf16(r, n)]) - ref);
+                    const double e = fabs(bf2f(hxn[img_mode ? img_bf16(r, n) : (size_t)r * D + n]) - ref);
                     if (e > maxerr_n) maxerr_n = e;
                     if (!(e <= 4e-2)) { ++nbad; if (first_bad_row < 0) { first_bad_row = r; first_bad_col = 1000 + n; } }
                 }
             }
-#endif
         }
+        if (xn_co) printf("chained LayerNorm: max |err| %.3e\n", maxerr_n);
 #ifdef PROBE_CO
-        printf("chained LayerNorm: max |err| %.3e\n", maxerr_n);
         return (nbad || nnan) ? (printf("check M=%d: max |err| %.3e, %ld bad, %ld NaN, first (row %d, col %d)\n", M, maxerr, nbad, nnan, first_bad_row, first_bad_col), 1)
                               : (printf("check M=%d: max |err| %.3e OK\n", M, maxerr), 0);
 #endif
-        {   // batch invariance: the same rows at a different position inside the tiles must give the same bits
-            const int sh = argc > 3 ? atoi(argv[3]) : 12;
-            CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        if (!img_mode || (argc > 3 && atoi(argv[3]) % 16 == 0)) {   // batch invariance: the same rows at a different position inside the tiles must give the same bits
+            const int sh = argc > 3 ? atoi(argv[3]) : 12;   // (image forms: whole fragments, i.e. a multiple of 16)
+            CK(hipMemcpy(x, img_mode == 3 ? hxi.data() : hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
             MlpParams p2 = p;
             p2.x = (float*)x + (size_t)sh * D;
             p2.y1 = (const uint16_t*)y + (size_t)sh * D;
@@ -291,6 +299,11 @@ int main(int argc, char** argv) {
             CK(hipDeviceSynchronize());
             std::vector<float> out2((size_t)M * D);
             CK(hipMemcpy(out2.data(), x, out2.size() * 4, hipMemcpyDeviceToHost));
+            if (img_mode) {   // (the shifted launch's fragments start sh rows later: un-image relative to its own base)
+                std::vector<float> t(out2);
+                for (int r = sh; r < M; ++r)
+                    for (int c = 0; c < D; ++c) out2[(size_t)r * D + c] = t[(size_t)sh * D + img_f32(r - sh, c)];
+            }
             long ndiff = 0;
             int fr = -1, fc = -1;
             for (int r = sh; r < M; ++r)
@@ -317,6 +330,15 @@ int main(int argc, char** argv) {
     masks.push_back(8);
     masks.push_back(12);
     masks.push_back(15);
+#endif
+#ifdef PROBE_FEW  // (-DPROBE_FEW: only the complete kernel and three ablations are instantiated: a quarter of the compile time)
+    for (int m : masks) switch (m) {
+            case 0: run<0>(p, iters); break;
+            case 2: run<2>(p, iters); break;
+            case 8: run<8>(p, iters); break;
+            case 15: run<15>(p, iters); break;
+        }
+    return 0;
 #endif
     for (int m : masks) switch (m) {
             case 0: run<0>(p, iters); break;
