@@ -50,17 +50,10 @@ __device__ __forceinline__ void mma32(f32x16& acc, const u32x4& a, const u32x4& 
 #ifndef PSTAMP_SEQ
 #define PSTAMP_SEQ 0  // which tile of a workgroup the debug stamps describe (0 = the first: every CU in step)
 #endif
-// Diagnostic builds only.  A stamp is read into SCALAR registers where it happens, unconditionally, and a tile's stamps are stored in
-// one place at the end of the tile: even a uniform branch around a clock read is a basic-block boundary, and one between the row
-// phase and the first ring phase makes hipcc spill the operand registers (353 spills in such a stamp build against 2 in the release
-// build) -- the stamp build would time a different kernel.
-#ifdef HIPT_DEBUG_STAMPS
-#define PSTAMP(k) stamp_rt[k] = __builtin_amdgcn_s_memrealtime()
-#define PSTAMP_CLK(k) stamp_clk[k] = __builtin_amdgcn_s_memtime()
-#else
-#define PSTAMP(k) (void)stamp_rt
-#define PSTAMP_CLK(k) (void)stamp_clk
-#endif
+#define PSTAMP(k)                                                                                                    \
+    do {                                                                                                             \
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
 enum { KA = 0, KB = 1 };  // phase kind: fc1 half / fc2 half
 
@@ -118,10 +111,6 @@ __global__ void mlp32_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* _
 // fragment reads.
 template <bool IMG = false, bool XIN = false, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
-    // DBG 64 (tools/mlp_probe.hip): WITH the L2 prefetch of the next tile's rows (prefetch_rows below).  Measured, interleaved on one
-    // box at 8 regions: 1 419-1 432 us with it, 1 384-1 388 without -- the row phase falls from 13.5 to 9 us per tile, the chunk phases
-    // take 6 k more cycles and the chip gives the saved idle time back as clock (1.63 instead of 1.73 GHz): off.
-    constexpr bool PF = (DBG & 64) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gam = (float*)(smem + 3 * UNIT);
     float* bet = gam + D;
@@ -129,7 +118,6 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     float* b1s = b2s + D;                  // [hidden]
     int* tile_s = (int*)(b1s + p.hidden);  // [2] tile handed to this workgroup, double-buffered by parity
     float* gam1 = (float*)(tile_s + 4);    // next block's LayerNorm-1 (gamma | beta), if p.xn_out
-    float* pfj = gam1 + 2 * D;             // [64] where the L2-prefetch loads below drop their dwords (never read)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,27 +141,6 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(smem + islot * UNIT + (12 * wave + (t & ~3)) * 1024), 16, ilane, ioff + (t & ~3) * 1024, (t & 3) * 1024, 0);
     };
 
-    // ---- L2 prefetch of the NEXT tile's row-phase inputs.  The row phase is latency: with 255 other CUs streaming weights a wave waits
-    // ~9 us for its 36 KiB of rows (14 us row phase; 6.7 us when the chip is otherwise quiet).  Touching one dword of every 128-byte
-    // line of the next tile's x and y1 rows from inside the LAST ring phase of this tile turns that wait into L2 hits.  The loads
-    // are LDS-DMA (no destination register: nothing for the register allocator to keep alive), all into one 256-byte scratch line;
-    // rows past the tile's end are out of the resource's range and dropped.  Nine instructions per wave: line (4 k + wave) * 64 + lane
-    // of x (k < 6) and of y1 (k < 3).  Why only in the last phase: vmcnt is ONE in-order counter -- a ring wait behind such a touch
-    // waits for HBM (round 2 issued them three phases ahead and lost 7 us of chunk phases to exactly that); the last phase's own
-    // wait leaves them in flight (vmcnt(NPF)), and the next ring wait is a whole epilogue + row phase away.
-    auto prefetch_rows = [&](int t_row0, int t_nrows) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)t_row0 * D), 0, t_nrows * D * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ry =
-            __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.y1 + (int64_t)t_row0 * D), 0, p.y1 ? t_nrows * D * 2 : 0, 0x00020000);
-        int ln;  // (a fresh lane id: the kernel-long one is spilled, and a scratch reload here would wait for the pieces in flight)
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-        const uint32_t vo = (uint32_t)(wave * 8192 + ln * 128);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (LDS_AS void*)pfj, 4, vo, k * 32768, 0, 0);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (LDS_AS void*)pfj, 4, vo, k * 32768, 0, 0);
-    };
-    constexpr int NPF = 9;                   // (what the last phase's ring wait leaves in flight)
     constexpr int NRD = (DBG & 16) ? 2 : 4;  // fragment reads per group
 
     for (int i = tid; i < D; i += 256) {
@@ -265,7 +232,6 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
             nrows = 16;
         }
         nrows = (p.M - row0) < nrows ? (p.M - row0) : nrows;
-        unsigned long long stamp_rt[5] = {0, 0, 0, 0, 0}, stamp_clk[2] = {0, 0};
         PSTAMP(0);
         // next tile: requested now, handed to LDS behind the first row loads (the atomic's round trip is theirs too), read by every
         // wave after the first ring barrier
@@ -307,10 +273,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                 // (1) fragment reads one group ahead
                 if constexpr (gg == 11) {
                     if constexpr ((DBG & 1) == 0) {
-                        if constexpr (needb < 0 && PF)
-                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPF) : "memory");  // (all but the row touches of group 5)
-                        else
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of the next unit have landed
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of the next unit have landed
                         __builtin_amdgcn_s_barrier();                     // ... everyone's; unit cons-1 is no longer read
                     }
                     set_issue(ipos, (cons + 2) % 3);
@@ -368,7 +331,6 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                     dma_piece(std::integral_constant<int, 2 + 2 * gg>{});
                     dma_piece(std::integral_constant<int, 3 + 2 * gg>{});
                 }
-                if constexpr (needb < 0 && PF && gg == 5) prefetch_rows(row0_next, nrows_next);
                 if constexpr (gh >= 0 && gg >= 4) {
                     gelu_unit(std::integral_constant<int, (gh >= 0 ? gh : 0)>{}, std::integral_constant<int, 8 * gsec + gg - 4>{});
                 }
@@ -382,27 +344,22 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         typedef std::integral_constant<int, 64> I64;
         typedef std::integral_constant<int, 128> I128;
 
-        // Where this lane's row lives (row phase and epilogue).  Rows are reached through BUFFER resources over the tile's rows -- a
-        // uniform 64-bit base in scalar registers, one 32-bit lane offset, the piece (O, q) in the instruction's scalar offset:
-        //   * no 64-bit lane arithmetic: its zero high word is a register hipcc keeps across the whole kernel, spills, and reloads at
-        //     the head of the epilogue -- a vmcnt(0) there, behind the row touches above;
-        //   * a row past the tile's end gets an offset out of the resource's range: its loads return zeros without traffic and its
-        //     stores are dropped -- no predication around 96 stores, no clamped re-reads;
-        //   * everything lane-dependent comes from a FRESH lane id: loop-invariant addresses would be hoisted out of the tile loop,
-        //     live through the chunk phases, and be spilled there.
-        // rb: element offset of the row's columns 4 h .. (row-major forms), fb: of its 16-row fragment (image forms: whole fragments
-        // only -- the launcher guarantees M % 16 == 0).
-        constexpr uint32_t OOB = 0x80000000u;
-        auto row_base = [&](int t_nrows, int& li_, int& h_, uint32_t& rb, uint32_t& fb, bool& live) __attribute__((always_inline)) {
+        // where this lane's row lives (row phase and epilogue; formed where it is used: kept across the chunk phases the pointers
+        // would be spilled, and a scratch reload inside a ring phase waits for the LDS-DMA in flight).  rb: float / element offset of
+        // the row's columns 4 h.. (row-major forms), fb: of its 16-row fragment (image forms: whole fragments only -- the launcher
+        // guarantees M % 16 == 0 -- so a fragment past the tile's end has no live row: it re-reads fragment 0, never stored)
+        // (everything lane-dependent is derived from an OPAQUE copy of the lane id: loop-invariant addresses would be hoisted out of
+        //  the tile loop, live through the chunk phases, and be spilled there)
+        auto row_base = [&](int t_row0, int t_nrows, int& li_, int& h_, int64_t& rb, int64_t& fb, bool& live) __attribute__((always_inline)) {
             int ln;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
             li_ = ln & 15;
             h_ = ln >> 5;
             const int m_ = (ln >> 4) & 1;
             const int r = wave * 32 + m_ * 16 + li_;
-            live = r < t_nrows;  // (the BYTE offset of a row that is not live becomes OOB: scaled first, or it would wrap back into range)
-            rb = (uint32_t)(r * D + 4 * h_);
-            fb = (uint32_t)((wave * 32 + m_ * 16) * D);
+            live = r < t_nrows;
+            rb = (int64_t)(t_row0 + (live ? r : 0)) * D + 4 * h_;
+            fb = (int64_t)(t_row0 + (live ? wave * 32 + m_ * 16 : 0)) * D;
         };
         // both lanes of a row (l, l ^ 32) get lo + hi, summed in that order (no LDS crossbar, no lane-id register)
         auto row_sum = [&](float v) __attribute__((always_inline)) -> float {
@@ -420,32 +377,36 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         // All 96 loads of a lane (36 KiB per wave) are in flight together: one memory latency per tile instead of two.
         {
 #pragma clang fp contract(off)
-            uint32_t xo, yo;  // byte offsets of this lane's pieces inside the tile's x / y1 rows
+            const float* xl;
+            const bf16_t* yr;
             uint32_t g2base;  // LN-2 gamma in accumulator column order: gam[32 O + 8 q + 4 h ..] at + (32 O + 8 q) * 4 (beta: + D * 4)
             {
-                uint32_t rb, fb;
-                int li_, h_;
+                int64_t rb, fb;
                 bool live;
-                row_base(nrows, li_, h_, rb, fb, live);
-                xo = live ? (XIN ? fb + (uint32_t)(256 * h_ + 4 * li_) : rb) * 4 : OOB;
-                yo = live ? (IMG ? fb + (uint32_t)(8 * li_ + 4 * h_) : rb) * 2 : OOB;
+                int li_, h_;
+                row_base(row0, nrows, li_, h_, rb, fb, live);
+                xl = XIN ? p.x + fb + 256 * h_ + 4 * li_ : p.x + rb;
+                yr = IMG ? (const bf16_t*)p.y1 + fb + 8 * li_ + 4 * h_ : (const bf16_t*)p.y1 + rb;
                 g2base = (uint32_t)(uintptr_t)(LDS_AS char*)gam + 16 * h_;
             }
             constexpr int xlo_ = XIN ? 512 : 32, xlq_ = XIN ? 64 : 8, yo_ = IMG ? 512 : 32, yq_ = IMG ? 128 : 8;
-            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)row0 * D), 0, nrows * D * 4, 0x00020000);
-            // (no y1: an empty range -- every piece reads as zero)
-            const __amdgpu_buffer_rsrc_t ry =
-                __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.y1 + (int64_t)row0 * D), 0, p.y1 ? nrows * D * 2 : 0, 0x00020000);
             f32x4 xv[NOT][4];
             u32x2 yv[NOT][4];
 #pragma unroll
             for (int O = 0; O < NOT; ++O)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xv[O][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo, (xlo_ * O + xlq_ * q) * 4, 0));
+                for (int q = 0; q < 4; ++q) xv[O][q] = *(const f32x4*)(xl + xlo_ * O + xlq_ * q);
+            if (p.y1) {
 #pragma unroll
-            for (int O = 0; O < NOT; ++O)
+                for (int O = 0; O < NOT; ++O)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) yv[O][q] = __builtin_amdgcn_raw_buffer_load_b64(ry, yo, (yo_ * O + yq_ * q) * 2, 0);
+                    for (int q = 0; q < 4; ++q) yv[O][q] = *(const u32x2*)(yr + yo_ * O + yq_ * q);
+            } else {
+#pragma unroll
+                for (int O = 0; O < NOT; ++O)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) yv[O][q] = u32x2{0u, 0u};
+            }
             if (tid == 0) {
                 asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
                 if (nt_req == last_fetch) *p.counter = 0;
@@ -509,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
             });
         }
         PSTAMP(2);
-        PSTAMP_CLK(0);
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime();
 
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -568,7 +529,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         __builtin_amdgcn_sched_barrier(0);
         phase(TB{}, I1{}, IM1{}, I0{}, IM1{}, 0);
         PSTAMP(3);
-        PSTAMP_CLK(1);
+        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
 
         // ---- epilogue: x <- acc2 + b2 (acc2 started from v = x + y1: nothing is re-read).  This workgroup owns its rows: in place.
         //      Lane (h, m, li) holds row 32 w + 16 m + li; acc2[O][4 q + e] is output column 32 O + 8 q + 4 h + e.
@@ -577,16 +538,15 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         //       fragments, and every old value was loaded in the row phase)
         {
 #pragma clang fp contract(off)
-            uint32_t rb, fb;
-            int li_, h_;
+            int64_t rb, fb;
             bool live;
-            row_base(nrows, li_, h_, rb, fb, live);
-            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)row0 * D), 0, nrows * D * 4, 0x00020000);
+            int li_, h_;
+            row_base(row0, nrows, li_, h_, rb, fb, live);
             const uint32_t b2base = (uint32_t)(uintptr_t)(LDS_AS char*)b2s + 16 * h_;   // b2[32 O + 8 q + 4 h ..]: + (32 O + 8 q) * 4
             const uint32_t g1base = (uint32_t)(uintptr_t)(LDS_AS char*)gam1 + 16 * h_;  // next LN-1 gamma (beta: + D * 4)
             // float / element offsets of piece (O, q): row-major rb + 32 O + 8 q; fp32 image fb + 512 O + 256 h + 64 q + 4 li;
             // bf16 image fb + 512 O + 128 q + 8 li + 4 h
-            const uint32_t xso = live ? (IMG ? fb + (uint32_t)(256 * h_ + 4 * li_) : rb) * 4 : OOB;
+            float* xs = IMG ? p.x + fb + 256 * h_ + 4 * li_ : p.x + rb;
             constexpr int xso_ = IMG ? 512 : 32, xsq_ = IMG ? 64 : 8, yo_ = IMG ? 512 : 32, yq_ = IMG ? 128 : 8;
             f32x2 rs2 = {0.f, 0.f};
             sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
@@ -604,7 +564,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                     rs2 = rs2 + a;
                     rs2 = rs2 + b;
                     const f32x4 v = {a[0], a[1], b[0], b[1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rx, xso, (xso_ * O + xsq_ * q) * 4, 0);
+                    if (live) *(f32x4*)(xs + xso_ * O + xsq_ * q) = v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) t[4 * q + e] = v[e];
                 }
@@ -627,8 +587,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                 const float qs = row_sum(qs2[0] + qs2[1]);
                 const float rstd = 1.0f / sqrtf(qs * (1.0f / D) + p.ln_eps);
                 const f32x2 rstd2 = {rstd, rstd};
-                const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc((void*)((bf16_t*)p.xn_out + (int64_t)row0 * D), 0, nrows * D * 2, 0x00020000);
-                const uint32_t nso = live ? (IMG ? fb + (uint32_t)(8 * li_ + 4 * h_) : rb) * 2 : OOB;
+                bf16_t* nr = IMG ? (bf16_t*)p.xn_out + fb + 8 * li_ + 4 * h_ : (bf16_t*)p.xn_out + rb;
                 sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
                     constexpr int O = decltype(O_)::value;
@@ -645,22 +604,13 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                         u32x2 o2;
                         o2[0] = pack_bf16x2(ya[0], ya[1]);
                         o2[1] = pack_bf16x2(yb[0], yb[1]);
-                        __builtin_amdgcn_raw_buffer_store_b64(o2, rn, nso, (yo_ * O + yq_ * q) * 2, 0);
+                        if (live) *(u32x2*)(nr + yo_ * O + yq_ * q) = o2;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
         }
         PSTAMP(4);
-        if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) {
-            unsigned long long* o = p.stamps + (size_t)blockIdx.x * 16;
-            o[0] = stamp_rt[0];
-            o[2] = stamp_rt[2];
-            o[3] = stamp_rt[3];
-            o[4] = stamp_rt[4];
-            o[8] = stamp_clk[0];
-            o[9] = stamp_clk[1];
-        }
         tile = tile_next;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (continuous stream: pieces of a pass that never runs)
@@ -687,7 +637,7 @@ int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D_, int hidden, v
 template <int DBG>
 int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     MlpParams p = p_in;
-    const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4 + 256;
+    const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4;
     if (!p.wpk || p.wpk_fmt != 1 || (p.img & 2 && !(p.img & 1)) || (p.img && p.M % 16 != 0) || p.fold) {
         hipt_set_error("mlp32: needs its packed weights; activation images need M %% 16 == 0 and img in {0, 1, 3}; no proj folding (img=%d, M=%d, fold=%d)", p.img,
                        p.M, p.fold);

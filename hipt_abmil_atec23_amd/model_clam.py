@@ -63,6 +63,11 @@ def _needs_autograd(module, *tensors) -> bool:
     return any(t.requires_grad for t in tensors) or any(p.requires_grad for p in module.parameters())
 
 
+def _all_on_cpu(module, x) -> bool:
+    """The caller keeps module AND input on the CPU (what the reference's relocate() does where no GPU is visible)."""
+    return not x.is_cuda and not any(p.is_cuda for p in module.parameters())
+
+
 class Attn_Net(nn.Module):
     """Ungated attention head (model_clam.py:15-31); plain PyTorch module (not on the HIP path)."""
 
@@ -125,7 +130,7 @@ class Attn_Net_Gated(nn.Module):
 
     def forward(self, x):
         dropout_on = self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in self.modules())
-        if self.attention_c.out_features != 1 or dropout_on or _needs_autograd(self, x) or not x.is_cuda:
+        if self.attention_c.out_features != 1 or dropout_on or _needs_autograd(self, x) or _all_on_cpu(self, x):
             return self._torch_forward(x)  # training / multi-branch (CLAM_MB) / a CPU tensor: PyTorch ops on the same device
         N.require_cuda(x, "Attn_Net_Gated")
         w = self._pack(x.device)
@@ -458,7 +463,8 @@ class CLAM_SB(nn.Module):
         # PyTorch-op sequence as soon as dropout is active or a gradient is needed: the inference kernels have neither
         # ... and so does a bag the caller keeps on the CPU (the reference's relocate() chooses the CPU where there is no GPU,
         # models/model_clam.py:102-106): PyTorch ops on the CPU.  A bag on a HIP device never comes this way.
-        if not self._gate or dropout_on or _needs_autograd(self, h) or self._multi or not h.is_cuda:
+        # (a CPU bag handed to a module that lives on a HIP device is a caller's mistake and raises below)
+        if not self._gate or dropout_on or _needs_autograd(self, h) or self._multi or _all_on_cpu(self, h):
             return self._torch_forward(h, label, instance_eval, return_features, attention_only)
         N.require_cuda(h, "CLAM_SB")
         if h.dim() != 2 or h.shape[0] == 0:

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Same-box A/B of whole library builds through bench.py itself (the probe's back-to-back launches sit in a power transient that the
+# pipeline does not): tools/bench_ab.sh <rounds> <lib suffix> ... ("" = the shipped library), interleaved; prints regions/s and the
+# per-launch time of the fused MLP / fused attention kernels.
+R=$1; shift
+for r in $(seq 1 $R); do
+  for v in "$@"; do
+    lib=hipt_abmil_atec23_amd/libhipt_abmil${v:+_$v}.so
+    [ "$v" = "-" ] && lib=hipt_abmil_atec23_amd/libhipt_abmil.so
+    HIPT_AMD_LIB=$PWD/$lib python bench.py --no-cpu-baseline --no-extras --slides 0 > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err || { echo "$v FAILED"; tail -3 gpurun_out/ab_tmp.err; continue; }
+    python - "$v" <<PY
+import json, sys
+d = json.loads(open("gpurun_out/ab_tmp.json").read().strip().splitlines()[-1])
+k = d.get("kernels", d.get("per_kernel", {}))
+print(f"{sys.argv[1]:>6}: {d['value']:.1f} regions/s  step {d['ms_per_step']:.2f} ms  mlp {d['roofline']['avg_launch_us']:.1f} us ({d['roofline']['frac']:.4f})  attn unit {d['roofline_attention_unit']['frac']:.4f}  abmil {d['roofline_abmil']['frac']:.4f}  {d['selfcheck']}")
+PY
+  done
+done

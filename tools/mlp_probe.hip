@@ -337,9 +337,10 @@ int main(int argc, char** argv) {
             case 2: run<2>(p, iters); break;
             case 8: run<8>(p, iters); break;
             case 15: run<15>(p, iters); break;
+            case 64: run<64>(p, iters); break;  // (mlp32.hip: WITH the L2 prefetch of the next tile's rows)
         }
     return 0;
-#endif
+#else
     for (int m : masks) switch (m) {
             case 0: run<0>(p, iters); break;
             case 1: run<1>(p, iters); break;
@@ -372,4 +373,5 @@ int main(int argc, char** argv) {
 #endif
         }
     return 0;
+#endif
 }
