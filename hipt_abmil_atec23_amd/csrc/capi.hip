@@ -144,7 +144,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     // s.att as bf16 operands; block i+1's QKV GEMM then skips the fp32 row load + LayerNorm
     // (only the streaming kernels have that epilogue / prologue: every block of the range needs its packed weight images)
     bool chain = seq && !hipt_generic_only() && hipt_mlp32_supported(dt, D, w->hidden) && hipt_seqgemm_pipe_supported(dt, D, 3 * D, false, 0);
-    for (int i = b0; i < b1 && chain; ++i) chain = w->blocks[i].qkv_pk && w->blocks[i].proj_pk && w->blocks[i].mlp_pk && w->blocks[i].mlp_pk_fmt == 1;
+    for (int i = b0; i < b1 && chain; ++i) chain = w->blocks[i].qkv_pk && w->blocks[i].proj_pk && w->blocks[i].mlp_pk && (w->blocks[i].mlp_pk_fmt == 1 || w->blocks[i].mlp_pk_fmt == 2);
     bool have_xn = false;
     // activation images: chained streaming blocks, whole 16-row fragments, no probability output
     const bool img = img_ok && chain && probs == nullptr && M % 16 == 0 && !hipt_env_on("HIPT_NO_IMG") && hipt_attention64_supported(dt, dh, w->ntok, false);
@@ -616,7 +616,12 @@ int hipt_vit_attention_unit(const hipt_vit_weights* w, int block, const void* xn
     return hipt_attention_launch(s.qkv, out_img, nullptr, nseq, w->ntok, w->heads, D / w->heads, attn_scale(w), w->dtype, st, 1, hm ? 1 : 0);
 }
 
-int hipt_vit_mlp_pack_format(const hipt_vit_weights* w) { return (w && hipt_mlp32_supported(w->dtype, w->dim, w->hidden)) ? 1 : 0; }
+// (HIPT_MLP16=1 at PACK time selects the 16x16x32-MFMA form of the fused MLP -- csrc/mlp16.hip, format 2; the format travels
+//  with the image, so a model packed either way keeps running its own kernel whatever the environment says later)
+int hipt_vit_mlp_pack_format(const hipt_vit_weights* w) {
+    if (!(w && hipt_mlp32_supported(w->dtype, w->dim, w->hidden))) return 0;
+    return hipt_env_on("HIPT_MLP16") ? 2 : 1;
+}
 
 size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {
     if (!w || w->dtype != HIPT_BF16) return 0;
@@ -624,7 +629,7 @@ size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {
     switch (what) {
         case HIPT_PACK_QKV: return hipt_seqgemm_pipe_supported(w->dtype, D, 3 * D, false, 0) ? (size_t)3 * D * D * 2 : 0;
         case HIPT_PACK_PROJ: return hipt_seqgemm_pipe_supported(w->dtype, D, D, false, 0) ? (size_t)D * D * 2 : 0;
-        case HIPT_PACK_MLP: return hipt_vit_mlp_pack_format(w) == 1 ? (size_t)2 * D * w->hidden * 2 : 0;
+        case HIPT_PACK_MLP: return hipt_vit_mlp_pack_format(w) != 0 ? (size_t)2 * D * w->hidden * 2 : 0;
         case HIPT_PACK_QKV_ATT: return hipt_qkv_attn_supported(w->dtype, D, w->heads, w->ntok) ? hipt_qkv_attn_packed_bytes() : 0;
         default: return 0;
     }
@@ -649,6 +654,7 @@ int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* 
         default:
             // the format the caller recorded beside the pointer (hipt_vit_mlp_pack_format): pack and launch read the same field
             if (b.mlp_pk_fmt == 1 && hipt_mlp32_supported(w->dtype, D, w->hidden)) return hipt_mlp32_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
+            if (b.mlp_pk_fmt == 2 && hipt_mlp16_supported(w->dtype, D, w->hidden)) return hipt_mlp16_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
             hipt_set_error("hipt_vit_pack_weights: blocks[%d].mlp_pk_fmt = %d is not a format this model has", block, b.mlp_pk_fmt);
             return HIPT_E_BADARG;
     }

@@ -102,7 +102,7 @@ struct MlpParams {
     const float* b2;
     int M, D, hidden;
     const void* wpk;     // optional (streaming kernel only): both weights pre-packed in ring order (hipt_mlp32_pack_launch)
-    int wpk_fmt;         // format of wpk: 1 = mlp32.hip's fragment image (the only one)
+    int wpk_fmt;         // format of wpk: 1 = mlp32.hip's fragment image, 2 = mlp16.hip's
     int img;             // (pipelined kernel only) activation images: bit 0 = y1, xn_out and the updated x, bit 1 = x on entry
     int* counter;        // device int the launcher zeroes on the stream: the kernel's tile queue
     int counter_zeroed;  // 1: the caller guarantees *counter == 0 at launch (mlp32.hip / mlp_co.hip skip their memset); these kernels leave it 0 again
@@ -124,6 +124,12 @@ int hipt_mlp_launch(const MlpParams& p, hipStream_t st);  // dispatches to the p
 bool hipt_mlp32_supported(int dtype, int D, int hidden);
 int hipt_mlp32_launch(const MlpParams& p, hipStream_t st);
 int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);
+// The same kernel on 16x16x32 MFMAs (mlp16.hip; image format 2, same size): the matrix pipes hold a higher clock on that shape under
+// the power cap, the waves pay twice the MFMA issue -- a tie on the fused MLP itself, +3 % on the kernels that run between its
+// launches; selected at pack time by HIPT_MLP16=1.
+bool hipt_mlp16_supported(int dtype, int D, int hidden);
+int hipt_mlp16_launch(const MlpParams& p, hipStream_t st);
+int hipt_mlp16_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);
 
 int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, const float* b, void* out, int out_dtype,
                           int64_t out_stride, int rows, int D, float eps, hipStream_t st);

@@ -1,29 +1,19 @@
-// FUSED MLP SUB-BLOCK for D = 384 (ViT-256) on 32x32x16 MFMAs:   x <- x + y1 + fc2( GELU( fc1( LN2(x + y1) ) ) )
+// FUSED MLP SUB-BLOCK for D = 384 (ViT-256) on 16x16x32 MFMAs:   x <- x + y1 + fc2( GELU( fc1( LN2(x + y1) ) ) )
 //   (Block.forward second half, HIPT_4K/vision_transformer.py:151 with Mlp.forward :98-104.)
 //
-// One 4-wave workgroup owns 128 rows; every wave its 32 rows end to end, all in registers at one wave per SIMD: LN2(x + y1) as MFMA
-// operand fragments, fc1 half-chunk accumulators -> GELU -> re-packed in registers as the fc2 operand, the [32, 384] fc2 accumulator.
-// Only weights stream through a 3 x 48 KiB LDS-DMA ring; phases A0(c) B1(c-1) A1(c) B0(c) so that a half's GELU hides under the two
-// phases that follow its fc1.
-//   * v_mfma_f32_32x32x16_bf16.  The kernel is ISSUE-bound, not MFMA-bound: per 128 MFMA cycles a wave also has to issue ~70 cycles
-//     of GELU arithmetic, ~70 of LDS-DMA pieces and its fragment reads; a 32x32x16 MFMA holds the SIMD's vector issue for 8 of its
-//     32 cycles (96 of 128 left; a 16x16x32 for 8 of 16).
-//   * a wave's 32 rows are ONE B operand (column = row): lane l = 32 h + 16 m + li holds row (fragment m, li) and, per 16-deep
-//     k-step, 8 k values of half h.
-//   * round 4: the row phase works in the ACCUMULATOR layout.  A lane loads its row's x and y1 as the 16-byte / 8-byte pieces the
-//     fc2 accumulator tiles hold (columns 32 O + 8 q + 4 h + e), takes LayerNorm-2 there (the two h-lanes of a row hold all of it),
-//     packs the normalised values straight into the fc1 operand -- k-step 2 O + p of lane half h carries columns 32 O + 16 p +
-//     8 (j >> 2) + 4 h + (j & 3), the order the weight image is built for -- and SEEDS the fc2 accumulators with v = x + y1.  The
-//     epilogue adds b2, stores, and applies the next block's LayerNorm-1: x and y1 are read ONCE per launch (round 3 re-read them
-//     in the epilogue: 1.21 of 3.99 GB per 8-region launch; tools/experiments/mlp32_r3.hip keeps that kernel for A/B runs).
-//   * weights as A operand: one fragment = 32 output units x 16 k = 1 KiB = one ds_read_b128 per lane; the packed image stores
-//     the fragments of a ring unit in consumption order, each as 64 x 16 consecutive bytes: every LDS read is conflict-free by
-//     construction, every DMA piece is 1 KiB of consecutive bytes.
-//   * fc1 accumulator tile (32 hidden x 32 rows): lane holds its row's hidden units (reg & 3) + 8 (reg >> 2) + 4 h.  After GELU,
-//     registers 8 s .. 8 s + 7 packed to bf16 ARE the fc2 operand fragment of k-step s (accumulator-as-operand); the fc2
-//     weight image lists the hidden units in that order.
-//   * fc2 accumulator tile (32 outputs x 32 rows): lane holds 4 runs of 4 consecutive output columns 32 O + 8 q + 4 h + (0..3):
-//     16-byte pieces of the fp32 row, 8-byte pieces of the bf16 ones.
+// The same kernel as mlp32.hip -- one 4-wave workgroup owns 128 rows, every wave its 32 rows end to end in registers, weights
+// through the 3 x 48 KiB LDS-DMA ring, phases A0(c) B1(c-1) A1(c) B0(c), row phase in the accumulator layout seeding the fc2
+// accumulators, epilogue without re-reads -- on the OTHER bf16 MFMA shape.  Why (round 4, tools/mfma_shape_probe.hip, random operands,
+// steady-state clock): a bare v_mfma_f32_16x16x32_bf16 loop holds 2.35 GHz where the 32x32x16 loop is throttled to 1.9 GHz --
+// 2 220 against 1 926 TFLOP/s, 1 968 against 1 538 with one ds_read_b128 per 32 matrix-pipe cycles.  These kernels run at the
+// chip's power cap (every re-scheduling of mlp32.hip's work lands on the same time: DESIGN.md), so energy per FLOP is what counts.
+//   * a wave's 32 rows are TWO B operands (row fragments m = 0 / 1 of 16 rows); every 1 KiB weight fragment (16 units x 32 k) is
+//     read from LDS once and feeds two MFMAs of 16 cycles: the LDS bytes per FLOP of mlp32.hip.
+//   * lane (g, i) = (lane >> 4, lane & 15).  B operand: row i of the fragment, k-slot group g.  Accumulator tile (16 units x 16
+//     rows): lane holds units 4 g + (0..3) of row i -- 16-byte pieces of an fp32 row at column 16 T + 4 g.
+//   * k orders follow the accumulator's columns, so that an accumulator tile pair IS an operand: k-step s of lane group g carries
+//     columns 32 s + 16 (j >> 2) + 4 g + (j & 3), j = 0..7 -- for the fc1 operand built by the row phase from LayerNorm-2'd
+//     accumulator-layout values, and for the fc2 operand packed from GELU'd fc1 accumulator tiles 2 t', 2 t' + 1.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -34,17 +24,16 @@
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int D = 384, NKS = 24, NOT = 12, TMR = 128;   // NKS: 16-deep k-steps of fc1; NOT: 32-wide output tiles
+constexpr int D = 384, NKS = 12, NT16 = 24, TMR = 128;   // NKS: 32-deep k-steps of fc1; NT16: 16-wide output tiles
 constexpr int UNIT = 48 * 1024;                                    // ring unit = one phase = 48 fragments of 1 KiB
 
 template <int DBG = 0>
-__device__ __forceinline__ void mma32(f32x16& acc, const u32x4& a, const u32x4& b) {
+__device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b) {
     if constexpr (DBG & 4) {
         asm volatile("" : "+v"(acc) : "v"(a), "v"(b));
         return;
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
 
 #ifndef PSTAMP_SEQ
@@ -84,32 +73,30 @@ __device__ __forceinline__ void unit_of(int pos, int nchunk, bool& is_a, int& c,
     }
 }
 
-// The packed image: unit after unit in pass order, each 48 fragments x 1 KiB, lane-major (lane l = 32 h + r: 16 bytes at l * 16).
-//   fc1 unit (chunk c, half hh: hidden Hb = 128 c + 64 hh): fragment 4 gg + 2 p + U (gg 0..11, p 0/1, tile U 0/1): element j =
-//       W1[Hb + 32 U + r][32 gg + 16 p + 8 (j >> 2) + 4 h + (j & 3)]        (k-step s = 2 gg + p of the activations' k order: the
-//       column order of an ACCUMULATOR tile, so that an operand may also come straight from one -- the fc2 order, see below)
-//   fc2 unit: fragment 4 O + t (output tile O 0..11, t = 2 U + s'): element j of lane (r, h) =
-//       W2[32 O + r][Hb + 32 U + 16 s' + 8 (j >> 2) + 4 h + (j & 3)]         (the hidden order of a GELU'd fc1 accumulator tile)
-__global__ void mlp32_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2, int hidden, u32x4* __restrict__ out) {
+// The packed image: unit after unit in pass order, each 48 fragments x 1 KiB, lane-major (lane l = 16 g + i: 16 bytes at l * 16).
+//   fc1 unit (chunk c, half hh: hidden Hb = 128 c + 64 hh): fragment 4 s + U (k-step s 0..11, hidden tile U 0..3): element j =
+//       W1[Hb + 16 U + i][32 s + 16 (j >> 2) + 4 g + (j & 3)]
+//   fc2 unit: fragment 4 gg + f (group gg 0..11; f = 2 (O' & 1) + t': output tile O' = 2 gg + (f >> 1), k-step t' 0/1): element j =
+//       W2[16 O' + i][Hb + 32 t' + 16 (j >> 2) + 4 g + (j & 3)]
+__global__ void mlp16_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2, int hidden, u32x4* __restrict__ out) {
     const int nchunk = hidden / 128, upt = 4 * nchunk;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte lane chunk
     if (i >= (int64_t)upt * (UNIT / 16)) return;
-    const int pos = (int)(i / (UNIT / 16)), o = (int)(i % (UNIT / 16)), frag = o >> 6, lane = o & 63, r = lane & 31, h = lane >> 5;
+    const int pos = (int)(i / (UNIT / 16)), o = (int)(i % (UNIT / 16)), frag = o >> 6, lane = o & 63, r = lane & 15, g = lane >> 4;
     bool is_a;
     int c, hh;
     unit_of(pos, nchunk, is_a, c, hh);
     const int Hb = 128 * c + 64 * hh;
+    const bf16_t* row;
     if (is_a) {
-        const int gg = frag >> 2, pp = (frag >> 1) & 1, U = frag & 1;
-        const bf16_t* row = w1 + (int64_t)(Hb + 32 * U + r) * D + 32 * gg + 16 * pp + 4 * h;
-        const u32x2 lo = *(const u32x2*)row, hi = *(const u32x2*)(row + 8);
-        out[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        const int ks = frag >> 2, U = frag & 3;
+        row = w1 + (int64_t)(Hb + 16 * U + r) * D + 32 * ks + 4 * g;
     } else {
-        const int O = frag >> 2, t = frag & 3, U = t >> 1, s2 = t & 1;
-        const bf16_t* row = w2 + (int64_t)(32 * O + r) * hidden + Hb + 32 * U + 16 * s2 + 4 * h;
-        const u32x2 lo = *(const u32x2*)row, hi = *(const u32x2*)(row + 8);
-        out[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        const int gg = frag >> 2, f = frag & 3, O = 2 * gg + (f >> 1), t = f & 1;
+        row = w2 + (int64_t)(16 * O + r) * hidden + Hb + 32 * t + 4 * g;
     }
+    const u32x2 lo = *(const u32x2*)row, hi = *(const u32x2*)(row + 16);
+    out[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
 // IMG / XIN: fragment-blocked activation images (kernels.h, "activation images") -- IMG: y1 is read and x / xn_out are written as
@@ -117,7 +104,7 @@ __global__ void mlp32_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* _
 // DBG (tools/mlp_probe.hip only): 1 = no weight DMA / ring syncs, 2 = GELU replaced by a plain pack, 4 = no MFMAs, 8 = no LDS
 // fragment reads.
 template <bool IMG = false, bool XIN = false, int DBG = 0>
-__global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
+__global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
     // RING2 (round 4): TWO weight units in flight.  Rounds 1-3 requested unit c + 1 in groups 0..4 of phase c and waited for it at the
     // end of the same phase: the last pieces had 7 groups (~0.8 us) to come from L2 -- under the load of 256 CUs streaming the image
     // that is the L2 -> LDS latency itself, every phase ended in that wait, and whatever the waves did in between (MFMA shape, GELU
@@ -245,24 +232,20 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
 
-    f32x4 bq[2][4];  // fc1 bias an A phase starts from: tile U, quad q: b1[off + 32 U + 8 q + 4 h + e], read one phase ahead
+    f32x4 bq[4];  // fc1 bias an A phase starts from: tile U: b1[off + 16 U + 4 g + e], read one phase ahead
     // (offset = a compile-time part, which rides in the instructions' immediates, + a run-time part: hipcc keeps every distinct
     //  b1base + constant in a register of its own across the tile loop, spills it, and reloads it inside a ring phase -- where the
     //  reload's vmcnt(0) waits for the LDS-DMA in flight)
-    auto bias_rd = [&](auto OFFC_, int offd) __attribute__((always_inline)) {  // 8 reads, no wait: covered by the next counted wait
+    auto bias_rd = [&](auto OFFC_, int offd) __attribute__((always_inline)) {  // 4 reads, no wait: covered by the next counted wait
         constexpr int oc = decltype(OFFC_)::value * 4;
-        int ln;  // (b1[.. + 4 h ..]: the lane half from a fresh lane id -- two instructions -- rather than from a register kept, and spilled)
+        int ln;  // (b1[.. + 4 g ..]: the lane group from a fresh lane id -- two instructions -- rather than from a register kept, and spilled)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-        const uint32_t a = (uint32_t)(uintptr_t)(LDS_AS char*)b1s + ((ln >> 5) << 4) + offd * 4;
-        f32x4 &q0 = bq[0][0], &q1 = bq[0][1], &q2 = bq[0][2], &q3 = bq[0][3], &q4 = bq[1][0], &q5 = bq[1][1], &q6 = bq[1][2], &q7 = bq[1][3];
+        const uint32_t a = (uint32_t)(uintptr_t)(LDS_AS char*)b1s + ((ln >> 4) << 4) + offd * 4;
+        f32x4 &q0 = bq[0], &q1 = bq[1], &q2 = bq[2], &q3 = bq[3];
         DSR128(q0, a, oc + 0);
-        DSR128(q1, a, oc + 32);
-        DSR128(q2, a, oc + 64);
-        DSR128(q3, a, oc + 96);
-        DSR128(q4, a, oc + 128);
-        DSR128(q5, a, oc + 160);
-        DSR128(q6, a, oc + 192);
-        DSR128(q7, a, oc + 224);
+        DSR128(q1, a, oc + 64);
+        DSR128(q2, a, oc + 128);
+        DSR128(q3, a, oc + 192);
     };
 
     for (int seq = 0; tile < p.ntiles; ++seq) {
@@ -284,24 +267,24 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         if (tid == 0) nt_req = atomicAdd(p.counter, 1);
         int tile_next = 0, row0_next = 0, nrows_next = 0;
 
-        u32x4 X[NKS];  // the fc1 B operand: k-step s = 2 c + p, lane half h: columns 32 c + 16 p + 8 (j >> 2) + 4 h + (j & 3)
+        u32x4 X[2][NKS];  // the fc1 B operands: [row fragment m][k-step s]: lane group g: columns 32 s + 16 (j >> 2) + 4 g + (j & 3)
 
-        f32x16 acc2[NOT];    // the fc2 accumulators, seeded by the row phase with v = x + y1
-        f32x16 acc1[2][2];   // [half][tile U]: hidden (reg & 3) + 8 (reg >> 2) + 4 h of tile U for this lane's row
-        u32x4 hf[2][2][2];   // [half][tile U][k-step s']: the GELU'd, bf16-packed registers 8 s' .. 8 s' + 7 of acc1[half][U]
+        f32x4 acc2[NT16][2];   // the fc2 accumulators [output tile T][m], seeded by the row phase with v = x + y1
+        f32x4 acc1[2][4][2];   // [half][hidden tile U][m]: hidden 16 U + 4 g + (0..3) of the half for this lane's row
+        u32x4 hf[2][2][2];     // [half][k-step t'][m]: the GELU'd, bf16-packed accumulator tiles 2 t', 2 t' + 1
         // one 2-element GELU: unit u (0..15) of half GH -> one 32-bit word of the fc2 operand fragments
         auto gelu_unit = [&](auto GH_, auto U_) __attribute__((always_inline)) {
             constexpr int gh = decltype(GH_)::value, u = decltype(U_)::value;
-            constexpr int tl = u >> 3, pi = u & 7;
-            float v0 = acc1[gh][tl][2 * pi], v1 = acc1[gh][tl][2 * pi + 1];
+            constexpr int tl = u >> 2, mm = (u >> 1) & 1, pr = u & 1;
+            float v0 = acc1[gh][tl][mm][2 * pr], v1 = acc1[gh][tl][mm][2 * pr + 1];
             if constexpr ((DBG & 2) == 0) {
                 v0 = gelu1(v0);
                 v1 = gelu1(v1);
             }
-            hf[gh][tl][pi >> 2][pi & 3] = pack_bf16x2(v0, v1);
+            hf[gh][tl >> 1][mm][(tl & 1) * 2 + pr] = pack_bf16x2(v0, v1);
         };
 
-        // ---- one phase: 12 groups of 4 MFMAs on the unit in slot cons % 3 ----
+        // ---- one phase: 12 groups of 4 fragments = 8 MFMAs on the unit in slot cons % 3 ----
         // KIND/H: fc1 half H (into acc1[H][.], started from the bias in bq) or fc2 half H (operand hf[H][.][.])
         // GH/GSEC: GELU units of half GH, first (0) or second (1) eight, one per group 4..11; GH = -1: none
         // NB/nb: NB > 0: the NEXT phase is an fc1 phase and starts from the bias at b1s offset NB + nb (read with the cross-phase
@@ -340,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                         rd_frag(NS{}, I0{}, sn);
                         if constexpr (needb > 0) {
                             bias_rd(std::integral_constant<int, (needb > 0 ? needb : 0)>{}, nb);
-                            LGKM(8 + NRD);
+                            LGKM(4 + NRD);
                         } else {
                             LGKM(NRD);
                         }
@@ -349,36 +332,32 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                     rd_frag(NS{}, std::integral_constant<int, gg + 1>{}, sa);
                     LGKM(NRD);
                 }
-                // (2) 4 MFMAs, with the vector work that hides under them
-                if constexpr (kind == KA) {
+                // (2) 8 MFMAs (4 fragments x 2 row fragments), with the vector work that hides under them
+                if constexpr (kind == KA) {  // group gg = k-step gg: hidden tiles U = 0..3
                     if constexpr (gg == 0) {
                         // the bias read a phase ago has landed only NOW (the wait above): re-define it here, so that no copy of
                         // it (hipcc moves it to the accumulator file) can be placed before this point
-                        f32x4 &q0 = bq[0][0], &q1 = bq[0][1], &q2 = bq[0][2], &q3 = bq[0][3], &q4 = bq[1][0], &q5 = bq[1][1], &q6 = bq[1][2], &q7 = bq[1][3];
-                        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7));
-                        f32x16 t0, t1;  // C operand = bias: register 4 q + e of tile U is hidden 32 U + 8 q + 4 h + e
+                        f32x4 &q0 = bq[0], &q1 = bq[1], &q2 = bq[2], &q3 = bq[3];
+                        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
+                        for (int U = 0; U < 4; ++U)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                t0[4 * q + e] = bq[0][q][e];
-                                t1[4 * q + e] = bq[1][q][e];
+                            for (int mm = 0; mm < 2; ++mm) {
+                                f32x4 t = bq[U];  // C operand = bias: register e of tile U is hidden 16 U + 4 g + e
+                                mma16<DBG>(t, wA[set][U], X[mm][0]);
+                                acc1[hh][U][mm] = t;
                             }
-                        mma32<DBG>(t0, wA[set][0], X[0]);
-                        mma32<DBG>(t1, wA[set][1], X[0]);
-                        mma32<DBG>(t0, wA[set][2], X[1]);
-                        mma32<DBG>(t1, wA[set][3], X[1]);
-                        acc1[hh][0] = t0;
-                        acc1[hh][1] = t1;
                     } else {
-                        mma32<DBG>(acc1[hh][0], wA[set][0], X[2 * gg]);
-                        mma32<DBG>(acc1[hh][1], wA[set][1], X[2 * gg]);
-                        mma32<DBG>(acc1[hh][0], wA[set][2], X[2 * gg + 1]);
-                        mma32<DBG>(acc1[hh][1], wA[set][3], X[2 * gg + 1]);
-                    }
-                } else {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) mma32<DBG>(acc2[gg], wA[set][t], hf[hh][t >> 1][t & 1]);
+                        for (int U = 0; U < 4; ++U)
+#pragma unroll
+                            for (int mm = 0; mm < 2; ++mm) mma16<DBG>(acc1[hh][U][mm], wA[set][U], X[mm][gg]);
+                    }
+                } else {  // group gg = output tiles 2 gg, 2 gg + 1 x k-steps t' = 0, 1
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+#pragma unroll
+                        for (int mm = 0; mm < 2; ++mm) mma16<DBG>(acc2[2 * gg + (f >> 1)][mm], wA[set][f], hf[hh][f & 1][mm]);
                 }
                 if constexpr (RING2) {
                     if constexpr (gg <= 5) {
@@ -406,129 +385,131 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         typedef std::integral_constant<int, 64> I64;
         typedef std::integral_constant<int, 128> I128;
 
-        // Where this lane's row lives (row phase and epilogue).  Rows are reached through BUFFER resources over the tile's rows -- a
-        // uniform 64-bit base in scalar registers, one 32-bit lane offset, the piece (O, q) in the instruction's scalar offset:
-        //   * no 64-bit lane arithmetic: its zero high word is a register hipcc keeps across the whole kernel, spills, and reloads at
-        //     the head of the epilogue -- a vmcnt(0) there, behind the row touches above;
+        // Where this lane's rows live (row phase and epilogue).  Lane (g, i) holds row i of BOTH row fragments of its wave (rows
+        // 32 w + 16 m + i, m = 0 / 1) and, per output tile T, columns 16 T + 4 g + (0..3): a 16-byte piece of the fp32 row (or image),
+        // an 8-byte piece of the bf16 one.  Rows are reached through BUFFER resources over the tile's rows -- a uniform 64-bit base in
+        // scalar registers, one 32-bit lane offset per row fragment, the piece T in the instruction's scalar offset:
+        //   * no 64-bit lane arithmetic (its zero high word is a register hipcc keeps across the whole kernel, spills, and reloads at
+        //     the head of the epilogue -- a vmcnt(0) there);
         //   * a row past the tile's end gets an offset out of the resource's range: its loads return zeros without traffic and its
         //     stores are dropped -- no predication around 96 stores, no clamped re-reads;
         //   * everything lane-dependent comes from a FRESH lane id: loop-invariant addresses would be hoisted out of the tile loop,
         //     live through the chunk phases, and be spilled there.
-        // rb: element offset of the row's columns 4 h .. (row-major forms), fb: of its 16-row fragment (image forms: whole fragments
-        // only -- the launcher guarantees M % 16 == 0).
+        // Piece T of a lane: row-major forms: element (row) * D + 16 T + 4 g.  Images (kernels.h; whole fragments only -- the launcher
+        // guarantees M % 16 == 0): fp32: fragment * 6144 + [(T >> 1) * 512 + (T & 1) * 128] + (g & 1) * 256 + (g >> 1) * 64 + 4 i;
+        // bf16: fragment * 6144 + [(T >> 1) * 512 + (T & 1) * 256] + (g >> 1) * 128 + 8 i + 4 (g & 1)   ([..] = the scalar part).
         constexpr uint32_t OOB = 0x80000000u;
-        auto row_base = [&](int t_nrows, int& li_, int& h_, uint32_t& rb, uint32_t& fb, bool& live) __attribute__((always_inline)) {
+        // byte offsets of this lane's pieces: f32 selects the fp32 (x) or the bf16 (y1, xn) form, img the image or the row-major one
+        auto lane_off = [&](int t_nrows, bool f32, bool img, uint32_t (&off)[2], int& g_) __attribute__((always_inline)) {
             int ln;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-            li_ = ln & 15;
-            h_ = ln >> 5;
-            const int m_ = (ln >> 4) & 1;
-            const int r = wave * 32 + m_ * 16 + li_;
-            live = r < t_nrows;  // (the BYTE offset of a row that is not live becomes OOB: scaled first, or it would wrap back into range)
-            rb = (uint32_t)(r * D + 4 * h_);
-            fb = (uint32_t)((wave * 32 + m_ * 16) * D);
+            const int i_ = ln & 15;
+            g_ = ln >> 4;
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const int r = wave * 32 + mm * 16 + i_;
+                const uint32_t e = img ? (uint32_t)((wave * 32 + mm * 16) * D) + (f32 ? (uint32_t)((g_ & 1) * 256 + (g_ >> 1) * 64 + 4 * i_)
+                                                                                     : (uint32_t)((g_ >> 1) * 128 + 8 * i_ + 4 * (g_ & 1)))
+                                       : (uint32_t)(r * D + 4 * g_);
+                off[mm] = r < t_nrows ? e * (f32 ? 4u : 2u) : OOB;  // (scaled first: OOB times 4 would wrap back into range)
+            }
         };
-        // both lanes of a row (l, l ^ 32) get lo + hi, summed in that order (no LDS crossbar, no lane-id register)
+        // all four lanes of a row (l ^ 16, l ^ 32) get the same sum, added in the same order (no LDS crossbar, no lane-id register)
         auto row_sum = [&](float v) __attribute__((always_inline)) -> float {
 #pragma clang fp contract(off)
             const uint32_t u = __builtin_bit_cast(uint32_t, v);
-            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-            return __builtin_bit_cast(float, (uint32_t)sw[0]) + __builtin_bit_cast(float, (uint32_t)sw[1]);
+            const auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+            const float a = __builtin_bit_cast(float, (uint32_t)s16[0]) + __builtin_bit_cast(float, (uint32_t)s16[1]);
+            const uint32_t ua = __builtin_bit_cast(uint32_t, a);
+            const auto s32 = __builtin_amdgcn_permlane32_swap(ua, ua, false, false);
+            return __builtin_bit_cast(float, (uint32_t)s32[0]) + __builtin_bit_cast(float, (uint32_t)s32[1]);
         };
+        constexpr int XI_T1 = 512, XI_T0 = 128, YI_T1 = 512, YI_T0 = 256;  // image pieces: (T >> 1) * _T1 + (T & 1) * _T0 elements
+#define PIECE_X(img, T) ((img) ? ((T) >> 1) * XI_T1 + ((T) & 1) * XI_T0 : 16 * (T))
+#define PIECE_Y(img, T) ((img) ? ((T) >> 1) * YI_T1 + ((T) & 1) * YI_T0 : 16 * (T))
 
-        // ---- row phase: v = x + y1 in the ACCUMULATOR layout.  Lane (h, m, li) holds row 32 w + 16 m + li and, per output tile O and
-        // quad q, columns 32 O + 8 q + 4 h + (0..3): the 16-byte pieces of the fp32 row (or image), the 8-byte pieces of the bf16
-        // one.  The two h-lanes of a row hold all of it, so LayerNorm-2 takes ONE cross-lane step; the normalised values packed to
-        // bf16 ARE the fc1 operand (the fc1 weight image lists k in the accumulator's column order: mlp32_pack_kernel); and v seeds
-        // the fc2 accumulators, so the epilogue never re-reads x and y1 (round 3 did: 1.21 of the 3.99 GB per 8-region launch).
-        // All 96 loads of a lane (36 KiB per wave) are in flight together: one memory latency per tile instead of two.
+        // ---- row phase: v = x + y1 in the ACCUMULATOR layout; LayerNorm-2 there (a row's four g-lanes hold all of it: two cross-lane
+        // steps); the normalised values packed to bf16 ARE the fc1 operand (the fc1 weight image lists k in the accumulator's column
+        // order: mlp16_pack_kernel); and v seeds the fc2 accumulators, so the epilogue never re-reads x and y1.
+        // All 96 loads of a lane (36 KiB per wave) are in flight together: one memory latency per tile.
         {
 #pragma clang fp contract(off)
-            uint32_t xo, yo;  // byte offsets of this lane's pieces inside the tile's x / y1 rows
-            uint32_t g2base;  // LN-2 gamma in accumulator column order: gam[32 O + 8 q + 4 h ..] at + (32 O + 8 q) * 4 (beta: + D * 4)
+            uint32_t xo[2], yo[2];
+            uint32_t g2base;  // LN-2 gamma in accumulator column order: gam[16 T + 4 g ..] at + 64 T bytes (beta: + D * 4)
             {
-                uint32_t rb, fb;
-                int li_, h_;
-                bool live;
-                row_base(nrows, li_, h_, rb, fb, live);
-                xo = live ? (XIN ? fb + (uint32_t)(256 * h_ + 4 * li_) : rb) * 4 : OOB;
-                yo = live ? (IMG ? fb + (uint32_t)(8 * li_ + 4 * h_) : rb) * 2 : OOB;
-                g2base = (uint32_t)(uintptr_t)(LDS_AS char*)gam + 16 * h_;
+                int g_;
+                lane_off(nrows, true, XIN, xo, g_);
+                lane_off(nrows, false, IMG, yo, g_);
+                g2base = (uint32_t)(uintptr_t)(LDS_AS char*)gam + 16 * g_;
             }
-            constexpr int xlo_ = XIN ? 512 : 32, xlq_ = XIN ? 64 : 8, yo_ = IMG ? 512 : 32, yq_ = IMG ? 128 : 8;
             const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)row0 * D), 0, nrows * D * 4, 0x00020000);
             // (no y1: an empty range -- every piece reads as zero)
             const __amdgpu_buffer_rsrc_t ry =
                 __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.y1 + (int64_t)row0 * D), 0, p.y1 ? nrows * D * 2 : 0, 0x00020000);
-            f32x4 xv[NOT][4];
-            u32x2 yv[NOT][4];
+            f32x4 xv[2][NT16];
+            u32x2 yv[2][NT16];
 #pragma unroll
-            for (int O = 0; O < NOT; ++O)
+            for (int T = 0; T < NT16; ++T)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xv[O][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo, (xlo_ * O + xlq_ * q) * 4, 0));
+                for (int mm = 0; mm < 2; ++mm) xv[mm][T] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo[mm], PIECE_X(XIN, T) * 4, 0));
 #pragma unroll
-            for (int O = 0; O < NOT; ++O)
+            for (int T = 0; T < NT16; ++T)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) yv[O][q] = __builtin_amdgcn_raw_buffer_load_b64(ry, yo, (yo_ * O + yq_ * q) * 2, 0);
+                for (int mm = 0; mm < 2; ++mm) yv[mm][T] = __builtin_amdgcn_raw_buffer_load_b64(ry, yo[mm], PIECE_Y(IMG, T) * 2, 0);
             if (tid == 0) {
                 asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
                 if (nt_req == last_fetch) *p.counter = 0;
             }
             // (packed fp32 arithmetic: no MFMA runs beside the row phases, and it halves their vector instructions)
-            f32x2 rs2 = {0.f, 0.f};
-            sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
+            float mean[2], rstd[2];
+            sfor<0, 2>([&](auto M_) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
-                constexpr int O = decltype(O_)::value;
+                constexpr int mm = decltype(M_)::value;
+                f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bf16x4 y = __builtin_bit_cast(bf16x4, yv[O][q]);
-                    f32x2 a = {xv[O][q][0], xv[O][q][1]}, b = {xv[O][q][2], xv[O][q][3]};
+                for (int T = 0; T < NT16; ++T) {
+                    const bf16x4 y = __builtin_bit_cast(bf16x4, yv[mm][T]);
+                    f32x2 a = {xv[mm][T][0], xv[mm][T][1]}, b = {xv[mm][T][2], xv[mm][T][3]};
                     a = a + f32x2{(float)y[0], (float)y[1]};
                     b = b + f32x2{(float)y[2], (float)y[3]};
                     rs2 = rs2 + a;
                     rs2 = rs2 + b;
-                    xv[O][q] = f32x4{a[0], a[1], b[0], b[1]};
+                    xv[mm][T] = f32x4{a[0], a[1], b[0], b[1]};
                 }
-            });
-            const float rs = row_sum(rs2[0] + rs2[1]);
-            const float mean = rs * (1.0f / D);
-            const f32x2 mean2 = {mean, mean};
-            f32x2 qs2 = {0.f, 0.f};
+                mean[mm] = row_sum(rs2[0] + rs2[1]) * (1.0f / D);
+                const f32x2 mean2 = {mean[mm], mean[mm]};
+                f32x2 qs2 = {0.f, 0.f};
 #pragma unroll
-            for (int O = 0; O < NOT; ++O)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x2 a = f32x2{xv[O][q][0], xv[O][q][1]} - mean2, b = f32x2{xv[O][q][2], xv[O][q][3]} - mean2;
+                for (int T = 0; T < NT16; ++T) {
+                    const f32x2 a = f32x2{xv[mm][T][0], xv[mm][T][1]} - mean2, b = f32x2{xv[mm][T][2], xv[mm][T][3]} - mean2;
                     qs2 = __builtin_elementwise_fma(a, a, qs2);
                     qs2 = __builtin_elementwise_fma(b, b, qs2);
                 }
-            const float qs = row_sum(qs2[0] + qs2[1]);
-            const float rstd = 1.0f / sqrtf(qs * (1.0f / D) + p.ln_eps);
-            const f32x2 rstd2 = {rstd, rstd};
-            sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
+                rstd[mm] = 1.0f / sqrtf(row_sum(qs2[0] + qs2[1]) * (1.0f / D) + p.ln_eps);
+            });
+            sfor<0, NKS>([&](auto S_) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
-                constexpr int O = decltype(O_)::value;
-                f32x4 gq[4], bqv[4];
+                constexpr int ks = decltype(S_)::value;
+                f32x4 g0, g1, b0, b1_;  // gamma / beta of tiles 2 s, 2 s + 1 at this lane's columns
                 const uint32_t ga = g2base;
-                f32x4 &g0 = gq[0], &g1 = gq[1], &g2 = gq[2], &g3 = gq[3], &b0 = bqv[0], &b1_ = bqv[1], &b2_ = bqv[2], &b3 = bqv[3];
-                DSR128X4_WAIT(g0, g1, g2, g3, ga, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
-                DSR128X4_WAIT(b0, b1_, b2_, b3, ga, D * 4 + O * 128, D * 4 + O * 128 + 32, D * 4 + O * 128 + 64, D * 4 + O * 128 + 96);
-                uint32_t w[8];
-                f32x16 t;
+                DSR128X4_WAIT(g0, g1, b0, b1_, ga, ks * 128, ks * 128 + 64, D * 4 + ks * 128, D * 4 + ks * 128 + 64);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x2 va = {xv[O][q][0], xv[O][q][1]}, vb = {xv[O][q][2], xv[O][q][3]};
-                    const f32x2 ya = __builtin_elementwise_fma((va - mean2) * rstd2, f32x2{gq[q][0], gq[q][1]}, f32x2{bqv[q][0], bqv[q][1]});
-                    const f32x2 yb = __builtin_elementwise_fma((vb - mean2) * rstd2, f32x2{gq[q][2], gq[q][3]}, f32x2{bqv[q][2], bqv[q][3]});
-                    w[2 * q] = pack_bf16x2(ya[0], ya[1]);
-                    w[2 * q + 1] = pack_bf16x2(yb[0], yb[1]);
+                for (int mm = 0; mm < 2; ++mm) {
+                    const f32x2 mean2 = {mean[mm], mean[mm]}, rstd2 = {rstd[mm], rstd[mm]};
+                    uint32_t w[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) t[4 * q + e] = xv[O][q][e];
+                    for (int t = 0; t < 2; ++t) {
+                        const f32x4 v = xv[mm][2 * ks + t], gq = t ? g1 : g0, bq_ = t ? b1_ : b0;
+                        const f32x2 ya = __builtin_elementwise_fma((f32x2{v[0], v[1]} - mean2) * rstd2, f32x2{gq[0], gq[1]}, f32x2{bq_[0], bq_[1]});
+                        const f32x2 yb = __builtin_elementwise_fma((f32x2{v[2], v[3]} - mean2) * rstd2, f32x2{gq[2], gq[3]}, f32x2{bq_[2], bq_[3]});
+                        w[2 * t] = pack_bf16x2(ya[0], ya[1]);
+                        w[2 * t + 1] = pack_bf16x2(yb[0], yb[1]);
+                        f32x4 sd = v;
+                        asm volatile("" : "+a"(sd));  // the seed goes to the accumulator file at once
+                        acc2[2 * ks + t][mm] = sd;
+                    }
+                    X[mm][ks] = u32x4{w[0], w[1], w[2], w[3]};  // k-slots j < 4: tile 2 s, j >= 4: tile 2 s + 1
                 }
-                X[2 * O] = u32x4{w[0], w[1], w[2], w[3]};      // k-step 2 O: columns 8 q + 4 h + e of the 32, q = 0, 1
-                X[2 * O + 1] = u32x4{w[4], w[5], w[6], w[7]};  // k-step 2 O + 1: q = 2, 3
-                asm volatile("" : "+a"(t));  // the seed goes to the accumulator file at once
-                acc2[O] = t;
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -584,8 +565,8 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         }
         LGKM(0);  // (the last B0 read a bias nobody uses: let it land before its registers are re-used ...
         {         //  ... and keep those registers allocated up to here: a fake use AFTER the wait)
-            f32x4 &q0 = bq[0][0], &q1 = bq[0][1], &q2 = bq[0][2], &q3 = bq[0][3], &q4 = bq[1][0], &q5 = bq[1][1], &q6 = bq[1][2], &q7 = bq[1][3];
-            asm volatile("" ::"v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(q4), "v"(q5), "v"(q6), "v"(q7));
+            f32x4 &q0 = bq[0], &q1 = bq[1], &q2 = bq[2], &q3 = bq[3];
+            asm volatile("" ::"v"(q0), "v"(q1), "v"(q2), "v"(q3));
         }
         // tail: second eight of the last half 1, then B1(last); its prefetch is the next tile's A0(0)
         sfor<8, 16>([&](auto U_) __attribute__((always_inline)) { gelu_unit(I1{}, U_); });
@@ -595,86 +576,85 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
         PSTAMP_CLK(1);
 
         // ---- epilogue: x <- acc2 + b2 (acc2 started from v = x + y1: nothing is re-read).  This workgroup owns its rows: in place.
-        //      Lane (h, m, li) holds row 32 w + 16 m + li; acc2[O][4 q + e] is output column 32 O + 8 q + 4 h + e.
-        //      Images: chunk-of-8 index 4 O + q = g' + 4 c' with g' = q, c' = O, half h, image lane 16 q + li.
         //      (row-major in, image out -- the first block of a forward -- converts in place: a wave's 32 rows are the bytes of its two
         //       fragments, and every old value was loaded in the row phase)
         {
 #pragma clang fp contract(off)
-            uint32_t rb, fb;
-            int li_, h_;
-            bool live;
-            row_base(nrows, li_, h_, rb, fb, live);
+            uint32_t xso[2], nso[2];
+            uint32_t b2base, g1base;
+            {
+                int g_;
+                lane_off(nrows, true, IMG, xso, g_);
+                lane_off(nrows, false, IMG, nso, g_);
+                b2base = (uint32_t)(uintptr_t)(LDS_AS char*)b2s + 16 * g_;   // b2[16 T + 4 g ..]: + 64 T bytes
+                g1base = (uint32_t)(uintptr_t)(LDS_AS char*)gam1 + 16 * g_;  // next LN-1 gamma (beta: + D * 4)
+            }
             const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)row0 * D), 0, nrows * D * 4, 0x00020000);
-            const uint32_t b2base = (uint32_t)(uintptr_t)(LDS_AS char*)b2s + 16 * h_;   // b2[32 O + 8 q + 4 h ..]: + (32 O + 8 q) * 4
-            const uint32_t g1base = (uint32_t)(uintptr_t)(LDS_AS char*)gam1 + 16 * h_;  // next LN-1 gamma (beta: + D * 4)
-            // float / element offsets of piece (O, q): row-major rb + 32 O + 8 q; fp32 image fb + 512 O + 256 h + 64 q + 4 li;
-            // bf16 image fb + 512 O + 128 q + 8 li + 4 h
-            const uint32_t xso = live ? (IMG ? fb + (uint32_t)(256 * h_ + 4 * li_) : rb) * 4 : OOB;
-            constexpr int xso_ = IMG ? 512 : 32, xsq_ = IMG ? 64 : 8, yo_ = IMG ? 512 : 32, yq_ = IMG ? 128 : 8;
-            f32x2 rs2 = {0.f, 0.f};
-            sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
+            f32x2 rs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+            sfor<0, NT16 / 4>([&](auto Q_) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
-                constexpr int O = decltype(O_)::value;
+                constexpr int T0 = 4 * decltype(Q_)::value;
                 f32x4 bb[4];
                 const uint32_t ba = b2base;
                 f32x4 &r0_ = bb[0], &r1_ = bb[1], &r2_ = bb[2], &r3_ = bb[3];
-                DSR128X4_WAIT(r0_, r1_, r2_, r3_, ba, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
-                f32x16 t = acc2[O];
+                DSR128X4_WAIT(r0_, r1_, r2_, r3_, ba, T0 * 64, T0 * 64 + 64, T0 * 64 + 128, T0 * 64 + 192);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x2 a = f32x2{t[4 * q], t[4 * q + 1]} + f32x2{bb[q][0], bb[q][1]};
-                    const f32x2 b = f32x2{t[4 * q + 2], t[4 * q + 3]} + f32x2{bb[q][2], bb[q][3]};
-                    rs2 = rs2 + a;
-                    rs2 = rs2 + b;
-                    const f32x4 v = {a[0], a[1], b[0], b[1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rx, xso, (xso_ * O + xsq_ * q) * 4, 0);
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) t[4 * q + e] = v[e];
-                }
-                acc2[O] = t;
+                    for (int mm = 0; mm < 2; ++mm) {
+                        const f32x4 c = acc2[T0 + t][mm];
+                        const f32x2 a = f32x2{c[0], c[1]} + f32x2{bb[t][0], bb[t][1]};
+                        const f32x2 b = f32x2{c[2], c[3]} + f32x2{bb[t][2], bb[t][3]};
+                        rs2[mm] = rs2[mm] + a;
+                        rs2[mm] = rs2[mm] + b;
+                        const f32x4 v = {a[0], a[1], b[0], b[1]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rx, xso[mm], PIECE_X(IMG, T0 + t) * 4, 0);
+                        acc2[T0 + t][mm] = v;
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             });
             if (p.xn_out) {
-                // LayerNorm-1 of the next block on the finished row (the two h-lanes of a row hold all of it), as bf16
-                const float rs = row_sum(rs2[0] + rs2[1]);
-                const float mean = rs * (1.0f / D);
-                const f32x2 mean2 = {mean, mean};
-                f32x2 qs2 = {0.f, 0.f};
+                // LayerNorm-1 of the next block on the finished rows (the four g-lanes of a row hold all of it), as bf16
+                float mean[2], rstd[2];
 #pragma unroll
-                for (int O = 0; O < NOT; ++O)
+                for (int mm = 0; mm < 2; ++mm) {
+                    mean[mm] = row_sum(rs2[mm][0] + rs2[mm][1]) * (1.0f / D);
+                    const f32x2 mean2 = {mean[mm], mean[mm]};
+                    f32x2 qs2 = {0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 16; e += 2) {
-                        const f32x2 a = f32x2{acc2[O][e], acc2[O][e + 1]} - mean2;
+                    for (int T = 0; T < NT16; ++T) {
+                        const f32x2 a = f32x2{acc2[T][mm][0], acc2[T][mm][1]} - mean2, b = f32x2{acc2[T][mm][2], acc2[T][mm][3]} - mean2;
                         qs2 = __builtin_elementwise_fma(a, a, qs2);
+                        qs2 = __builtin_elementwise_fma(b, b, qs2);
                     }
-                const float qs = row_sum(qs2[0] + qs2[1]);
-                const float rstd = 1.0f / sqrtf(qs * (1.0f / D) + p.ln_eps);
-                const f32x2 rstd2 = {rstd, rstd};
+                    rstd[mm] = 1.0f / sqrtf(row_sum(qs2[0] + qs2[1]) * (1.0f / D) + p.ln_eps);
+                }
                 const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc((void*)((bf16_t*)p.xn_out + (int64_t)row0 * D), 0, nrows * D * 2, 0x00020000);
-                const uint32_t nso = live ? (IMG ? fb + (uint32_t)(8 * li_ + 4 * h_) : rb) * 2 : OOB;
-                sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
+                sfor<0, NT16 / 2>([&](auto S_) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
-                    constexpr int O = decltype(O_)::value;
-                    f32x4 gq[4], bqv[4];
+                    constexpr int T0 = 2 * decltype(S_)::value;
+                    f32x4 g0, g1, b0, b1_;
                     const uint32_t ga = g1base;
-                    f32x4 &g0 = gq[0], &g1 = gq[1], &g2 = gq[2], &g3 = gq[3], &b0 = bqv[0], &b1_ = bqv[1], &b2_ = bqv[2], &b3 = bqv[3];
-                    DSR128X4_WAIT(g0, g1, g2, g3, ga, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
-                    DSR128X4_WAIT(b0, b1_, b2_, b3, ga, D * 4 + O * 128, D * 4 + O * 128 + 32, D * 4 + O * 128 + 64, D * 4 + O * 128 + 96);
+                    DSR128X4_WAIT(g0, g1, b0, b1_, ga, T0 * 64, T0 * 64 + 64, D * 4 + T0 * 64, D * 4 + T0 * 64 + 64);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x2 va = {acc2[O][4 * q], acc2[O][4 * q + 1]}, vb = {acc2[O][4 * q + 2], acc2[O][4 * q + 3]};
-                        const f32x2 ya = __builtin_elementwise_fma((va - mean2) * rstd2, f32x2{gq[q][0], gq[q][1]}, f32x2{bqv[q][0], bqv[q][1]});
-                        const f32x2 yb = __builtin_elementwise_fma((vb - mean2) * rstd2, f32x2{gq[q][2], gq[q][3]}, f32x2{bqv[q][2], bqv[q][3]});
-                        u32x2 o2;
-                        o2[0] = pack_bf16x2(ya[0], ya[1]);
-                        o2[1] = pack_bf16x2(yb[0], yb[1]);
-                        __builtin_amdgcn_raw_buffer_store_b64(o2, rn, nso, (yo_ * O + yq_ * q) * 2, 0);
-                    }
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int mm = 0; mm < 2; ++mm) {
+                            const f32x2 mean2 = {mean[mm], mean[mm]}, rstd2 = {rstd[mm], rstd[mm]};
+                            const f32x4 v = acc2[T0 + t][mm], gq = t ? g1 : g0, bq_ = t ? b1_ : b0;
+                            const f32x2 ya = __builtin_elementwise_fma((f32x2{v[0], v[1]} - mean2) * rstd2, f32x2{gq[0], gq[1]}, f32x2{bq_[0], bq_[1]});
+                            const f32x2 yb = __builtin_elementwise_fma((f32x2{v[2], v[3]} - mean2) * rstd2, f32x2{gq[2], gq[3]}, f32x2{bq_[2], bq_[3]});
+                            u32x2 o2;
+                            o2[0] = pack_bf16x2(ya[0], ya[1]);
+                            o2[1] = pack_bf16x2(yb[0], yb[1]);
+                            __builtin_amdgcn_raw_buffer_store_b64(o2, rn, nso[mm], PIECE_Y(IMG, T0 + t) * 2, 0);
+                        }
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
         }
+#undef PIECE_X
+#undef PIECE_Y
         PSTAMP(4);
         if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0 && seq == PSTAMP_SEQ) {
             unsigned long long* o = p.stamps + (size_t)blockIdx.x * 16;
@@ -693,43 +673,43 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
 
 }  // namespace
 
-bool hipt_mlp32_supported(int dtype, int D_, int hidden) {
+bool hipt_mlp16_supported(int dtype, int D_, int hidden) {
     return dtype == HIPT_BF16 && D_ == 384 && hidden % 128 == 0 && hidden >= 256 && hidden <= 1536;
 }
 
-int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D_, int hidden, void* packed, hipStream_t st) {
+int hipt_mlp16_pack_launch(const void* w1, const void* w2, int D_, int hidden, void* packed, hipStream_t st) {
     if (!(D_ == 384 && hidden % 128 == 0 && hidden >= 256 && hidden <= 1536)) {
-        hipt_set_error("mlp32 pack: unsupported D=%d hidden=%d", D_, hidden);
+        hipt_set_error("mlp16 pack: unsupported D=%d hidden=%d", D_, hidden);
         return HIPT_E_UNSUPPORTED;
     }
     const int64_t chunks = (int64_t)(hidden / 128) * 4 * (UNIT / 16);
-    hipLaunchKernelGGL(mlp32_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const bf16_t*)w1, (const bf16_t*)w2, hidden, (u32x4*)packed);
+    hipLaunchKernelGGL(mlp16_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const bf16_t*)w1, (const bf16_t*)w2, hidden, (u32x4*)packed);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }
 
 template <int DBG>
-int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
+int hipt_mlp16_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     MlpParams p = p_in;
     const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4 + 256;
     if (!p.wpk || p.wpk_fmt != 1 || (p.img & 2 && !(p.img & 1)) || (p.img && p.M % 16 != 0) || p.fold) {
-        hipt_set_error("mlp32: needs its packed weights; activation images need M %% 16 == 0 and img in {0, 1, 3}; no proj folding (img=%d, M=%d, fold=%d)", p.img,
+        hipt_set_error("mlp16: needs its packed weights; activation images need M %% 16 == 0 and img in {0, 1, 3}; no proj folding (img=%d, M=%d, fold=%d)", p.img,
                        p.M, p.fold);
         return HIPT_E_BADARG;
     }
-    auto k = p.img == 3 ? mlp32_kernel<true, true, DBG> : p.img == 1 ? mlp32_kernel<true, false, DBG> : mlp32_kernel<false, false, DBG>;
+    auto k = p.img == 3 ? mlp16_kernel<true, true, DBG> : p.img == 1 ? mlp16_kernel<true, false, DBG> : mlp16_kernel<false, false, DBG>;
     static DevOnce once;
     HIPT_CUR_DEVICE(dev);
     if (!once.done[dev]) {
-        if (hipFuncSetAttribute((const void*)mlp32_kernel<true, true, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)mlp32_kernel<true, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)mlp32_kernel<false, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            hipt_set_error("hipFuncSetAttribute(mlp32) failed");
+        if (hipFuncSetAttribute((const void*)mlp16_kernel<true, true, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mlp16_kernel<true, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mlp16_kernel<false, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            hipt_set_error("hipFuncSetAttribute(mlp16) failed");
             return HIPT_E_LAUNCH;
         }
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-            hipt_set_error("mlp32: cannot query the device");
+            hipt_set_error("mlp16: cannot query the device");
             return HIPT_E_LAUNCH;
         }
         once.ncu[dev] = prop.multiProcessorCount;
@@ -751,7 +731,7 @@ int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     const int grid = p.ntiles < ncu ? p.ntiles : ncu;
     p.stagger = 0;
     if (!p.counter_zeroed && hipMemsetAsync(p.counter, 0, sizeof(int), st) != hipSuccess) {
-        hipt_set_error("mlp32: hipMemsetAsync(counter) failed");
+        hipt_set_error("mlp16: hipMemsetAsync(counter) failed");
         return HIPT_E_LAUNCH;
     }
 #ifdef HIPT_DEBUG_STAMPS  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
@@ -782,11 +762,17 @@ int hipt_mlp32_launch_dbg(const MlpParams& p_in, hipStream_t st) {
             epi += (double)(h[b * 16 + 4] - h[b * 16 + 3]) * 0.01 / grid;
             ghz += (double)(h[b * 16 + 9] - h[b * 16 + 8]) / (double)(h[b * 16 + 3] - h[b * 16 + 2]) * 0.1 / grid;
         }
-        fprintf(stderr, "[mlp32 dbg=%d hidden=%d grid=%d tiles=%d(+%d)] total %.1f us | tile %d of each workgroup: rows+LN %.1f, chunks %.1f (%.2f GHz), epilogue %.1f\n",
+        fprintf(stderr, "[mlp16 dbg=%d hidden=%d grid=%d tiles=%d(+%d)] total %.1f us | tile %d of each workgroup: rows+LN %.1f, chunks %.1f (%.2f GHz), epilogue %.1f\n",
                 DBG, p.hidden, grid, p.full_tiles, p.ntiles - p.full_tiles, (double)(t4 - t0) * 0.01, PSTAMP_SEQ, pro, chunks, ghz, epi);
     }
 #endif
     return HIPT_OK;
 }
 
-int hipt_mlp32_launch(const MlpParams& p, hipStream_t st) { return hipt_mlp32_launch_dbg<0>(p, st); }
+int hipt_mlp16_launch(const MlpParams& p, hipStream_t st) { return hipt_mlp16_launch_dbg<0>(p, st); }
+
+#ifdef MLP16_AS_MLP32  // (A/B builds: this object stands in for mlp32.o -- tools/bench_ab.sh)
+bool hipt_mlp32_supported(int dtype, int D_, int hidden) { return hipt_mlp16_supported(dtype, D_, hidden); }
+int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D_, int hidden, void* packed, hipStream_t st) { return hipt_mlp16_pack_launch(w1, w2, D_, hidden, packed, st); }
+int hipt_mlp32_launch(const MlpParams& p, hipStream_t st) { return hipt_mlp16_launch(p, st); }
+#endif

@@ -359,6 +359,33 @@ def test_vit256_streaming_kernels_vs_generic_kernels(vit256, monkeypatch):
         N.call("hipt_vit_pack_weights", pk32.ref, 0, N.PACK_MLP, N.ptr(x), N.stream_ptr(x.device))
 
 
+def test_vit256_fused_mlp_on_16x16x32_mfmas(vit256, monkeypatch):
+    """csrc/mlp16.hip: the fused MLP on the other bf16 MFMA shape (HIPT_MLP16=1 when the weight images are packed: image format 2).
+    Another fragment / accumulator layout and another summation order over the same bf16 products: held to the bf16 bar against
+    the default kernel, bit-identical between batchings, and the format travels with the image (no environment at launch)."""
+    x = synth.hash_uniform_torch((16, 3, 256, 256), 23, device=DEV)
+    vit256.set_compute_dtype("bf16")
+    try:
+        default = vit256(x)
+        assert all(vit256._tokens(x)[0].blocks[i].mlp_pk_fmt == 1 for i in range(12))
+        vit256._packed.clear()
+        monkeypatch.setenv("HIPT_MLP16", "1")
+        pk = vit256._tokens(x)[0]
+        monkeypatch.delenv("HIPT_MLP16")
+        assert all(pk.blocks[i].mlp_pk_fmt == 2 and pk.blocks[i].mlp_pk for i in range(12))
+        m16 = vit256(x)
+        assert all(vit256._tokens(x)[0].blocks[i].mlp_pk_fmt == 2 for i in range(12))  # (the same images: still format 2)
+        sub = vit256(x[3:8])
+    finally:
+        monkeypatch.delenv("HIPT_MLP16", raising=False)
+        vit256._packed.clear()
+        vit256.set_compute_dtype("fp32")
+    rel = float((m16 - default).norm() / default.norm())
+    print(f"fused MLP 16x16x32 vs 32x32x16: [CLS] features rel-L2 {rel:.2e}")
+    assert 0 < rel < 1.3e-2
+    assert torch.equal(sub, m16[3:8])
+
+
 def test_vit256_patch_embedding_from_fp32_pixels(vit256, monkeypatch):
     """csrc/embed32.hip reads the fp32 image itself (pixels rounded to bf16 in registers, weights through the LDS-DMA ring); the
     generic path (HIPT_GENERIC=1) makes a bf16 copy of the image and runs the generic GEMM over an im2col view.  Same bf16

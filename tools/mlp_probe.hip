@@ -24,6 +24,11 @@ int hipt_mlp_pipe_launch(const MlpParams&, hipStream_t) { return -1; }
 #include "../hipt_abmil_atec23_amd/csrc/mlp32.hip"
 #define LAUNCH(DBG, p) hipt_mlp32_launch_dbg<DBG>(p, 0)
 #define hipt_mlp_pack_launch hipt_mlp32_pack_launch
+#elif defined(PROBE_16)  // the 16x16x32 form of mlp32.hip (csrc/mlp16.hip); -DPROBE_16
+#include "../hipt_abmil_atec23_amd/csrc/mlp16.hip"
+#define PROBE_32
+#define LAUNCH(DBG, p) hipt_mlp16_launch_dbg<DBG>(p, 0)
+#define hipt_mlp_pack_launch hipt_mlp16_pack_launch
 #elif defined(PROBE_32R3)  // round 3's mlp32 (row phases in the 16-row fragment layout, epilogue re-reads x and y1; proj folding); -DPROBE_32R3
 #define HIPT_EXPERIMENTS
 #include "experiments/mlp32_r3.hip"
