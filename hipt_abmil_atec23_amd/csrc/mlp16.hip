@@ -688,11 +688,16 @@ int hipt_mlp16_pack_launch(const void* w1, const void* w2, int D_, int hidden, v
     return HIPT_OK;
 }
 
+#ifdef MLP16_AS_MLP32  // (A/B builds, tools/bench_ab.sh: this object stands in for mlp32.o and takes its format number)
+constexpr int MLP16_FMT = 1;
+#else
+constexpr int MLP16_FMT = 2;
+#endif
 template <int DBG>
 int hipt_mlp16_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     MlpParams p = p_in;
     const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4 + 256;
-    if (!p.wpk || p.wpk_fmt != 1 || (p.img & 2 && !(p.img & 1)) || (p.img && p.M % 16 != 0) || p.fold) {
+    if (!p.wpk || p.wpk_fmt != MLP16_FMT || (p.img & 2 && !(p.img & 1)) || (p.img && p.M % 16 != 0) || p.fold) {
         hipt_set_error("mlp16: needs its packed weights; activation images need M %% 16 == 0 and img in {0, 1, 3}; no proj folding (img=%d, M=%d, fold=%d)", p.img,
                        p.M, p.fold);
         return HIPT_E_BADARG;

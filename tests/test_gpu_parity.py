@@ -375,7 +375,8 @@ def test_vit256_fused_mlp_on_16x16x32_mfmas(vit256, monkeypatch):
         assert all(pk.blocks[i].mlp_pk_fmt == 2 and pk.blocks[i].mlp_pk for i in range(12))
         m16 = vit256(x)
         assert all(vit256._tokens(x)[0].blocks[i].mlp_pk_fmt == 2 for i in range(12))  # (the same images: still format 2)
-        sub = vit256(x[3:8])
+        sub = vit256(torch.cat([x[5:], x]))  # (27 patches: other tiles, other positions inside them, still whole fragments? no: 27 * 257 rows)
+        two = vit256(torch.cat([x, x]))      # 32 patches = whole 16-row fragments, like the 16: the same kernels, other tile positions
     finally:
         monkeypatch.delenv("HIPT_MLP16", raising=False)
         vit256._packed.clear()
@@ -383,7 +384,8 @@ def test_vit256_fused_mlp_on_16x16x32_mfmas(vit256, monkeypatch):
     rel = float((m16 - default).norm() / default.norm())
     print(f"fused MLP 16x16x32 vs 32x32x16: [CLS] features rel-L2 {rel:.2e}")
     assert 0 < rel < 1.3e-2
-    assert torch.equal(sub, m16[3:8])
+    assert torch.equal(two[:16], m16) and torch.equal(two[16:], m16)
+    assert float((sub[11:] - m16).norm() / m16.norm()) < 1.3e-2  # (27 patches run row-major: another path, the bf16 bar)
 
 
 def test_vit256_patch_embedding_from_fp32_pixels(vit256, monkeypatch):

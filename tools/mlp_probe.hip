@@ -151,6 +151,9 @@ int main(int argc, char** argv) {
 #if defined(PROBE_32) || defined(PROBE_CO)
         p.wpk_fmt = 1;
 #endif
+#ifdef PROBE_16
+        p.wpk_fmt = 2;
+#endif
 #ifdef PROBE_WS
         p.wpk_fmt = 2;
 #endif
