@@ -139,7 +139,7 @@ def kernel_flops(cat, rows, D=384, H=1536, heads=6, ntok=257):
 
 
 # rocprofv3 kernel names of the categories, most specific first (keys of profiles/<tag>_traffic.json)
-TRAFFIC_KEYS = {"mlp_fused": ["void mlp32_kernel<true, true, 0, false>", "void mlp32_kernel<true, true, 0>"],
+TRAFFIC_KEYS = {"mlp_fused": ["void mlp32_kernel<true, true, 0>", "void mlp16_kernel<true, true, 0>", "void mlp32_kernel<true, true, 0, false>"],
                 "qkv_attention_fused": ["qkv_attn_kernel"],
                 "qkv_gemm": ["void seqgemm_pipe_kernel<false, 0, true, true, false, true>", "void seqgemm_pipe_kernel<true, 0, true, false, false, false>",
                              "void seqgemm_pipe_kernel<true, 0>"],
@@ -149,17 +149,28 @@ TRAFFIC_KEYS = {"mlp_fused": ["void mlp32_kernel<true, true, 0, false>", "void m
                 "abmil_fused": ["void abmil32_kernel<24>", "abmil_pipe_kernel", "void abmil_stream_kernel<6>"]}
 
 
-def pmc_traffic(cat):
+def pmc_traffic(cat, with_source=False):
     """Per-launch HBM bytes from the newest committed PMC summary (separate rocprofv3 --pmc passes, corrected as
-    MI355X_MICROARCH.md prescribes; tools/summarize_profile.py), or None."""
+    MI355X_MICROARCH.md prescribes; tools/summarize_profile.py), or None.  NOT measured by this run (counters need rocprofv3):
+    with_source=True also names the file the figure was read from and the commit that last touched it."""
     pdir = os.path.join(ROOT, "profiles")
     for f in sorted([p for p in os.listdir(pdir) if p.endswith("_traffic.json")], reverse=True) if os.path.isdir(pdir) else []:
         t = json.load(open(os.path.join(pdir, f)))
         for k in TRAFFIC_KEYS.get(cat, []):
             for name, v in t.items():
                 if name.startswith(k) or k in name:
-                    return v["hbm_bytes"]
-    return None
+                    if not with_source:
+                        return v["hbm_bytes"]
+                    commit = None
+                    try:
+                        import subprocess
+                        commit = subprocess.run(["git", "-C", ROOT, "log", "-n", "1", "--format=%h", "--", os.path.join("profiles", f)],
+                                                capture_output=True, text=True, timeout=10).stdout.strip() or None
+                    except Exception:
+                        pass
+                    return v["hbm_bytes"], {"file": "profiles/" + f, "kernel": name, "commit": commit,
+                                            "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command (tools/run_profile.sh), per launch"}
+    return (None, None) if with_source else None
 
 
 def host_cores():
@@ -390,19 +401,32 @@ def main():
         t5 = time.perf_counter()
         r5 = run5()
         barrier()
-        d5 = torch.tensor([time.perf_counter() - t5], dtype=torch.float64, device=dev)
+        t5_local = time.perf_counter() - t5  # (incl. the wait at the closing barrier: the job's time as this rank saw it)
+        d5 = torch.tensor([t5_local], dtype=torch.float64, device=dev)
         nreg = torch.tensor([r5.local_regions], dtype=torch.float64, device=dev)
+        # per-rank load: regions, slides and the seconds a rank spent in its own slides (before the gather) -- min / max over the
+        # ranks show the imbalance of the slide-level sharding directly
+        mine = torch.tensor([float(r5.local_regions), float(len(r5.local_slides)), float(r5.local_seconds)],
+                            dtype=torch.float64, device=dev)
+        lo, hi = mine.clone(), mine.clone()
         if world > 1:
             torch.distributed.all_reduce(d5, op=torch.distributed.ReduceOp.MAX)
             torch.distributed.all_reduce(nreg, op=torch.distributed.ReduceOp.SUM)
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         d5, nreg = float(d5.item()), float(nreg.item())
+        per_rank = {"regions_min": int(lo[0].item()), "regions_max": int(hi[0].item()), "slides_min": int(lo[1].item()),
+                    "slides_max": int(hi[1].item()), "seconds_min": float(lo[2].item()), "seconds_max": float(hi[2].item())}
         total_regions = sum(s.n_regions for s in slides)
         cfg5 = {"slides": args.slides, "regions_per_slide_nominal": args.slide_regions, "regions_sampled_per_slide": ns,
                 "seconds": d5, "regions_per_s": nreg / d5, "sampled_slides_per_s": args.slides / d5,
                 "slides_per_s_extrapolated": args.slides / (d5 * total_regions / nreg),
-                "note": "slide i -> rank i mod G; per slide the sampled regions through HIPT_4K (bf16), the features tiled to the slide's "
-                        "n regions, CLAM_SB [192,128,64], ONE all-gather of logits + ragged A_raw; extrapolation = measured time x "
-                        "(all regions / sampled regions), i.e. it charges the per-slide CLAM_SB + gather at the sampled rate",
+                "per_rank": per_rank,
+                "note": "a PLUMBING check of BASELINE configs[4], not a throughput figure: slide i -> rank i mod G; per slide only the stated "
+                        "sample of its regions goes through HIPT_4K (bf16), the features are tiled to the slide's n regions, CLAM_SB "
+                        "[192,128,64] and ONE all-gather of logits + ragged A_raw carry their true sizes.  slides_per_s_extrapolated = "
+                        "measured time x (all regions / sampled regions): it charges the per-slide CLAM_SB + gather at the sampled rate and "
+                        "is dominated by the 8 sampled regions per slide -- the headline `value` is the measured throughput",
                 "gathered_logits_shape": list(r5.logits.shape), "gathered_a_raw_total": int(sum(a.numel() for a in r5.a_raw))}
 
     if rank != 0:
@@ -474,7 +498,7 @@ def main():
             frac[c] = {"achieved": ach, "frac": ach / PEAK_TFLOPS[args.dtype], "avg_launch_us": v["avg_us"], "launches_per_step": v["launches_per_step"]}
         dom = max(mf, key=lambda c: mf[c]["ms_per_step"])  # dominant kernel = largest share of the step
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": frac[dom]["achieved"], "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                           "frac": frac[dom]["frac"], "traffic": pmc_traffic(dom), "flops_per_launch": flops_of(dom),
+                           "frac": frac[dom]["frac"], "traffic": pmc_traffic(dom), "traffic_source": pmc_traffic(dom, True)[1], "flops_per_launch": flops_of(dom),
                            "rows_per_launch": rows_launch, "launches_per_step": mf[dom]["launches_per_step"], "avg_launch_us": mf[dom]["avg_us"]}
         out["roofline_all"] = {c: round(f["frac"], 4) for c, f in frac.items()}
         if all(c in frac for c in ("qkv_attention_fused", "proj_gemm")):
@@ -488,7 +512,8 @@ def main():
                                               "cls_rows_us_per_block": side,
                                               "achieved": fl / (us * 1e-6) / 1e12, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                               "frac": fl / (us * 1e-6) / 1e12 / PEAK_TFLOPS[args.dtype], "target": 0.60,
-                                              "traffic": pmc_traffic("qkv_attention_fused")}
+                                              "traffic": pmc_traffic("qkv_attention_fused"),
+                                              "traffic_source": pmc_traffic("qkv_attention_fused", True)[1]}
         elif all(c in frac for c in ("qkv_gemm", "attention", "proj_gemm")):
             # north_star's "ViT-256 attention" unit: LN1 + QKV + QK^T + softmax + PV + proj = 404 620 800 FLOP per patch and block
             us = sum(frac[c]["avg_launch_us"] for c in ("qkv_gemm", "attention", "proj_gemm"))
@@ -499,18 +524,21 @@ def main():
     if "abmil_fused" in kernels:
         esz = 2 if args.dtype == "bf16" else 4
         alg = BAG_N * BAG_S0 * esz + 4 * BAG_N
-        gbs = alg / (kernels["abmil_fused"]["avg_us"] * 1e-6) / 1e9
+        # `frac` / `achieved` / `avg_launch_us`: one HIP-event pair around every launch, as every other roofline entry of this line and
+        # as in earlier rounds.  The kernel's own pace (20 launches in one replayed HIP graph between ONE event pair: no event record
+        # between launches) is reported beside it under its own names -- single-process runs with extras only.
         us = kernels["abmil_fused"]["avg_us"]
-        how = "one HIP-event pair around every launch (library profile)"
+        gbs = alg / (us * 1e-6) / 1e9
+        ra = {"kernel": "abmil_fused", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+              "frac": gbs / PEAK_HBM_GBS, "traffic": pmc_traffic("abmil_fused"), "traffic_source": pmc_traffic("abmil_fused", True)[1],
+              "algorithmic_bytes": alg, "avg_launch_us": us, "timing": "one HIP-event pair around every launch (library profile)",
+              "graph": abmil_graph, "target": 0.50}
         if abmil_graph and "us_per_launch_mean" in abmil_graph:
-            us = abmil_graph["us_per_launch_mean"]
-            how = (f"{abmil_graph['launches']} launches in one replayed HIP graph between one HIP-event pair on their stream, "
-                   f"mean of {abmil_graph['replays']} replays")
-            gbs = alg / (us * 1e-6) / 1e9
-        out["roofline_abmil"] = {"kernel": "abmil_fused", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": gbs / PEAK_HBM_GBS, "traffic": pmc_traffic("abmil_fused"), "algorithmic_bytes": alg,
-                                 "avg_launch_us": us, "timing": how, "avg_launch_us_event_pairs": kernels["abmil_fused"]["avg_us"],
-                                 "graph": abmil_graph, "target": 0.50}
+            ug = abmil_graph["us_per_launch_mean"]
+            ra.update({"avg_launch_us_graph": ug, "achieved_graph": alg / (ug * 1e-6) / 1e9, "frac_graph": alg / (ug * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                       "timing_graph": (f"{abmil_graph['launches']} launches in one replayed HIP graph between one HIP-event pair on their "
+                                        f"stream, mean of {abmil_graph['replays']} replays")})
+        out["roofline_abmil"] = ra
 
     # ---- the reference's own call patterns (SURVEY.md §8d configs 2-3 as the unmodified scripts issue them) ----
     if not args.no_extras:

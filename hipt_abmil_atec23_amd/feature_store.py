@@ -69,28 +69,52 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
     8+ regions per call).  Consecutive loader batches of the same shape and type are therefore gathered until ``coalesce``
     regions are at hand and go through ``model`` in ONE call; features and coordinates are appended in loader order, and a
     region's features do not depend on what else is in the call (rows are independent through every kernel), so the saved
-    files are the ones the one-by-one loop writes -- bit for bit for 4096 x 4096 regions (any patch count that is a multiple
-    of 16: both calls then take the same kernels; tested), to the bf16 bar otherwise.  ``coalesce <= 1`` restores the one-by-one loop."""
+    files are the ones the one-by-one loop writes -- bit for bit: only regions whose patch count is a multiple of 16 (4096 x 4096:
+    256) are gathered, because both calls then take the same kernels (tested); other sizes go one loader batch per call.
+    ``coalesce <= 1`` restores the one-by-one loop for everything.  Peak memory of a gathered call: the gathered batch plus one
+    loader batch."""
     w = FeatureWriter(feat_dir, slide_id)
     held: list = []  # (regions, coords) waiting for company
 
     def flush():
         if not held:
             return
-        regions = held[0][0] if len(held) == 1 else torch.cat([r for r, _ in held], 0)
-        feats = model(regions)
-        o = 0
-        for r, c in held:  # one append per loader batch, as the reference's loop does
-            w.append(feats[o:o + r.shape[0]], c)
-            o += r.shape[0]
+        counts, coords = [r.shape[0] for r, _ in held], [c for _, c in held]
+        if len(held) == 1:
+            regions = held[0][0]
+        else:
+            # gathered in ONE buffer, each loader batch released as soon as it is copied: the peak is the gathered batch plus one
+            # loader batch (8 fp32 4096 x 4096 regions: 1.6 GB + 0.2 GB), not two copies of everything
+            regions = torch.empty((sum(counts),) + tuple(held[0][0].shape[1:]), dtype=held[0][0].dtype, device=held[0][0].device)
+            o = 0
+            for i in range(len(held)):
+                r = held[i][0]
+                regions[o:o + r.shape[0]].copy_(r)
+                o += r.shape[0]
+                held[i] = None
+                del r
         held.clear()
+        feats = model(regions)
+        del regions
+        o = 0
+        for n, c in zip(counts, coords):  # one append per loader batch, as the reference's loop does
+            w.append(feats[o:o + n], c)
+            o += n
+
+    def gathers_bit_exactly(regions) -> bool:
+        # whole 16-row fragments in every call (patch count a multiple of 16): the gathered call and the one-by-one call take the
+        # same kernels and write the same bits; other region sizes are NOT gathered (they would agree to the bf16 bar only)
+        if regions.dim() != 4:
+            return False
+        hw = regions.shape[2:] if regions.shape[1] == 3 else regions.shape[1:3]  # planar [R,3,W,H] or interleaved [R,W,H,3]
+        return ((hw[0] // 256) * (hw[1] // 256)) % 16 == 0
 
     with torch.no_grad():
         for regions, coords in batches:
             if held and (regions.shape[1:] != held[0][0].shape[1:] or regions.dtype != held[0][0].dtype or regions.device != held[0][0].device):
                 flush()  # a different shape / type cannot share a call
             held.append((regions, coords))
-            if coalesce <= 1 or sum(r.shape[0] for r, _ in held) >= coalesce:
+            if coalesce <= 1 or not gathers_bit_exactly(regions) or sum(r.shape[0] for r, _ in held) >= coalesce:
                 flush()
         flush()
     return w.close()

@@ -443,7 +443,10 @@ class CLAM_SB(nn.Module):
             # |A_raw - bc| <= sum |wc_j| (tanh * sigmoid lies in (-1, 1)): lets the streaming kernel exponentiate against a fixed
             # shift instead of a running maximum (include/hipt_abmil.h, hipt_clam_weights.logit_bound); one tiny reduction per
             # set of weights, read back here once
-            w.logit_bound = float(keep["wc"].abs().sum().item())
+            # (0 means "unknown" in the ABI: an all-zero attention_c -- a zero-initialised head -- has the bound 0 and still takes the
+            #  streaming kernel through the smallest positive bound.  The read-back synchronises once per set of weights; pack outside
+            #  a graph capture.)
+            w.logit_bound = max(float(keep["wc"].abs().sum().item()), 1e-30)
             # the streaming kernel's LDS image of these weights (bf16 [384|192,128,64]): packed once here, copied straight by
             # LDS-DMA at every launch
             nb = N.lib().hipt_clam_stream_packed_bytes(C_.byref(w))

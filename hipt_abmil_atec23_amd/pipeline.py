@@ -80,6 +80,7 @@ class SlideRun:
     local_regions: int = 0                    # regions this rank pushed through HIPT_4K
     local_features: Dict[int, torch.Tensor] = field(default_factory=dict)   # slide -> [n_s, d] (kept when keep_features)
     seconds: float = 0.0                      # wall time of this rank's loop + gather (no barrier inside)
+    local_seconds: float = 0.0                # ... of its own slides alone (device work finished, before the gather): the load-imbalance figure
 
 
 def process_slides(model: Callable, clam: Callable, slides: Sequence[SlideSpec], rank: int = 0, world: int = 1, *,
@@ -135,6 +136,9 @@ def process_slides(model: Callable, clam: Callable, slides: Sequence[SlideSpec],
             logits, _, _, a_raw, _ = clam(bag)
             lg.append(logits.reshape(-1))
             ar.append(a_raw.reshape(-1))
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)  # (this rank's share is DONE here: what min / max over the ranks compare)
+    run.local_seconds = time.perf_counter() - t0
     run.logits, run.a_raw = D.gather_slide_outputs(mine, lg, ar, len(slides), device=device)
     run.seconds = time.perf_counter() - t0
     return run

@@ -134,6 +134,35 @@ def test_bench_dry_run_two_ranks(launcher):
     assert bad.returncode != 0 and not any(l.startswith("{") for l in bad.stdout.splitlines())
 
 
+def test_bench_dry_run_eight_ranks_and_fewer_slides_than_ranks():
+    """The driver's 8-rank launch form rehearsed on CPU / gloo: (i) 8 ranks over the default 64 slides, (ii) 8 ranks over 5
+    slides -- three ranks have NO slide: they must contribute an empty (all -1) block to the gather and still reach every barrier,
+    and the gathered result must be the whole job.  config5's per-rank min / max show the imbalance directly."""
+    import json
+    import subprocess
+    from hipt_abmil_atec23_amd import pipeline as PL
+    bench = os.path.join(ROOT, "bench.py")
+    for slides in (64, 5):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), bench, "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run", "--slides", str(slides)]
+        env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")  # 8 ranks on the container's 8 cores
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=560, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        d = json.loads(lines[0])
+        c5 = d["config5"]
+        assert d["dry_run"] is True and d["n_gpus"] == 8 and d["value"] > 0
+        assert c5["slides"] == slides and c5["gathered_logits_shape"] == [slides, 2]
+        assert c5["gathered_a_raw_total"] == sum(s.n_regions for s in PL.synthetic_slides(slides, 8192))
+        pr = c5["per_rank"]
+        if slides == 5:
+            assert pr["slides_min"] == 0 and pr["slides_max"] == 1 and pr["regions_min"] == 0 and pr["regions_max"] > 0
+        else:
+            assert pr["slides_min"] == pr["slides_max"] == 8 and pr["regions_min"] > 0
+        assert 0 <= pr["seconds_min"] <= pr["seconds_max"]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # GPU: the real models
 # ---------------------------------------------------------------------------------------------------------------------
