@@ -118,6 +118,7 @@ class _HipVitMixin:
         """The device-side images (ctypes structs + packed tensors) are caches: never pickled, never deep-copied."""
         d = self.__dict__.copy()
         d["_packed"], d["_pos_cache"] = {}, {}
+        d.pop("_graphs", None)  # (captured HIP graphs of small calls: a cache as well)
         return d
 
     def set_compute_dtype(self, name: str):
@@ -426,6 +427,7 @@ class VisionTransformer(_HipVitMixin, nn.Module):
 
     def forward_features(self, x, layout=None, nseq=None, chunk=0):
         """[nseq, D] CLS features; ``layout`` lets HIPT_4K address 256x256 patches inside a region."""
+        own_layout = layout is None
         x, pk = (x, None) if layout is not None else self._prep_input(x)
         if layout is None:
             layout, nseq = self._layout(x), x.shape[0]
@@ -434,12 +436,51 @@ class VisionTransformer(_HipVitMixin, nn.Module):
             N.same_device(type(self).__name__, self.pos_embed.device, x)
             pk = self._packed_for(self._pos_for((layout.patch_h // 16) * (layout.patch_w // 16), layout.patch_h,
                                                 layout.patch_w))
-        out = torch.empty((nseq, pk.w.dim), dtype=torch.float32, device=x.device)
         need = N.lib().hipt_vit256_forward_workspace_bytes(pk.ref, C.byref(layout), nseq, chunk)
+        # A handful of patches (BASELINE configs[1]: ONE 256 x 256 patch) is ~150 launches of a few microseconds of work each: the
+        # call is launch-bound.  The library only enqueues, so such a call is captured once per (shape, weights) into a HIP graph
+        # and replayed: one launch of the whole forward.
+        if own_layout and nseq <= self.graph_max_patches and not torch.cuda.is_current_stream_capturing():
+            g = self._graph_for(x, pk, layout, nseq, chunk, need)
+            if g is not None:
+                g["x"].copy_(x)
+                g["graph"].replay()
+                return g["out"].clone()
+        out = torch.empty((nseq, pk.w.dim), dtype=torch.float32, device=x.device)
         ws = Fn.workspace(x.device, need)
         N.call("hipt_vit256_forward", pk.ref, N.ptr(x), C.byref(layout), nseq, chunk, N.ptr(out), N.ptr(ws), ws.numel(),
                N.stream_ptr(x.device))
         return out
+
+    graph_max_patches = 4  # calls of at most this many patches replay a captured HIP graph (0: never)
+
+    def _graph_for(self, x, pk, layout, nseq, chunk, need):
+        """The captured forward for this input shape and these packed weights (buffers of its own: input, output, workspace), or None
+        when capture is not possible on this stack -- the plain enqueue then runs, never anything else."""
+        key = (x.device, tuple(x.shape), id(pk), chunk)
+        cache = self.__dict__.setdefault("_graphs", {})
+        g = cache.get(key)
+        if g is None:
+            try:
+                # eager once on the capture's own buffers (first-use attribute calls of the kernels must not fall inside a capture)
+                xs, out = torch.empty_like(x), torch.empty((nseq, pk.w.dim), dtype=torch.float32, device=x.device)
+                ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+                xs.copy_(x)
+                side = torch.cuda.Stream(device=x.device)
+                side.wait_stream(torch.cuda.current_stream(x.device))
+                with torch.cuda.stream(side):
+                    N.call("hipt_vit256_forward", pk.ref, N.ptr(xs), C.byref(layout), nseq, chunk, N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(x.device))
+                torch.cuda.current_stream(x.device).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    N.call("hipt_vit256_forward", pk.ref, N.ptr(xs), C.byref(layout), nseq, chunk, N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(x.device))
+                g = {"graph": graph, "x": xs, "out": out, "ws": ws, "pk": pk}
+            except Exception as e:  # (reported once, then the plain path for this key)
+                g = {"error": repr(e)[:200]}
+            if len(cache) >= 8:
+                cache.clear()  # (shapes / weights keep changing: do not hoard device memory)
+            cache[key] = g
+        return g if "graph" in g else None
 
     def forward(self, x):
         return self.forward_features(x)

@@ -388,6 +388,37 @@ def test_vit256_fused_mlp_on_16x16x32_mfmas(vit256, monkeypatch):
     assert float((sub[11:] - m16).norm() / m16.norm()) < 1.3e-2  # (27 patches run row-major: another path, the bf16 bar)
 
 
+def test_vit256_small_calls_replay_a_captured_graph(vit256):
+    """BASELINE configs[1] is ONE patch: ~150 launches of microseconds each.  Calls of at most `graph_max_patches` patches are
+    captured once per (shape, weights) and replayed; the result is the plain enqueue's bit for bit, in both precisions, for
+    fresh inputs, and after the weights change (a new capture, never a stale one)."""
+    xs = [synth.hash_uniform_torch((1, 3, 256, 256), 40 + i, device=DEV) for i in range(3)]
+    for dt in ("fp32", "bf16"):
+        vit256.set_compute_dtype(dt)
+        try:
+            vit256.graph_max_patches = 0
+            plain = [vit256(x) for x in xs]
+            vit256.graph_max_patches = 4
+            vit256.__dict__.pop("_graphs", None)
+            replayed = [vit256(x) for x in xs] + [vit256(xs[0])]
+            assert len(vit256._graphs) == 1 and all("graph" in g for g in vit256._graphs.values()), vit256._graphs
+            for a, b in zip(plain + [plain[0]], replayed):
+                assert torch.equal(a, b)
+            three = vit256(torch.cat(xs))  # another shape: its own capture
+            assert len(vit256._graphs) == 2 and torch.allclose(three, torch.cat(plain), atol=1e-2 if dt == "bf16" else 1e-4)
+            keep = vit256.norm.bias.detach().clone()
+            with torch.no_grad():
+                vit256.norm.bias.add_(0.25)  # the weights change: the packed images, and with them the capture, are rebuilt
+            moved = vit256(xs[0])
+            with torch.no_grad():
+                vit256.norm.bias.copy_(keep)
+            assert float((moved - plain[0]).abs().max()) > 0.2
+            assert torch.equal(vit256(xs[0]), plain[0])
+        finally:
+            vit256.graph_max_patches = 4
+            vit256.set_compute_dtype("fp32")
+
+
 def test_vit256_patch_embedding_from_fp32_pixels(vit256, monkeypatch):
     """csrc/embed32.hip reads the fp32 image itself (pixels rounded to bf16 in registers, weights through the LDS-DMA ring); the
     generic path (HIPT_GENERIC=1) makes a bf16 copy of the image and runs the generic GEMM over an im2col view.  Same bf16
