@@ -389,9 +389,9 @@ def test_vit256_fused_mlp_on_16x16x32_mfmas(vit256, monkeypatch):
 
 
 def test_vit256_small_calls_replay_a_captured_graph(vit256):
-    """BASELINE configs[1] is ONE patch: ~150 launches of microseconds each.  Calls of at most `graph_max_patches` patches are
-    captured once per (shape, weights) and replayed; the result is the plain enqueue's bit for bit, in both precisions, for
-    fresh inputs, and after the weights change (a new capture, never a stale one)."""
+    """BASELINE configs[1] is ONE patch: ~150 launches of microseconds each.  With the opt-in `graph_max_patches` > 0, calls of at
+    most that many patches are captured once per (shape, weights) and replayed; the result is the plain enqueue's bit for bit,
+    in both precisions, for fresh inputs, and after the weights change (a new capture, never a stale one)."""
     xs = [synth.hash_uniform_torch((1, 3, 256, 256), 40 + i, device=DEV) for i in range(3)]
     for dt in ("fp32", "bf16"):
         vit256.set_compute_dtype(dt)
@@ -415,7 +415,8 @@ def test_vit256_small_calls_replay_a_captured_graph(vit256):
             assert float((moved - plain[0]).abs().max()) > 0.2
             assert torch.equal(vit256(xs[0]), plain[0])
         finally:
-            vit256.graph_max_patches = 4
+            vit256.graph_max_patches = 0
+            vit256.__dict__.pop("_graphs", None)
             vit256.set_compute_dtype("fp32")
 
 

@@ -1,0 +1,42 @@
+"""One region per HIPT_4K.forward (the reference's batch size): time per call by stream count, with and without the captured ViT-4K
+stage.  usage: python tools/batch1_graph_bench.py [streams ...] [--no-graph]"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from hipt_abmil_atec23_amd import HIPT_4K, synth
+
+dev = "cuda:0"
+m = HIPT_4K(None, None, dev, dev)
+m.model256.load_state_dict(synth.make_state_dict(synth.vit_param_specs("vit256"), 256))
+m.model4k.load_state_dict(synth.make_state_dict(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096))
+m = m.eval().to(dev)
+m.set_compute_dtype("bf16")
+x = synth.hash_uniform_torch((1, 3, 4096, 4096), 3, device=dev)
+
+
+def timed(n=20):
+    for _ in range(3):
+        m(x)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        m(x)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e3
+
+
+graphs = "--no-graph" not in sys.argv
+for streams in [int(a) for a in sys.argv[1:] if a.isdigit()] or [2, 1]:
+    m.streams = streams
+    m.model4k.graph_max_regions = 0
+    a = timed()
+    ref = m(x)
+    line = f"streams {streams}: one region per call {a:.3f} ms ({1e3 / a:.1f} regions/s)"
+    if graphs:
+        m.model4k.graph_max_regions = 2
+        b = timed()
+        line += f" -> with the ViT-4K graph {b:.3f} ms ({1e3 / b:.1f} regions/s); same bits {torch.equal(ref, m(x))}"
+    print(line, flush=True)
