@@ -616,11 +616,13 @@ int hipt_vit_attention_unit(const hipt_vit_weights* w, int block, const void* xn
     return hipt_attention_launch(s.qkv, out_img, nullptr, nseq, w->ntok, w->heads, D / w->heads, attn_scale(w), w->dtype, st, 1, hm ? 1 : 0);
 }
 
-// (HIPT_MLP16=1 at PACK time selects the 16x16x32-MFMA form of the fused MLP -- csrc/mlp16.hip, format 2; the format travels
-//  with the image, so a model packed either way keeps running its own kernel whatever the environment says later)
+// The fused MLP exists on both bf16 MFMA shapes: format 2 = csrc/mlp16.hip (16x16x32, the default since round 4), format 1 =
+// csrc/mlp32.hip (32x32x16; HIPT_MLP32=1 at PACK time).  On the MLP launches themselves the two tie (1 375 us per 8 regions); the
+// 16x16x32 form draws less power, and the kernels between its launches run 3 % faster for it.  The format
+// travels with the image, so a model packed either way keeps running its own kernel whatever the environment says later.
 int hipt_vit_mlp_pack_format(const hipt_vit_weights* w) {
     if (!(w && hipt_mlp32_supported(w->dtype, w->dim, w->hidden))) return 0;
-    return hipt_env_on("HIPT_MLP16") ? 2 : 1;
+    return hipt_env_on("HIPT_MLP32") ? 1 : 2;
 }
 
 size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {

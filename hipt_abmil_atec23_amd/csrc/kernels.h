@@ -124,9 +124,9 @@ int hipt_mlp_launch(const MlpParams& p, hipStream_t st);  // dispatches to the p
 bool hipt_mlp32_supported(int dtype, int D, int hidden);
 int hipt_mlp32_launch(const MlpParams& p, hipStream_t st);
 int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);
-// The same kernel on 16x16x32 MFMAs (mlp16.hip; image format 2, same size): the matrix pipes hold a higher clock on that shape under
-// the power cap, the waves pay twice the MFMA issue -- a tie on the fused MLP itself, +3 % on the kernels that run between its
-// launches; selected at pack time by HIPT_MLP16=1.
+// The same kernel on 16x16x32 MFMAs (mlp16.hip; image format 2, same size; the default since round 4): the matrix pipes hold a higher
+// clock on that shape under the power cap, the waves pay twice the MFMA issue -- a tie on the fused MLP itself, +3 % on the kernels
+// that run between its launches.  HIPT_MLP32=1 at pack time selects format 1.
 bool hipt_mlp16_supported(int dtype, int D, int hidden);
 int hipt_mlp16_launch(const MlpParams& p, hipStream_t st);
 int hipt_mlp16_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);

@@ -165,8 +165,8 @@ size_t hipt_vit_workspace_bytes(const hipt_vit_weights* w, int nseq);
  * Done once per set of weights by the module that owns them (vision_transformer.py:_PackedVit here). */
 size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what);
 /* The fused-MLP image format hipt_vit_pack_weights(.., HIPT_PACK_MLP, ..) writes for this model, to be stored in
- * hipt_block_weights.mlp_pk_fmt beside the pointer: 1 = the streaming (32x32x16-MFMA) kernel's fragment image, 2 = its
- * 16x16x32-MFMA form's (HIPT_MLP16=1 in the environment when packing), 0 = this
+ * hipt_block_weights.mlp_pk_fmt beside the pointer: 2 = the streaming kernel's fragment image on 16x16x32 MFMAs (the default),
+ * 1 = its 32x32x16-MFMA form's (HIPT_MLP32=1 in the environment when packing), 0 = this
  * dtype / shape has no packed form (the generic kernel reads the row-major matrices). */
 int hipt_vit_mlp_pack_format(const hipt_vit_weights* w);
 int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* out, void* stream);

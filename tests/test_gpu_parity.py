@@ -341,7 +341,7 @@ def test_vit256_streaming_kernels_vs_generic_kernels(vit256, monkeypatch):
     try:
         pk = vit256._tokens(x)[0]
         assert all(pk.blocks[i].mlp_pk and pk.blocks[i].qkv_pk and pk.blocks[i].proj_pk and pk.blocks[i].qkv_att_pk for i in range(pk.w.depth))
-        assert all(pk.blocks[i].mlp_pk_fmt == 1 for i in range(pk.w.depth))
+        assert all(pk.blocks[i].mlp_pk_fmt == 2 for i in range(pk.w.depth))  # (the 16x16x32 form is the default)
         default = vit256(x), vit256.get_intermediate_layers(x, n=2)
         monkeypatch.setenv("HIPT_GENERIC", "1")
         generic = vit256(x), vit256.get_intermediate_layers(x, n=2)
@@ -359,30 +359,31 @@ def test_vit256_streaming_kernels_vs_generic_kernels(vit256, monkeypatch):
         N.call("hipt_vit_pack_weights", pk32.ref, 0, N.PACK_MLP, N.ptr(x), N.stream_ptr(x.device))
 
 
-def test_vit256_fused_mlp_on_16x16x32_mfmas(vit256, monkeypatch):
-    """csrc/mlp16.hip: the fused MLP on the other bf16 MFMA shape (HIPT_MLP16=1 when the weight images are packed: image format 2).
-    Another fragment / accumulator layout and another summation order over the same bf16 products: held to the bf16 bar against
-    the default kernel, bit-identical between batchings, and the format travels with the image (no environment at launch)."""
+def test_vit256_fused_mlp_on_both_mfma_shapes(vit256, monkeypatch):
+    """The fused MLP exists on both bf16 MFMA shapes: csrc/mlp16.hip (16x16x32, image format 2, the default) and csrc/mlp32.hip
+    (32x32x16, format 1, HIPT_MLP32=1 when the weight images are packed).  Another fragment / accumulator layout and another
+    summation order over the same bf16 products: held to the bf16 bar against each other, bit-identical between batchings, and
+    the format travels with the image (no environment at launch)."""
     x = synth.hash_uniform_torch((16, 3, 256, 256), 23, device=DEV)
     vit256.set_compute_dtype("bf16")
     try:
         default = vit256(x)
-        assert all(vit256._tokens(x)[0].blocks[i].mlp_pk_fmt == 1 for i in range(12))
+        assert all(vit256._tokens(x)[0].blocks[i].mlp_pk_fmt == 2 for i in range(12))
         vit256._packed.clear()
-        monkeypatch.setenv("HIPT_MLP16", "1")
+        monkeypatch.setenv("HIPT_MLP32", "1")
         pk = vit256._tokens(x)[0]
-        monkeypatch.delenv("HIPT_MLP16")
-        assert all(pk.blocks[i].mlp_pk_fmt == 2 and pk.blocks[i].mlp_pk for i in range(12))
+        monkeypatch.delenv("HIPT_MLP32")
+        assert all(pk.blocks[i].mlp_pk_fmt == 1 and pk.blocks[i].mlp_pk for i in range(12))
         m16 = vit256(x)
-        assert all(vit256._tokens(x)[0].blocks[i].mlp_pk_fmt == 2 for i in range(12))  # (the same images: still format 2)
+        assert all(vit256._tokens(x)[0].blocks[i].mlp_pk_fmt == 1 for i in range(12))  # (the same images: still format 1)
         sub = vit256(torch.cat([x[5:], x]))  # (27 patches: other tiles, other positions inside them, still whole fragments? no: 27 * 257 rows)
         two = vit256(torch.cat([x, x]))      # 32 patches = whole 16-row fragments, like the 16: the same kernels, other tile positions
     finally:
-        monkeypatch.delenv("HIPT_MLP16", raising=False)
+        monkeypatch.delenv("HIPT_MLP32", raising=False)
         vit256._packed.clear()
         vit256.set_compute_dtype("fp32")
     rel = float((m16 - default).norm() / default.norm())
-    print(f"fused MLP 16x16x32 vs 32x32x16: [CLS] features rel-L2 {rel:.2e}")
+    print(f"fused MLP 32x32x16 vs 16x16x32: [CLS] features rel-L2 {rel:.2e}")
     assert 0 < rel < 1.3e-2
     assert torch.equal(two[:16], m16) and torch.equal(two[16:], m16)
     assert float((sub[11:] - m16).norm() / m16.norm()) < 1.3e-2  # (27 patches run row-major: another path, the bf16 bar)

@@ -34,7 +34,7 @@ def short(name):
 
 
 def ours(name):
-    return any(k in name for k in ("seqgemm", "mlp_kernel", "mlp_pipe_kernel", "mlp32_kernel", "mlp_co_kernel", "mlp_ws_kernel", "mlp32_pack", "mlp_ws_pack", "embed32", "gemm_kernel", "attn_kernel", "attn64_kernel", "attn_cls_kernel", "gather_cls", "u8_norm", "ln_kernel", "abmil", "mlp_pack",
+    return any(k in name for k in ("seqgemm", "mlp_kernel", "mlp_pipe_kernel", "mlp32_kernel", "mlp16_kernel", "mlp16_pack", "qkv_attn", "mlp_co_kernel", "mlp_ws_kernel", "mlp32_pack", "mlp_ws_pack", "embed32", "gemm_kernel", "attn_kernel", "attn64_kernel", "attn_cls_kernel", "gather_cls", "u8_norm", "ln_kernel", "abmil", "mlp_pack",
                                    "cls_init", "f32_to_bf16", "gate_kernel", "pool_kernel", "add_bf16", "clam_train", "topk_rows", "attn_cls_probs"))
 
 
