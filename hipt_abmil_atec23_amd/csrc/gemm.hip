@@ -193,8 +193,63 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
     }
 }
 
+// ---- small M (a few hundred rows: ONE 256 x 256 patch through ViT-256 is 257, BASELINE configs[1]; the second-level ViT of a region;
+// the [CLS] rows of a launch) ----
+// The sequence-tiled kernel above puts such a problem on N / 128 workgroups -- 3 for the proj / fc2 Linears of ViT-256, 9 for QKV:
+// a fp32 one-patch forward spent 5.8 ms on nine CUs.  Here a WAVE owns one 16-row fragment x 32 output columns and streams both
+// operands straight from L2 (the whole problem is a few MB: no LDS, no barriers), k-step after k-step in order (a row's sum does
+// not depend on what else is in the call); a 4-wave workgroup covers 16 rows x 128 columns: ceil(M / 16) x ceil(N / 128)
+// workgroups -- 51 to 204 for ViT-256's Linears at 257 rows.
+constexpr int SMALL_M = 1088;  // at most four 272-row sequences take this kernel
+
+template <typename T, int FLAGS>
+__global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int row0 = (blockIdx.x / tiles_n) * 16, n0 = (blockIdx.x % tiles_n) * BN + wave * 32;
+    if (n0 >= p.N) return;
+    constexpr int EPC = Tr<T>::EPC, KC = 4 * EPC;  // one mma16 call consumes KC k values: lane group g supplies its 16-byte chunk
+    int r = row0 + li;
+    r = r < p.M ? r : p.M - 1;                      // (padding rows re-read the last valid row: never stored)
+    const T* ap = (const T*)p.A + (int64_t)r * p.lda + g * EPC;
+    const T* wp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int n = n0 + j * 16 + li;
+        n = n < p.N ? n : p.N - 1;
+        wp[j] = (const T*)p.W + (int64_t)n * p.ldw + g * EPC;
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int nk = p.K / KC;
+    // operands of step k + 1 are requested before the products of step k are issued
+    u32x4 a = *(const u32x4*)ap, w0 = *(const u32x4*)wp[0], w1 = *(const u32x4*)wp[1];
+    for (int k = 0; k < nk; ++k) {
+        const int kn = (k + 1 < nk ? k + 1 : k) * KC;
+        const u32x4 an = *(const u32x4*)(ap + kn), w0n = *(const u32x4*)(wp[0] + kn), w1n = *(const u32x4*)(wp[1] + kn);
+        Tr<T>::mma16(acc[0], w0, a);
+        Tr<T>::mma16(acc[1], w1, a);
+        a = an;
+        w0 = w0n;
+        w1 = w1n;
+    }
+    if (row0 + li >= p.M) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + j * 16 + 4 * g;
+        if (n < p.N) epilogue<T, FLAGS>(p, row0 + li, n, acc[j]);
+    }
+}
+
 template <typename T, int ALOAD, int FLAGS>
 int launch(const GemmParams& p, hipStream_t st) {
+    if constexpr (ALOAD == ALOAD_PLAIN) {
+        if (p.M <= SMALL_M && p.K % (4 * Tr<T>::EPC) == 0) {
+            hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS>), dim3(((p.M + 15) / 16) * ((p.N + BN - 1) / BN)), dim3(256), 0, st, p);
+            HIPT_CHECK_LAUNCH();
+            return HIPT_OK;
+        }
+    }
     const int tiles = ((p.M + p.rpt - 1) / p.rpt) * ((p.N + BN - 1) / BN);
     static DevOnce once;  // > 64 KiB dynamic LDS needs the opt-in once per kernel and device
     HIPT_CUR_DEVICE(dev);

@@ -118,54 +118,7 @@ class _HipVitMixin:
         """The device-side images (ctypes structs + packed tensors) are caches: never pickled, never deep-copied."""
         d = self.__dict__.copy()
         d["_packed"], d["_pos_cache"] = {}, {}
-        d.pop("_graphs", None)  # (captured HIP graphs of small calls: a cache as well)
         return d
-
-    # Captured-graph replay of launch-bound calls: OPT-IN (0 = never, the default).  Measured on MI355X: one 256 x 256 patch through
-    # ViT-256 in bf16 1.60 -> 0.39 ms (fp32: 5.8 ms either way -- that call is bound by its nine-workgroup GEMMs, not by launches);
-    # HIPT_4K's second stage of one region 5.06 -> 5.03 ms.  Why not on by default: a replay issued after the allocator has released
-    # and re-mapped other device memory (a first large call, a new stream's workspace) has faulted on this stack
-    # (tools/graph_interleave_check.py reproduces it; every buffer the graph names is alive -- unresolved), while replays right after
-    # the capture are bit-identical to the plain enqueue (tests/test_gpu_parity.py).  Set them on a model that only ever sees small calls.
-    graph_max_patches = 0  # ViT-256 calls of at most this many patches replay a captured HIP graph
-    graph_max_regions = 0  # ViT-4K calls (HIPT_4K's second stage) of at most this many regions likewise
-
-    def _replay(self, key, x, out_shape, need, pk, enqueue):
-        """A launch-bound call -- a few hundred rows through ~150 kernels of microseconds each -- as ONE launch: the library only
-        enqueues, so the call is captured once per (shape, packed weights) into a HIP graph with buffers of its own (input, output,
-        workspace) and replayed.  Returns the output, or None when this stack cannot capture (the caller then enqueues plainly --
-        the same kernels either way)."""
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        cache = self.__dict__.setdefault("_graphs", {})
-        key = (x.device,) + tuple(key)
-        g = cache.get(key)
-        if g is None:
-            try:
-                xs = torch.empty_like(x)
-                out = torch.empty(out_shape, dtype=torch.float32, device=x.device)
-                ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-                xs.copy_(x)
-                # once eagerly on the capture's own buffers (first-use attribute calls of the kernels must not fall inside a capture)
-                side = torch.cuda.Stream(device=x.device)
-                side.wait_stream(torch.cuda.current_stream(x.device))
-                with torch.cuda.stream(side):
-                    enqueue(xs, out, ws)
-                torch.cuda.current_stream(x.device).wait_stream(side)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    enqueue(xs, out, ws)
-                g = {"graph": graph, "x": xs, "out": out, "ws": ws, "pk": pk}
-            except Exception as e:  # (remembered: the plain path for this key from now on)
-                g = {"error": repr(e)[:200]}
-            if len(cache) >= 8:
-                cache.clear()  # (shapes / weights keep changing: do not hoard device memory)
-            cache[key] = g
-        if "graph" not in g:
-            return None
-        g["x"].copy_(x)
-        g["graph"].replay()
-        return g["out"].clone()
 
     def set_compute_dtype(self, name: str):
         N.dtype_code(name)
@@ -473,7 +426,6 @@ class VisionTransformer(_HipVitMixin, nn.Module):
 
     def forward_features(self, x, layout=None, nseq=None, chunk=0):
         """[nseq, D] CLS features; ``layout`` lets HIPT_4K address 256x256 patches inside a region."""
-        own_layout = layout is None
         x, pk = (x, None) if layout is not None else self._prep_input(x)
         if layout is None:
             layout, nseq = self._layout(x), x.shape[0]
@@ -483,15 +435,6 @@ class VisionTransformer(_HipVitMixin, nn.Module):
             pk = self._packed_for(self._pos_for((layout.patch_h // 16) * (layout.patch_w // 16), layout.patch_h,
                                                 layout.patch_w))
         need = N.lib().hipt_vit256_forward_workspace_bytes(pk.ref, C.byref(layout), nseq, chunk)
-        # A handful of patches (BASELINE configs[1]: ONE 256 x 256 patch) is ~150 launches of a few microseconds of work each: the
-        # call is launch-bound.  The library only enqueues, so such a call is captured once per (shape, weights) into a HIP graph
-        # and replayed: one launch of the whole forward.
-        if own_layout and nseq <= self.graph_max_patches:
-            got = self._replay((tuple(x.shape), id(pk), chunk), x, (nseq, pk.w.dim), need, pk,
-                               lambda xs, out, ws: N.call("hipt_vit256_forward", pk.ref, N.ptr(xs), C.byref(layout), nseq, chunk, N.ptr(out),
-                                                          N.ptr(ws), ws.numel(), N.stream_ptr(x.device)))
-            if got is not None:
-                return got
         out = torch.empty((nseq, pk.w.dim), dtype=torch.float32, device=x.device)
         ws = Fn.workspace(x.device, need)
         N.call("hipt_vit256_forward", pk.ref, N.ptr(x), C.byref(layout), nseq, chunk, N.ptr(out), N.ptr(ws), ws.numel(),

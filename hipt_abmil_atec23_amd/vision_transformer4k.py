@@ -96,15 +96,6 @@ class VisionTransformer4K(_HipVitMixin, nn.Module):
         pk = self._packed_for(self._pos_for(w * h, w, h))
         B = tokens_in.shape[0]
         need = N.lib().hipt_vit4k_forward_workspace_bytes(pk.ref, B)
-        if B <= self.graph_max_regions:
-            # the second stage of ONE region (the reference's batch size, extract_features_fp.py:159-171): 257 rows through 24
-            # latency-sized launches -- 0.6 of the call's 5.1 ms -- replayed from a captured graph instead
-            tin = tokens_in.contiguous()
-            got = self._replay(("vit4k", tuple(tin.shape), id(pk), w, h), tin, (B, pk.w.dim), need, pk,
-                               lambda xs, out, ws: N.call("hipt_vit4k_forward", pk.ref, N.ptr(xs), B, N.ptr(out), N.ptr(ws), ws.numel(),
-                                                          N.stream_ptr(xs.device)))
-            if got is not None:
-                return got
         out = torch.empty((B, pk.w.dim), dtype=torch.float32, device=tokens_in.device)
         ws = Fn.workspace(tokens_in.device, need)
         N.call("hipt_vit4k_forward", pk.ref, N.ptr(tokens_in), B, N.ptr(out), N.ptr(ws), ws.numel(),

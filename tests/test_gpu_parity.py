@@ -84,7 +84,10 @@ def test_layernorm(rows, D):
     assert out16.dtype == torch.bfloat16 and md(out16, ref) < 3e-2
 
 
-@pytest.mark.parametrize("M,Nn,K", [(1, 64, 64), (257, 576, 192), (300, 384, 1536), (1000, 1152, 384), (130, 8, 192)])
+# (M <= 1088 rows take the small-M kernel -- a wave per 16 x 32 output tile, operands straight from L2 -- larger ones the
+#  sequence-tiled LDS kernel: both are covered)
+@pytest.mark.parametrize("M,Nn,K", [(1, 64, 64), (257, 576, 192), (300, 384, 1536), (1000, 1152, 384), (130, 8, 192), (1088, 384, 384),
+                                    (1089, 384, 384), (2056, 1152, 384)])
 @pytest.mark.parametrize("mode", ["plain", "gelu", "relu", "resid"])
 def test_linear_fp32(M, Nn, K, mode):
     a = synth.hash_uniform_np((M, K), 41)
@@ -103,7 +106,7 @@ def test_linear_fp32(M, Nn, K, mode):
     assert md(out, ref) < 2e-5
 
 
-@pytest.mark.parametrize("M,Nn,K", [(257, 576, 192), (1000, 1152, 384), (300, 384, 1536)])
+@pytest.mark.parametrize("M,Nn,K", [(257, 576, 192), (1000, 1152, 384), (300, 384, 1536), (1500, 384, 1536), (2056, 1152, 384)])
 def test_linear_bf16(M, Nn, K):
     a = synth.hash_uniform_np((M, K), 41)
     w = synth.hash_uniform_np((Nn, K), 42, 0.05)
@@ -116,6 +119,18 @@ def test_linear_bf16(M, Nn, K):
     assert md(out, ref) < 1e-4
     out16 = Fn.linear(T(a), T(w), T(b), dtype=N.HIPT_BF16, gelu=True, out_f32=False)
     assert out16.dtype == torch.bfloat16 and rel_l2(out16, O.gelu(ref)) < 5e-3
+
+
+def test_linear_small_and_large_calls_agree():
+    """The same rows through the small-M kernel (257 of them alone) and through the sequence-tiled kernel (as the head of 2056):
+    two summation orders of the same products -- fp32 to 1e-5, and each row's result independent of the rest of ITS call."""
+    a = T(synth.hash_uniform_np((2056, 384), 45))
+    w, b = T(synth.hash_uniform_np((1152, 384), 46, 0.05)), T(synth.hash_uniform_np((1152,), 47, 0.1))
+    big = Fn.linear(a, w, b, dtype=N.HIPT_F32)
+    small = Fn.linear(a[:257], w, b, dtype=N.HIPT_F32)
+    assert float((big[:257] - small).abs().max()) < 1e-5
+    assert torch.equal(Fn.linear(a[100:357], w, b, dtype=N.HIPT_F32)[:157], small[100:])  # small kernel: rows do not see each other
+    assert torch.equal(Fn.linear(a[:1500], w, b, dtype=N.HIPT_F32), big[:1500])            # nor in the tiled kernel
 
 
 @pytest.mark.parametrize("B,ntok,heads,dh", [(2, 257, 6, 64), (3, 257, 6, 32), (2, 25, 2, 32), (1, 13, 6, 32), (2, 1, 2, 64),
@@ -387,38 +402,6 @@ def test_vit256_fused_mlp_on_both_mfma_shapes(vit256, monkeypatch):
     assert 0 < rel < 1.3e-2
     assert torch.equal(two[:16], m16) and torch.equal(two[16:], m16)
     assert float((sub[11:] - m16).norm() / m16.norm()) < 1.3e-2  # (27 patches run row-major: another path, the bf16 bar)
-
-
-def test_vit256_small_calls_replay_a_captured_graph(vit256):
-    """BASELINE configs[1] is ONE patch: ~150 launches of microseconds each.  With the opt-in `graph_max_patches` > 0, calls of at
-    most that many patches are captured once per (shape, weights) and replayed; the result is the plain enqueue's bit for bit,
-    in both precisions, for fresh inputs, and after the weights change (a new capture, never a stale one)."""
-    xs = [synth.hash_uniform_torch((1, 3, 256, 256), 40 + i, device=DEV) for i in range(3)]
-    for dt in ("fp32", "bf16"):
-        vit256.set_compute_dtype(dt)
-        try:
-            vit256.graph_max_patches = 0
-            plain = [vit256(x) for x in xs]
-            vit256.graph_max_patches = 4
-            vit256.__dict__.pop("_graphs", None)
-            replayed = [vit256(x) for x in xs] + [vit256(xs[0])]
-            assert len(vit256._graphs) == 1 and all("graph" in g for g in vit256._graphs.values()), vit256._graphs
-            for a, b in zip(plain + [plain[0]], replayed):
-                assert torch.equal(a, b)
-            three = vit256(torch.cat(xs))  # another shape: its own capture
-            assert len(vit256._graphs) == 2 and torch.allclose(three, torch.cat(plain), atol=1e-2 if dt == "bf16" else 1e-4)
-            keep = vit256.norm.bias.detach().clone()
-            with torch.no_grad():
-                vit256.norm.bias.add_(0.25)  # the weights change: the packed images, and with them the capture, are rebuilt
-            moved = vit256(xs[0])
-            with torch.no_grad():
-                vit256.norm.bias.copy_(keep)
-            assert float((moved - plain[0]).abs().max()) > 0.2
-            assert torch.equal(vit256(xs[0]), plain[0])
-        finally:
-            vit256.graph_max_patches = 0
-            vit256.__dict__.pop("_graphs", None)
-            vit256.set_compute_dtype("fp32")
 
 
 def test_vit256_patch_embedding_from_fp32_pixels(vit256, monkeypatch):
