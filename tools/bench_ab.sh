@@ -12,7 +12,8 @@ for r in $(seq 1 $R); do
 import json, sys
 d = json.loads(open("gpurun_out/ab_tmp.json").read().strip().splitlines()[-1])
 k = d.get("kernels", d.get("per_kernel", {}))
-print(f"{sys.argv[1]:>6}: {d['value']:.1f} regions/s  step {d['ms_per_step']:.2f} ms  mlp {d['roofline']['avg_launch_us']:.1f} us ({d['roofline']['frac']:.4f})  attn unit {d['roofline_attention_unit']['frac']:.4f}  abmil {d['roofline_abmil']['frac']:.4f}  {d['selfcheck']}")
+au = d['roofline_attention_unit']
+print(f"{sys.argv[1]:>6}: {d['value']:.1f} regions/s  step {d['ms_per_step']:.2f} ms  mlp {d['roofline']['avg_launch_us']:.1f} us ({d['roofline']['frac']:.4f})  attn unit {au['frac']:.4f} ({au['us_per_launch_set']:.0f} us, [CLS] side {au.get('cls_rows_us_per_block', 0):.1f} us)  abmil {d['roofline_abmil']['frac']:.4f}  {d['selfcheck']}")
 PY
   done
 done
