@@ -156,9 +156,10 @@ def pmc_traffic(cat, with_source=False):
     pdir = os.path.join(ROOT, "profiles")
     for f in sorted([p for p in os.listdir(pdir) if p.endswith("_traffic.json")], reverse=True) if os.path.isdir(pdir) else []:
         t = json.load(open(os.path.join(pdir, f)))
+        meta = t.get("_meta") or {}
         for k in TRAFFIC_KEYS.get(cat, []):
             for name, v in t.items():
-                if name.startswith(k) or k in name:
+                if name != "_meta" and (name.startswith(k) or k in name):
                     if not with_source:
                         return v["hbm_bytes"]
                     commit = None
@@ -168,7 +169,7 @@ def pmc_traffic(cat, with_source=False):
                                                 capture_output=True, text=True, timeout=10).stdout.strip() or None
                     except Exception:
                         pass
-                    return v["hbm_bytes"], {"file": "profiles/" + f, "kernel": name, "commit": commit,
+                    return v["hbm_bytes"], {"file": "profiles/" + f, "kernel": name, "commit": commit or meta.get("measured_at_commit"),
                                             "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command (tools/run_profile.sh), per launch"}
     return (None, None) if with_source else None
 

@@ -82,5 +82,13 @@ if agg:
             traffic[k] = {"fetch_bytes": med_big(d["FETCH_SIZE"]) * 1024 * 2, "write_bytes": med_big(d["WRITE_SIZE"]) * 1024,
                           "note": "per launch (upper-quartile launch = ViT-256 shape); FETCH_SIZE doubled per MI355X_MICROARCH.md"}
             traffic[k]["hbm_bytes"] = traffic[k]["fetch_bytes"] + traffic[k]["write_bytes"]
+    # the commit whose library these counters were taken on (bench.py quotes it as roofline.traffic_source: the GPU box has no .git)
+    try:
+        import subprocess
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+    except Exception:
+        head = ""
+    traffic["_meta"] = {"tag": tag, "measured_at_commit": head or None,
+                        "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 3 --warmup 1 --streams 1` (tools/run_profile.sh)"}
     json.dump(traffic, open(os.path.join(OUT, f"{tag}_traffic.json"), "w"), indent=1)
     print("wrote", f"profiles/{tag}_pmc.csv, profiles/{tag}_traffic.json", len(traffic), "kernels with traffic")
