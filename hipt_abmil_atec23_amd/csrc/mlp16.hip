@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
     // requests unit c + 2 into that slot and its closing wait is vmcnt(12): a unit has a whole phase more to land.
     // (DBG 128, tools/mlp_probe.hip: the old protocol)
     constexpr bool RING2 = (DBG & 128) == 0;
+    constexpr bool SGB = (DBG & 256) == 0;  // (DBG 256: hipcc's own instruction order inside the GELU groups)
     // DBG 64 (tools/mlp_probe.hip): WITH the L2 prefetch of the next tile's rows (prefetch_rows below).  Measured, interleaved on one
     // box at 8 regions: 1 419-1 432 us with it, 1 384-1 388 without -- the row phase falls from 13.5 to 9 us per tile, the chunk phases
     // take 6 k more cycles and the chip gives the saved idle time back as clock (1.63 instead of 1.73 GHz): off.
@@ -374,6 +375,25 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
                 if constexpr (needb < 0 && PF && gg == (RING2 ? 6 : 5)) prefetch_rows(row0_next, nrows_next);
                 if constexpr (gh >= 0 && gg >= 4) {
                     gelu_unit(std::integral_constant<int, (gh >= 0 ? gh : 0)>{}, std::integral_constant<int, 8 * gsec + gg - 4>{});
+                    // The wave issues in order: a 16x16x32 MFMA holds the issue port 8 of its 16 cycles, so two or three single-issue
+                    // instructions fit behind each one for free -- but hipcc's own order for this group is MFMA, MFMA, twelve GELU
+                    // instructions in a row (the matrix pipe idle under them), ..., three MFMAs back to back (the wave stalled on the
+                    // pipe): the counters show it (38 % of the wave cycles in issue stalls beside 44 % matrix-pipe occupancy).
+                    // Dealt out instead: one MFMA, three vector instructions (transcendentals included), eight times.
+                    if constexpr (SGB) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x402, 3, 0);
+                        }
+                    }
+                }
+                if constexpr (SGB && !(gh >= 0 && gg >= 4) && RING2 && gg <= 5) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
