@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
     // requests unit c + 2 into that slot and its closing wait is vmcnt(12): a unit has a whole phase more to land.
     // (DBG 128, tools/mlp_probe.hip: the old protocol)
     constexpr bool RING2 = (DBG & 128) == 0;
+    constexpr bool SGB = (DBG & 256) == 0;  // (DBG 256: hipcc's own instruction order inside the groups)
     // DBG 64 (tools/mlp_probe.hip): WITH the L2 prefetch of the next tile's rows (prefetch_rows below).  Measured, interleaved on one
     // box at 8 regions: 1 419-1 432 us with it, 1 384-1 388 without -- the row phase falls from 13.5 to 9 us per tile, the chunk phases
     // take 6 k more cycles and the chip gives the saved idle time back as clock (1.63 instead of 1.73 GHz): off.
@@ -395,6 +396,21 @@ __global__ __launch_bounds__(256, 1) void mlp32_kernel(const MlpParams p) {
                 if constexpr (needb < 0 && PF && gg == (RING2 ? 6 : 5)) prefetch_rows(row0_next, nrows_next);
                 if constexpr (gh >= 0 && gg >= 4) {
                     gelu_unit(std::integral_constant<int, (gh >= 0 ? gh : 0)>{}, std::integral_constant<int, 8 * gsec + gg - 4>{});
+                    // (instruction order dealt out by hand, as in mlp16.hip: a 32x32x16 MFMA holds the issue port 8 of its 32 cycles -- five
+                    //  or six single-issue instructions fit behind each; hipcc's own order bunches the GELU behind two MFMAs)
+                    if constexpr (SGB) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
+                        }
+                    }
+                } else if constexpr (SGB && RING2 && gg <= 5) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });

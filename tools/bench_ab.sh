@@ -1,13 +1,15 @@
 #!/bin/bash
 # Same-box A/B of whole library builds through bench.py itself (the probe's back-to-back launches sit in a power transient that the
-# pipeline does not): tools/bench_ab.sh <rounds> <lib suffix> ... ("" = the shipped library), interleaved; prints regions/s and the
+# pipeline does not): tools/bench_ab.sh <rounds> <lib suffix> ... ("-" = the shipped library; NAME=VALUE = the shipped library under that environment switch, e.g. HIPT_MLP32=1), interleaved; prints regions/s and the
 # per-launch time of the fused MLP / fused attention kernels.
 R=$1; shift
 for r in $(seq 1 $R); do
   for v in "$@"; do
     lib=hipt_abmil_atec23_amd/libhipt_abmil${v:+_$v}.so
     [ "$v" = "-" ] && lib=hipt_abmil_atec23_amd/libhipt_abmil.so
-    HIPT_AMD_LIB=$PWD/$lib python bench.py --no-cpu-baseline --no-extras --slides 0 > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err || { echo "$v FAILED"; tail -3 gpurun_out/ab_tmp.err; continue; }
+    ev=""
+    case "$v" in *=*) ev="$v"; lib=hipt_abmil_atec23_amd/libhipt_abmil.so;; esac   # NAME=VALUE: the shipped library under that environment
+    env $ev HIPT_AMD_LIB=$PWD/$lib python bench.py --no-cpu-baseline --no-extras --slides 0 > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err || { echo "$v FAILED"; tail -3 gpurun_out/ab_tmp.err; continue; }
     python - "$v" <<PY
 import json, sys
 d = json.loads(open("gpurun_out/ab_tmp.json").read().strip().splitlines()[-1])
