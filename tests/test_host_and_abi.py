@@ -84,6 +84,28 @@ def test_integration_md_binding_is_the_current_abi():
     assert callable(ns["clam_sb_forward"])
 
 
+def test_integration_md_names_only_switches_the_code_reads():
+    """INTEGRATION.md section 6 lists the environment switches: each one must be read somewhere in the package (C or Python), and
+    every switch the library reads (csrc/common.h's hipt_env_on calls) must be listed -- the table was two rounds stale once."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 6. Environment switches"):]
+    listed = set(re.findall(r"`(HIPT_[A-Z0-9_]+)(?:=[^`]*)?`", sec.split("\n## ")[0]))
+    src = ""
+    pkg = os.path.join(ROOT, "hipt_abmil_atec23_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if os.sep + "build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src += open(os.path.join(dirpath, f)).read()
+    read_by_lib = set(re.findall(r'hipt_env_on\("(HIPT_[A-Z0-9_]+)"\)', src)) | set(re.findall(r'getenv\("(HIPT_[A-Z0-9_]+)"\)', src)) | \
+        set(re.findall(r'environ(?:\.get)?\(?\[?"(HIPT_[A-Z0-9_]+)"', src))
+    missing_in_code = sorted(v for v in listed if v not in src)
+    assert not missing_in_code, f"INTEGRATION.md lists switches nothing reads: {missing_in_code}"
+    unlisted = sorted(v for v in read_by_lib if v not in listed)
+    assert not unlisted, f"switches read by the code but missing from INTEGRATION.md section 6: {unlisted}"
+
+
 def test_asm_read_audit_is_clean_and_part_of_the_build():
     """Every hot kernel relies on inline-asm loads whose destinations hipcc must not touch before a hand-counted wait (a hit is a
     wrong result or a GPU memory fault).  The Makefile audits the .s of every object as it is built and refuses to link on a hit;
