@@ -130,12 +130,20 @@ int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* 
 // that runs block b1 itself (the [CLS]-pruned last block); *have_xn tells it whether that happened
 // img_ok / x_img_out: the caller owns x and accepts it back as an fp32 activation image (kernels.h): blocks after the
 // first then exchange y1 / xn / x as images (coalesced row phases); *x_img_out tells whether x came back as one
+// at most four 272-row sequences: what gemm.hip's small-M kernel takes (HIPT_GENERIC keeps its meaning: the generic kernels either way)
+static bool small_call(const hipt_vit_weights* w, int nseq) { return (int64_t)nseq * w->ntok <= 1088; }
+
 int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, float* probs, const BlockScratch& s,
                hipStream_t st, bool emit_last = false, bool* have_xn_out = nullptr, bool img_ok = false, bool* x_img_out = nullptr) {
     const int D = w->dim, M = nseq * w->ntok, dt = w->dtype, dh = D / w->heads;
     const float scale = attn_scale(w);
     int rc;
-    const bool seq = hipt_seqgemm_supported(dt, D) && hipt_mlp_supported(dt, D, w->hidden);
+    // A call of a few hundred rows (ONE 256 x 256 patch: 257; the second-level ViT of one region: 257) is latency, not throughput: the
+    // A-stationary kernels would put it on two 192-row tiles, the fused MLP on seventeen 16-row tiles that each stream the whole weight
+    // image (55 us a block).  Such calls take the per-operator path below, whose Linears run on the small-M GEMM (gemm.hip: a wave per
+    // 16 x 32 output tile, 51-204 workgroups): seven launches of a few microseconds per block.
+    const bool small = small_call(w, nseq);
+    const bool seq = hipt_seqgemm_supported(dt, D) && hipt_mlp_supported(dt, D, w->hidden) && !small;
     // timing categories: the kernels of the small second-level ViT (D = 192, a few hundred rows) are booked together,
     // so that the per-kernel categories hold only the ViT-256 launches the roofline is computed on
     const bool big = D >= 384;
@@ -701,7 +709,7 @@ static int vit256_range_impl(const hipt_vit_weights* w, const void* img, const h
         } else if ((rc = embed256(w, img, lay, seq0 + s0, n, x, st))) {
             return rc;
         }
-        if (can_prune_last(w)) {
+        if (can_prune_last(w) && !small_call(w, n)) {
             float* xc = (float*)((char*)s.hid + 4096);  // (the hidden-tensor slot is free on this path; its head holds tile queues)
             bool have_xn = false, x_img = false;  // (x is this function's own buffer: it may come back as an activation image)
             if ((rc = run_blocks(w, x, n, 0, w->depth - 1, nullptr, s, st, true, &have_xn, true, &x_img))) return rc;

@@ -409,12 +409,13 @@ def test_vit256_patch_embedding_from_fp32_pixels(vit256, monkeypatch):
     generic path (HIPT_GENERIC=1) makes a bf16 copy of the image and runs the generic GEMM over an im2col view.  Same bf16
     products, another summation order: the tokens agree with an fp64 Conv2d on the bf16-rounded operands to 1e-4 on both paths,
     also for a batch that is not a whole region and for a sub-batch (bitwise: a token's result does not depend on its
-    neighbours)."""
+    neighbours; the sub-batch has 5 patches = 1285 rows so that both calls are on the streaming side of capi.hip's small_call()
+    threshold of 1088 rows -- calls below it run the per-operator kernels, same values to the bf16 bar, other bits)."""
     x = synth.hash_uniform_torch((7, 3, 256, 256), 31, device=DEV)
     vit256.set_compute_dtype("bf16")
     try:
         fused = vit256(x)
-        fused_sub = vit256(x[2:5])
+        fused_sub = vit256(x[2:7])
         tok = vit256.prepare_tokens(x)
         monkeypatch.setenv("HIPT_GENERIC", "1")
         tok_plain = vit256.prepare_tokens(x)
@@ -429,7 +430,26 @@ def test_vit256_patch_embedding_from_fp32_pixels(vit256, monkeypatch):
     print(f"fused patch embedding: tokens vs fp64 Conv2d: max |err| {e_new:.2e} (generic path {e_old:.2e})")
     assert e_new < 1e-4 and e_old < 1e-4
     assert torch.equal(tok[:, 0], tok_plain[:, 0])
-    assert torch.equal(fused[2:5], fused_sub)
+    assert torch.equal(fused[2:7], fused_sub)
+
+
+def test_vit256_small_calls_agree_with_large_ones(vit256):
+    """Calls of at most 1088 token rows (4 patches; capi.hip small_call()) run the per-operator kernels with the Linears on the
+    wave-per-tile GEMM instead of the streaming kernels, whose fixed set-up costs more than such a call's work: the same features
+    as the same patches inside a 7-patch call -- to 1e-4 in fp32, to the bf16 bar in bf16 -- and identical bits between two small
+    calls that hold the same patch (rows do not meet on this path either)."""
+    x = synth.hash_uniform_torch((7, 3, 256, 256), 41, device=DEV)
+    for dt, bar in (("fp32", None), ("bf16", 1.3e-2)):
+        vit256.set_compute_dtype(dt)
+        try:
+            big, small, one = vit256(x), vit256(x[2:5]), vit256(x[3:4])
+        finally:
+            vit256.set_compute_dtype("fp32")
+        if bar is None:
+            assert float((big[2:5] - small).abs().max()) < 1e-4
+        else:
+            assert float((big[2:5] - small).norm() / big[2:5].norm()) < bar
+        assert torch.equal(small[1:2], one), dt
 
 
 def test_hipt4k_patch_embedding_addresses_regions(hipt, monkeypatch):
