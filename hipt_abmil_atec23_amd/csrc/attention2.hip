@@ -175,10 +175,13 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const bf16_t* __restrict
     // registers are free then, and the softmax / PV that follow hide the latency).
     // (257 tokens are 17 tiles: one wave of the four has five.  Which one rotates with the workgroup, so that the two workgroups
     //  sharing a CU do not both load the same SIMD.)
-    int qt = (wave + blockIdx.x) & 3;
+    // (gridDim.y > 1, calls of a few sequences: the query tiles are also dealt over gridDim.y workgroups, each staging K and V for
+    //  itself -- 6 workgroups would leave 250 CUs idle for 12 us; a query row's arithmetic is the same wherever it runs)
+    const int QS = 4 * gridDim.y;
+    int qt = ((wave + blockIdx.x) & 3) + 4 * blockIdx.y;
     u32x4 qf[2][2];
     if (qt < nqt) load_q(qbase, tokstride, ntok, qt, li, g, qf[0]);
-    if (qt + 4 < nqt) load_q(qbase, tokstride, ntok, qt + 4, li, g, qf[1]);
+    if (qt + QS < nqt) load_q(qbase, tokstride, ntok, qt + QS, li, g, qf[1]);
 
     // ---- stage K and V by LDS-DMA: piece = 8 LDS rows (1 KiB); lane i fills row 8 piece + i/8, physical chunk i%8 ----
     {
@@ -199,12 +202,12 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const bf16_t* __restrict
 
     bf16_t* obase = out_img ? out : out + (int64_t)b * ntok * D + h * DH;
     const int64_t oimg = out_img ? (int64_t)b * ntok : -1;
-    for (; qt + 4 < nqt; qt += 8) {
+    for (; qt + QS < nqt; qt += 2 * QS) {
         f32x4 s[2][NKT];
         scores<2, NKS>(qf, Ks, li, g, s);
-        if (qt + 8 < nqt) load_q(qbase, tokstride, ntok, qt + 8, li, g, qf[0]);
-        if (qt + 12 < nqt) load_q(qbase, tokstride, ntok, qt + 12, li, g, qf[1]);
-        finish<2, NKS>(s, obase, Vs, D, ntok, sl2e, qt, qt + 4, li, g, oimg, h);
+        if (qt + 2 * QS < nqt) load_q(qbase, tokstride, ntok, qt + 2 * QS, li, g, qf[0]);
+        if (qt + 3 * QS < nqt) load_q(qbase, tokstride, ntok, qt + 3 * QS, li, g, qf[1]);
+        finish<2, NKS>(s, obase, Vs, D, ntok, sl2e, qt, qt + QS, li, g, oimg, h);
     }
     if (qt < nqt) {
         f32x4 s[1][NKT];
@@ -232,7 +235,8 @@ int hipt_attention64_launch(const void* qkv, void* out, int B, int ntok, int hea
         }
         once.done[dev] = true;
     }
-    hipLaunchKernelGGL(ntok <= ROWS - 16 ? attn64_kernel<NKT - 1> : attn64_kernel<NKT>, dim3(B * heads), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, ntok, heads,
+    const int qsplit = B * heads <= 48 ? (((ntok + 15) >> 4) + 3) / 4 : 1;  // few sequences: one query tile per wave
+    hipLaunchKernelGGL(ntok <= ROWS - 16 ? attn64_kernel<NKT - 1> : attn64_kernel<NKT>, dim3(B * heads, qsplit), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, ntok, heads,
                        scale * 1.4426950408889634f, out_img, qkv_hm);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;

@@ -108,7 +108,8 @@ BlockScratch carve_blocks(Carver& c, const hipt_vit_weights* w, int nseq) {
 }
 
 int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, void* out,
-           int64_t ldc, int M, int N, int K, int dtype, int flags, hipStream_t st, int rpt = 0) {
+           int64_t ldc, int M, int N, int K, int dtype, int flags, hipStream_t st, int rpt = 0, const float* ln_w = nullptr,
+           const float* ln_b = nullptr, float ln_eps = 0.f) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A;
@@ -123,6 +124,9 @@ int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* 
     p.out = out;
     p.ldc = ldc;
     p.rpt = rpt;
+    p.ln_w = ln_w;  // (set: A is the fp32 residual rows and the GEMM normalises them itself -- small calls, gemm.hip)
+    p.ln_b = ln_b;
+    p.ln_eps = ln_eps;
     return hipt_gemm_launch(p, dtype, ALOAD_PLAIN, flags, st);
 }
 
@@ -227,13 +231,24 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             PROF(cMLP, hipt_mlp_launch(m, st));
             continue;
         } else {
-            PROF(PC_LN, hipt_layernorm_launch(x, D, b.ln1_w, b.ln1_b, s.xn, dt, D, M, D, w->ln_eps, st));
-            PROF(PC_QKV, linear(s.xn, D, b.qkv_w, D, b.qkv_b, nullptr, s.qkv, 3 * D, M, 3 * D, D, dt, 0, st, w->ntok));
+            // (small calls: both LayerNorms run in the prologue of the GEMM that consumes them -- five launches a block instead of seven)
+            const bool ln_in_gemm = small && !hipt_generic_only() && hipt_gemm_ln_supported(M, D, ALOAD_PLAIN, 0);
+            if (ln_in_gemm) {
+                PROF(PC_QKV, linear(x, D, b.qkv_w, D, b.qkv_b, nullptr, s.qkv, 3 * D, M, 3 * D, D, dt, 0, st, w->ntok, b.ln1_w, b.ln1_b, w->ln_eps));
+            } else {
+                PROF(PC_LN, hipt_layernorm_launch(x, D, b.ln1_w, b.ln1_b, s.xn, dt, D, M, D, w->ln_eps, st));
+                PROF(PC_QKV, linear(s.xn, D, b.qkv_w, D, b.qkv_b, nullptr, s.qkv, 3 * D, M, 3 * D, D, dt, 0, st, w->ntok));
+            }
             PROF(PC_ATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st));
             if (last_probs) break;  // Block.forward(return_attention=True) returns before the residual (:148-149)
             PROF(PC_PROJ, linear(s.att, D, b.proj_w, D, b.proj_b, x, x, D, M, D, D, dt, HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st, w->ntok));
-            PROF(PC_LN, hipt_layernorm_launch(x, D, b.ln2_w, b.ln2_b, s.xn, dt, D, M, D, w->ln_eps, st));
-            PROF(PC_FC1, linear(s.xn, D, b.fc1_w, D, b.fc1_b, nullptr, s.hid, w->hidden, M, w->hidden, D, dt, HIPT_EPI_GELU, st, w->ntok));
+            if (ln_in_gemm) {
+                PROF(PC_FC1, linear(x, D, b.fc1_w, D, b.fc1_b, nullptr, s.hid, w->hidden, M, w->hidden, D, dt, HIPT_EPI_GELU, st, w->ntok, b.ln2_w, b.ln2_b,
+                                    w->ln_eps));
+            } else {
+                PROF(PC_LN, hipt_layernorm_launch(x, D, b.ln2_w, b.ln2_b, s.xn, dt, D, M, D, w->ln_eps, st));
+                PROF(PC_FC1, linear(s.xn, D, b.fc1_w, D, b.fc1_b, nullptr, s.hid, w->hidden, M, w->hidden, D, dt, HIPT_EPI_GELU, st, w->ntok));
+            }
         }
         PROF(PC_FC2, linear(s.hid, w->hidden, b.fc2_w, w->hidden, b.fc2_b, x, x, D, M, D, w->hidden, dt,
                             HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st, w->ntok));

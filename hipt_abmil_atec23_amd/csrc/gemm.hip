@@ -201,8 +201,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
 // not depend on what else is in the call); a 4-wave workgroup covers 16 rows x 128 columns: ceil(M / 16) x ceil(N / 128)
 // workgroups -- 51 to 204 for ViT-256's Linears at 257 rows.
 constexpr int SMALL_M = 1088;  // at most four 272-row sequences take this kernel
+constexpr int SMALL_RING = 6;  // k-steps of operands in flight per wave (6 divides the step count of every ViT Linear)
 
-template <typename T, int FLAGS>
+template <typename T, int FLAGS, bool EVEN>
 __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, g = lane >> 4;
@@ -222,17 +223,168 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const int nk = p.K / KC;
-    // operands of step k + 1 are requested before the products of step k are issued
-    u32x4 a = *(const u32x4*)ap, w0 = *(const u32x4*)wp[0], w1 = *(const u32x4*)wp[1];
-    for (int k = 0; k < nk; ++k) {
-        const int kn = (k + 1 < nk ? k + 1 : k) * KC;
-        const u32x4 an = *(const u32x4*)(ap + kn), w0n = *(const u32x4*)(wp[0] + kn), w1n = *(const u32x4*)(wp[1] + kn);
-        Tr<T>::mma16(acc[0], w0, a);
-        Tr<T>::mma16(acc[1], w1, a);
-        a = an;
-        w0 = w0n;
-        w1 = w1n;
+    // a ring of RING k-steps of operands in registers: a step's products are issued RING - 1 requests behind its loads, so that
+    // the L2 round trip is paid once per RING steps instead of once per step (fc2's K = 1536 is 48 steps in bf16).
+    constexpr int RING = SMALL_RING;
+    u32x4 a[RING], w0[RING], w1[RING];
+    if constexpr (EVEN) {
+        // nk a multiple of RING (every Linear of the two ViTs: K = 192 .. 1536): no guards in the loop, so that hipcc counts the
+        // loads in flight instead of draining them at every conditional.  The walk over k starts at a step that depends on the
+        // COLUMN tile (and wraps): all waves start together, and with a row pitch of 3072 B (K = 1536 in bf16) the 16 rows of a
+        // request fall on 4 of the 16 L2 channels at any one k -- staggered starts spread the waves of a row tile over all of
+        // them.  The summation order of an output element depends on its column only, not on which rows share the call.
+        const int rot = ((n0 >> 5) * 4) % nk;
+        auto koff = [&](int j) {
+            int kk = rot + j;
+            kk = kk >= nk ? kk - nk : kk;
+            return kk * KC;
+        };
+#pragma unroll
+        for (int d = 0; d < RING; ++d) {
+            const int kn = koff(d);
+            a[d] = *(const u32x4*)(ap + kn), w0[d] = *(const u32x4*)(wp[0] + kn), w1[d] = *(const u32x4*)(wp[1] + kn);
+        }
+        for (int k = 0; k + RING < nk; k += RING) {
+#pragma unroll
+            for (int d = 0; d < RING; ++d) {
+                Tr<T>::mma16(acc[0], w0[d], a[d]);
+                Tr<T>::mma16(acc[1], w1[d], a[d]);
+                const int kn = koff(k + d + RING);
+                a[d] = *(const u32x4*)(ap + kn), w0[d] = *(const u32x4*)(wp[0] + kn), w1[d] = *(const u32x4*)(wp[1] + kn);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < RING; ++d) {
+            Tr<T>::mma16(acc[0], w0[d], a[d]);
+            Tr<T>::mma16(acc[1], w1[d], a[d]);
+        }
+    } else {  // any K that is a multiple of KC: k ascending, guarded ring
+#pragma unroll
+        for (int d = 0; d < RING; ++d) {
+            const int kn = (d < nk ? d : nk - 1) * KC;
+            a[d] = *(const u32x4*)(ap + kn), w0[d] = *(const u32x4*)(wp[0] + kn), w1[d] = *(const u32x4*)(wp[1] + kn);
+        }
+        for (int k = 0; k < nk; k += RING) {
+#pragma unroll
+            for (int d = 0; d < RING; ++d) {
+                if (k + d < nk) {
+                    Tr<T>::mma16(acc[0], w0[d], a[d]);
+                    Tr<T>::mma16(acc[1], w1[d], a[d]);
+                }
+                if (k + d + RING < nk) {
+                    const int kn = (k + d + RING) * KC;
+                    a[d] = *(const u32x4*)(ap + kn), w0[d] = *(const u32x4*)(wp[0] + kn), w1[d] = *(const u32x4*)(wp[1] + kn);
+                }
+            }
+        }
     }
+    if (row0 + li >= p.M) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + j * 16 + 4 * g;
+        if (n < p.N) epilogue<T, FLAGS>(p, row0 + li, n, acc[j]);
+    }
+}
+
+// The same kernel with LayerNorm in its prologue (GemmParams::ln_w set; A = the fp32 residual rows, K = 384 or 192): the lane that
+// supplies chunk g of row `li` to every k-step holds exactly that row's columns 4 EPC s + EPC g + (0..EPC-1) -- a quarter of the
+// row, K / 4 values; the other three quarters sit in lanes li + 16, + 32, + 48.  Row statistics are therefore a sum over the lane's
+// own values and two cross-lane steps (two-pass, like misc.hip's ln_kernel), and the normalised row never leaves the registers: it
+// is rounded to T straight into the MFMA operands of all k-steps.  Every wave of a row tile repeats the statistics of its 16 rows
+// (N / 32 times 24 KiB out of L2 at K = 384): a small call is bound by its chain of launches, not by L2 bytes, and this removes
+// two launches of the seven a block has.
+template <typename T, int FLAGS, int K>
+__global__ __launch_bounds__(256) void lngemm_small_kernel(const GemmParams p) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int row0 = (blockIdx.x / tiles_n) * 16, n0 = (blockIdx.x % tiles_n) * BN + wave * 32;
+    // (a wave past the last column tile stays: it carries its share of gamma | beta to LDS and meets the barrier; its loads are
+    //  clamped to the last weight row and it stores nothing)
+    constexpr int EPC = Tr<T>::EPC, KC = 4 * EPC, NKMAX = K / KC, nk = NKMAX;  // (K is a template parameter: no guard, every load in one flight)
+    int r = row0 + li;
+    r = r < p.M ? r : p.M - 1;
+    const float* ap = (const float*)p.A + (int64_t)r * p.lda + g * EPC;
+    const T* wp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int n = n0 + j * 16 + li;
+        n = n < p.N ? n : p.N - 1;
+        wp[j] = (const T*)p.W + (int64_t)n * p.ldw + g * EPC;
+    }
+    // one flight of requests: the weights of the first RING k-steps, gamma | beta on their way to LDS (the four waves share them),
+    // the wave's 16 rows.  (sched_barrier: hipcc otherwise sinks each load to its first use and waits there, one round trip each.)
+    constexpr int RING = nk < 12 ? nk : 12;
+    __shared__ __attribute__((aligned(16))) float gb[2][K];
+    u32x4 w0[RING], w1[RING];
+#pragma unroll
+    for (int d = 0; d < RING; ++d) w0[d] = *(const u32x4*)(wp[0] + d * KC), w1[d] = *(const u32x4*)(wp[1] + d * KC);
+    f32x4 gbv;
+    const int gi = threadIdx.x < K / 4 ? threadIdx.x : threadIdx.x - K / 4;  // threads [0, K/4): gamma, [K/4, K/2): beta
+    const bool gb_on = threadIdx.x < K / 2;
+    if (gb_on) gbv = *(const f32x4*)((threadIdx.x < K / 4 ? p.ln_w : p.ln_b) + 4 * gi);
+    float v[NKMAX][EPC];
+#pragma unroll
+    for (int s = 0; s < NKMAX; ++s) {
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) {
+            const f32x4 t = *(const f32x4*)(ap + s * KC + e);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[s][e + i] = t[i];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (gb_on) *(f32x4*)(&gb[threadIdx.x < K / 4 ? 0 : 1][4 * gi]) = gbv;
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < NKMAX; ++s)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) sum += v[s][e];
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum / (float)K;
+    float q = 0.f;
+#pragma unroll
+    for (int s = 0; s < NKMAX; ++s)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float c = v[s][e] - mean;
+            q += c * c;
+        }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)K + p.ln_eps);
+    __syncthreads();
+    u32x4 a[NKMAX];
+#pragma unroll
+    for (int s = 0; s < NKMAX; ++s) {
+        float o[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) {
+            const f32x4 gm = *(const f32x4*)(&gb[0][s * KC + g * EPC + e]), bt = *(const f32x4*)(&gb[1][s * KC + g * EPC + e]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[e + i] = (v[s][e + i] - mean) * rstd * gm[i] + bt[i];
+        }
+        if constexpr (EPC == 8) {
+            a[s][0] = pack_bf16x2(o[0], o[1]), a[s][1] = pack_bf16x2(o[2], o[3]);
+            a[s][2] = pack_bf16x2(o[4], o[5]), a[s][3] = pack_bf16x2(o[6], o[7]);
+        } else {
+            f32x4 t;
+            t[0] = o[0], t[1] = o[1], t[2] = o[2], t[3] = o[3];
+            a[s] = __builtin_bit_cast(u32x4, t);
+        }
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < NKMAX; ++s)
+        if (s < nk) {
+            Tr<T>::mma16(acc[0], w0[s % RING], a[s]);
+            Tr<T>::mma16(acc[1], w1[s % RING], a[s]);
+            if (s + RING < nk) {
+                const int kn = (s + RING) * KC;
+                w0[s % RING] = *(const u32x4*)(wp[0] + kn), w1[s % RING] = *(const u32x4*)(wp[1] + kn);
+            }
+        }
     if (row0 + li >= p.M) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -244,8 +396,22 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
 template <typename T, int ALOAD, int FLAGS>
 int launch(const GemmParams& p, hipStream_t st) {
     if constexpr (ALOAD == ALOAD_PLAIN) {
+        const dim3 sgrid(((p.M + 15) / 16) * ((p.N + BN - 1) / BN));
+        if (p.ln_w) {  // (checked by hipt_gemm_launch: small M, K = 384 or 192, the two plain epilogues)
+            if constexpr (FLAGS == 0 || FLAGS == HIPT_EPI_GELU) {
+                if (p.K == 384)
+                    hipLaunchKernelGGL((lngemm_small_kernel<T, FLAGS, 384>), sgrid, dim3(256), 0, st, p);
+                else
+                    hipLaunchKernelGGL((lngemm_small_kernel<T, FLAGS, 192>), sgrid, dim3(256), 0, st, p);
+                HIPT_CHECK_LAUNCH();
+                return HIPT_OK;
+            }
+        }
         if (p.M <= SMALL_M && p.K % (4 * Tr<T>::EPC) == 0) {
-            hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS>), dim3(((p.M + 15) / 16) * ((p.N + BN - 1) / BN)), dim3(256), 0, st, p);
+            if (p.K % (SMALL_RING * 4 * Tr<T>::EPC) == 0)
+                hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS, true>), sgrid, dim3(256), 0, st, p);
+            else
+                hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS, false>), sgrid, dim3(256), 0, st, p);
             HIPT_CHECK_LAUNCH();
             return HIPT_OK;
         }
@@ -286,6 +452,10 @@ int dispatch(const GemmParams& p, int aload, int flags, hipStream_t st) {
 
 }  // namespace
 
+bool hipt_gemm_ln_supported(int M, int K, int aload, int flags) {
+    return M <= SMALL_M && (K == 384 || K == 192) && aload == ALOAD_PLAIN && (flags == 0 || flags == HIPT_EPI_GELU);
+}
+
 int hipt_gemm_launch(const GemmParams& p_in, int dtype, int aload, int flags, hipStream_t st) {
     GemmParams p = p_in;
     const int kb = dtype == HIPT_F32 ? 32 : 64;
@@ -304,6 +474,10 @@ int hipt_gemm_launch(const GemmParams& p_in, int dtype, int aload, int flags, hi
                            (p.im.batch_stride * esz) % 16 == 0 && p.K == 768,
                        "gemm/im2col: image strides must be 16-byte multiples and K == 768");
     HIPT_CHECK_ARG((p.ldw * esz) % 16 == 0, "gemm: ldw rows must be 16-byte multiples");
+    if (p.ln_w)
+        HIPT_CHECK_ARG(hipt_gemm_ln_supported(p.M, p.K, aload, flags) && p.ln_b && (p.lda * 4) % 16 == 0 && ((uintptr_t)p.ln_w % 16) == 0 &&
+                           ((uintptr_t)p.ln_b % 16) == 0,
+                       "gemm: the LayerNorm prologue takes M <= %d fp32 rows of K = 384 or 192, plain loader, no or GELU epilogue", SMALL_M);
     if (dtype == HIPT_F32) return dispatch<float>(p, aload, flags, st);
     if (dtype == HIPT_BF16) return dispatch<bf16_t>(p, aload, flags, st);
     hipt_set_error("gemm: bad dtype %d", dtype);

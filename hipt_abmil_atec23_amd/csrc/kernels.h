@@ -25,8 +25,13 @@ struct GemmParams {
     // ALOAD_IM2COL
     hipt_image_layout im;
     int im_nty, im_ntx, im_seq0;
+    // LayerNorm prologue (small calls only, hipt_gemm_ln_supported): A is then the fp32 rows [M, K] whatever the compute dtype, and
+    // the product is taken with LayerNorm(A) rounded to the compute dtype -- what misc.hip's ln_kernel + this GEMM give in two launches
+    const float *ln_w, *ln_b;
+    float ln_eps;
 };
 
+bool hipt_gemm_ln_supported(int M, int K, int aload, int flags);
 int hipt_gemm_launch(const GemmParams& p, int dtype, int aload, int flags, hipStream_t st);
 
 // Patch embedding of ViT-256 straight from the fp32 image (embed32.hip): x[seq, 1 + t, :] = Conv2d_k16_s16(pixels) + bias + pos[1 + t]
