@@ -196,30 +196,37 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
 // ---- small M (a few hundred rows: ONE 256 x 256 patch through ViT-256 is 257, BASELINE configs[1]; the second-level ViT of a region;
 // the [CLS] rows of a launch) ----
 // The sequence-tiled kernel above puts such a problem on N / 128 workgroups -- 3 for the proj / fc2 Linears of ViT-256, 9 for QKV:
-// a fp32 one-patch forward spent 5.8 ms on nine CUs.  Here a WAVE owns one 16-row fragment x 32 output columns and streams both
-// operands straight from L2 (the whole problem is a few MB: no LDS, no barriers), k-step after k-step in order (a row's sum does
-// not depend on what else is in the call); a 4-wave workgroup covers 16 rows x 128 columns: ceil(M / 16) x ceil(N / 128)
-// workgroups -- 51 to 204 for ViT-256's Linears at 257 rows.
+// a fp32 one-patch forward spent 5.8 ms on nine CUs.  Here a one-WAVE workgroup owns one 16-row fragment x 32 output columns and
+// streams both operands straight from L2 (the whole problem is a few MB: no LDS, no barriers): ceil(M / 16) x ceil(N / 32)
+// workgroups -- 204 to 816 for ViT-256's Linears at 257 rows, a CU's vector-memory path per wave (four waves on one CU shared it:
+// fc2 took 18.5 us on 51 CUs, bound by the L1 fill rate).
+//   k order.  One mma16 consumes KC = 4 EPC k values, lane group g supplying one 16-byte chunk per operand row.  WHICH k values a
+// chunk holds is free as long as both operands agree, so a PAIR of steps covers 128 consecutive bytes of every row -- lane group g
+// owns bytes [32 g, 32 g + 32) of them, first half for the even step, second half for the odd one: the two requests of a pair touch
+// the same 16 (or 32) cache lines back to back.  (With 64 bytes of a row per step, the second half of each line was fetched again
+// a step later, after the ring's other requests had pushed it out of the 32 KiB L1.)
 constexpr int SMALL_M = 1088;  // at most four 272-row sequences take this kernel
 constexpr int SMALL_RING = 6;  // k-steps of operands in flight per wave (6 divides the step count of every ViT Linear)
 
+// element offset of step s inside an operand row, for the lane whose pointer already holds + 2 EPC g  (paired order, see above)
+template <int EPC> __device__ __forceinline__ constexpr int pair_off(int s) { return (s >> 1) * 8 * EPC + (s & 1) * EPC; }
+
 template <typename T, int FLAGS, bool EVEN>
-__global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+__global__ __launch_bounds__(64) void gemm_small_kernel(const GemmParams p) {
+    const int lane = threadIdx.x;
     const int li = lane & 15, g = lane >> 4;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int row0 = (blockIdx.x / tiles_n) * 16, n0 = (blockIdx.x % tiles_n) * BN + wave * 32;
-    if (n0 >= p.N) return;
-    constexpr int EPC = Tr<T>::EPC, KC = 4 * EPC;  // one mma16 call consumes KC k values: lane group g supplies its 16-byte chunk
+    const int tiles_n = (p.N + 31) / 32;
+    const int row0 = (blockIdx.x / tiles_n) * 16, n0 = (blockIdx.x % tiles_n) * 32;
+    constexpr int EPC = Tr<T>::EPC, KC = 4 * EPC;
     int r = row0 + li;
     r = r < p.M ? r : p.M - 1;                      // (padding rows re-read the last valid row: never stored)
-    const T* ap = (const T*)p.A + (int64_t)r * p.lda + g * EPC;
+    const T* ap = (const T*)p.A + (int64_t)r * p.lda + g * (EVEN ? 2 * EPC : EPC);
     const T* wp[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         int n = n0 + j * 16 + li;
         n = n < p.N ? n : p.N - 1;
-        wp[j] = (const T*)p.W + (int64_t)n * p.ldw + g * EPC;
+        wp[j] = (const T*)p.W + (int64_t)n * p.ldw + g * (EVEN ? 2 * EPC : EPC);
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const int nk = p.K / KC;
@@ -230,14 +237,14 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
     if constexpr (EVEN) {
         // nk a multiple of RING (every Linear of the two ViTs: K = 192 .. 1536): no guards in the loop, so that hipcc counts the
         // loads in flight instead of draining them at every conditional.  The walk over k starts at a step that depends on the
-        // COLUMN tile (and wraps): all waves start together, and with a row pitch of 3072 B (K = 1536 in bf16) the 16 rows of a
-        // request fall on 4 of the 16 L2 channels at any one k -- staggered starts spread the waves of a row tile over all of
-        // them.  The summation order of an output element depends on its column only, not on which rows share the call.
+        // COLUMN tile (and wraps): with a row pitch of 3072 B (K = 1536 in bf16) the 16 rows of a request fall on 4 of the 16 L2
+        // channels at any one k -- staggered starts spread the waves of a row tile over all of them.  The summation order of an
+        // output element depends on its column only, not on which rows share the call.
         const int rot = ((n0 >> 5) * 4) % nk;
         auto koff = [&](int j) {
             int kk = rot + j;
             kk = kk >= nk ? kk - nk : kk;
-            return kk * KC;
+            return pair_off<EPC>(kk);
         };
 #pragma unroll
         for (int d = 0; d < RING; ++d) {
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
             Tr<T>::mma16(acc[0], w0[d], a[d]);
             Tr<T>::mma16(acc[1], w1[d], a[d]);
         }
-    } else {  // any K that is a multiple of KC: k ascending, guarded ring
+    } else {  // any K that is a multiple of KC: k ascending in 64-byte steps, guarded ring
 #pragma unroll
         for (int d = 0; d < RING; ++d) {
             const int kn = (d < nk ? d : nk - 1) * KC;
@@ -287,57 +294,63 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
 }
 
 // The same kernel with LayerNorm in its prologue (GemmParams::ln_w set; A = the fp32 residual rows, K = 384 or 192): the lane that
-// supplies chunk g of row `li` to every k-step holds exactly that row's columns 4 EPC s + EPC g + (0..EPC-1) -- a quarter of the
-// row, K / 4 values; the other three quarters sit in lanes li + 16, + 32, + 48.  Row statistics are therefore a sum over the lane's
-// own values and two cross-lane steps (two-pass, like misc.hip's ln_kernel), and the normalised row never leaves the registers: it
-// is rounded to T straight into the MFMA operands of all k-steps.  Every wave of a row tile repeats the statistics of its 16 rows
-// (N / 32 times 24 KiB out of L2 at K = 384): a small call is bound by its chain of launches, not by L2 bytes, and this removes
-// two launches of the seven a block has.
+// supplies lane group g's chunks of row `li` holds, over all k-steps, exactly a quarter of that row -- K / 4 values, columns
+// 8 EPC m + 2 EPC g + (0 .. 2 EPC - 1) for every step pair m; the other three quarters sit in lanes li + 16, + 32, + 48.  Row
+// statistics are therefore a sum over the lane's own values and two cross-lane steps (two-pass, like misc.hip's ln_kernel), and
+// the normalised row never leaves the registers: it is rounded to T straight into the MFMA operands of all k-steps.  Every wave
+// of a row tile repeats the statistics of its 16 rows (N / 32 times 24 KiB out of L2 at K = 384): a small call is bound by its
+// chain of launches, not by L2 bytes, and this removes two launches of the seven a block has.
 template <typename T, int FLAGS, int K>
-__global__ __launch_bounds__(256) void lngemm_small_kernel(const GemmParams p) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+__global__ __launch_bounds__(64) void lngemm_small_kernel(const GemmParams p) {
+    const int lane = threadIdx.x;
     const int li = lane & 15, g = lane >> 4;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int row0 = (blockIdx.x / tiles_n) * 16, n0 = (blockIdx.x % tiles_n) * BN + wave * 32;
-    // (a wave past the last column tile stays: it carries its share of gamma | beta to LDS and meets the barrier; its loads are
-    //  clamped to the last weight row and it stores nothing)
-    constexpr int EPC = Tr<T>::EPC, KC = 4 * EPC, NKMAX = K / KC, nk = NKMAX;  // (K is a template parameter: no guard, every load in one flight)
+    const int tiles_n = (p.N + 31) / 32;
+    const int row0 = (blockIdx.x / tiles_n) * 16, n0 = (blockIdx.x % tiles_n) * 32;
+    constexpr int EPC = Tr<T>::EPC, KC = 4 * EPC, nk = K / KC;  // (K is a template parameter: no guard, every load in one flight)
+    static_assert(nk % 2 == 0 && (K / 2) % 4 == 0, "paired k order");
     int r = row0 + li;
     r = r < p.M ? r : p.M - 1;
-    const float* ap = (const float*)p.A + (int64_t)r * p.lda + g * EPC;
+    const float* ap = (const float*)p.A + (int64_t)r * p.lda + g * 2 * EPC;
     const T* wp[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         int n = n0 + j * 16 + li;
         n = n < p.N ? n : p.N - 1;
-        wp[j] = (const T*)p.W + (int64_t)n * p.ldw + g * EPC;
+        wp[j] = (const T*)p.W + (int64_t)n * p.ldw + g * 2 * EPC;
     }
-    // one flight of requests: the weights of the first RING k-steps, gamma | beta on their way to LDS (the four waves share them),
-    // the wave's 16 rows.  (sched_barrier: hipcc otherwise sinks each load to its first use and waits there, one round trip each.)
+    // one flight of requests: the weights of the first RING k-steps, gamma | beta on their way to LDS, the wave's 16 rows.
+    // (sched_barrier: hipcc otherwise sinks each load to its first use and waits there, one round trip each.)
     constexpr int RING = nk < 12 ? nk : 12;
-    __shared__ __attribute__((aligned(16))) float gb[2][K];
+    constexpr int GBN = (K / 2 + 63) / 64;  // float4 pieces of gamma | beta per lane
+    __shared__ __attribute__((aligned(16))) float gb[2 * K];
     u32x4 w0[RING], w1[RING];
 #pragma unroll
-    for (int d = 0; d < RING; ++d) w0[d] = *(const u32x4*)(wp[0] + d * KC), w1[d] = *(const u32x4*)(wp[1] + d * KC);
-    f32x4 gbv;
-    const int gi = threadIdx.x < K / 4 ? threadIdx.x : threadIdx.x - K / 4;  // threads [0, K/4): gamma, [K/4, K/2): beta
-    const bool gb_on = threadIdx.x < K / 2;
-    if (gb_on) gbv = *(const f32x4*)((threadIdx.x < K / 4 ? p.ln_w : p.ln_b) + 4 * gi);
-    float v[NKMAX][EPC];
+    for (int d = 0; d < RING; ++d) w0[d] = *(const u32x4*)(wp[0] + pair_off<EPC>(d)), w1[d] = *(const u32x4*)(wp[1] + pair_off<EPC>(d));
+    f32x4 gbv[GBN];
 #pragma unroll
-    for (int s = 0; s < NKMAX; ++s) {
+    for (int i = 0; i < GBN; ++i) {
+        const int idx = lane + 64 * i;  // piece idx of gamma (idx < K / 4) or beta
+        if (idx < K / 2) gbv[i] = *(const f32x4*)(idx < K / 4 ? p.ln_w + 4 * idx : p.ln_b + 4 * (idx - K / 4));
+    }
+    float v[nk][EPC];
+#pragma unroll
+    for (int s = 0; s < nk; ++s) {
 #pragma unroll
         for (int e = 0; e < EPC; e += 4) {
-            const f32x4 t = *(const f32x4*)(ap + s * KC + e);
+            const f32x4 t = *(const f32x4*)(ap + pair_off<EPC>(s) + e);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[s][e + i] = t[i];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (gb_on) *(f32x4*)(&gb[threadIdx.x < K / 4 ? 0 : 1][4 * gi]) = gbv;
+#pragma unroll
+    for (int i = 0; i < GBN; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < K / 2) *(f32x4*)(&gb[4 * idx]) = gbv[i];
+    }
     float sum = 0.f;
 #pragma unroll
-    for (int s = 0; s < NKMAX; ++s)
+    for (int s = 0; s < nk; ++s)
 #pragma unroll
         for (int e = 0; e < EPC; ++e) sum += v[s][e];
     sum += __shfl_xor(sum, 16, 64);
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(256) void lngemm_small_kernel(const GemmParams p) {
     const float mean = sum / (float)K;
     float q = 0.f;
 #pragma unroll
-    for (int s = 0; s < NKMAX; ++s)
+    for (int s = 0; s < nk; ++s)
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const float c = v[s][e] - mean;
@@ -354,14 +367,15 @@ __global__ __launch_bounds__(256) void lngemm_small_kernel(const GemmParams p) {
     q += __shfl_xor(q, 16, 64);
     q += __shfl_xor(q, 32, 64);
     const float rstd = 1.0f / sqrtf(q / (float)K + p.ln_eps);
-    __syncthreads();
-    u32x4 a[NKMAX];
+    __syncthreads();  // (one wave: orders the LDS writes above before the reads below)
+    u32x4 a[nk];
 #pragma unroll
-    for (int s = 0; s < NKMAX; ++s) {
+    for (int s = 0; s < nk; ++s) {
         float o[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; e += 4) {
-            const f32x4 gm = *(const f32x4*)(&gb[0][s * KC + g * EPC + e]), bt = *(const f32x4*)(&gb[1][s * KC + g * EPC + e]);
+            const int col = pair_off<EPC>(s) + g * 2 * EPC + e;
+            const f32x4 gm = *(const f32x4*)(&gb[col]), bt = *(const f32x4*)(&gb[K + col]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[e + i] = (v[s][e + i] - mean) * rstd * gm[i] + bt[i];
         }
@@ -376,15 +390,11 @@ __global__ __launch_bounds__(256) void lngemm_small_kernel(const GemmParams p) {
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int s = 0; s < NKMAX; ++s)
-        if (s < nk) {
-            Tr<T>::mma16(acc[0], w0[s % RING], a[s]);
-            Tr<T>::mma16(acc[1], w1[s % RING], a[s]);
-            if (s + RING < nk) {
-                const int kn = (s + RING) * KC;
-                w0[s % RING] = *(const u32x4*)(wp[0] + kn), w1[s % RING] = *(const u32x4*)(wp[1] + kn);
-            }
-        }
+    for (int s = 0; s < nk; ++s) {
+        Tr<T>::mma16(acc[0], w0[s % RING], a[s]);
+        Tr<T>::mma16(acc[1], w1[s % RING], a[s]);
+        if (s + RING < nk) w0[s % RING] = *(const u32x4*)(wp[0] + pair_off<EPC>(s + RING)), w1[s % RING] = *(const u32x4*)(wp[1] + pair_off<EPC>(s + RING));
+    }
     if (row0 + li >= p.M) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -396,22 +406,22 @@ __global__ __launch_bounds__(256) void lngemm_small_kernel(const GemmParams p) {
 template <typename T, int ALOAD, int FLAGS>
 int launch(const GemmParams& p, hipStream_t st) {
     if constexpr (ALOAD == ALOAD_PLAIN) {
-        const dim3 sgrid(((p.M + 15) / 16) * ((p.N + BN - 1) / BN));
+        const dim3 sgrid(((p.M + 15) / 16) * ((p.N + 31) / 32));
         if (p.ln_w) {  // (checked by hipt_gemm_launch: small M, K = 384 or 192, the two plain epilogues)
             if constexpr (FLAGS == 0 || FLAGS == HIPT_EPI_GELU) {
                 if (p.K == 384)
-                    hipLaunchKernelGGL((lngemm_small_kernel<T, FLAGS, 384>), sgrid, dim3(256), 0, st, p);
+                    hipLaunchKernelGGL((lngemm_small_kernel<T, FLAGS, 384>), sgrid, dim3(64), 0, st, p);
                 else
-                    hipLaunchKernelGGL((lngemm_small_kernel<T, FLAGS, 192>), sgrid, dim3(256), 0, st, p);
+                    hipLaunchKernelGGL((lngemm_small_kernel<T, FLAGS, 192>), sgrid, dim3(64), 0, st, p);
                 HIPT_CHECK_LAUNCH();
                 return HIPT_OK;
             }
         }
         if (p.M <= SMALL_M && p.K % (4 * Tr<T>::EPC) == 0) {
             if (p.K % (SMALL_RING * 4 * Tr<T>::EPC) == 0)
-                hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS, true>), sgrid, dim3(256), 0, st, p);
+                hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS, true>), sgrid, dim3(64), 0, st, p);
             else
-                hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS, false>), sgrid, dim3(256), 0, st, p);
+                hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS, false>), sgrid, dim3(64), 0, st, p);
             HIPT_CHECK_LAUNCH();
             return HIPT_OK;
         }
