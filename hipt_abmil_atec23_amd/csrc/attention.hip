@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const T* __restrict__ qkv,
 
     const int g = lane >> 4, li = lane & 15;
     const int nqt = (ntok + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    // (gridDim.y > 1, calls of a few sequences: the query tiles are dealt over gridDim.y workgroups as well, each staging K and V
+    //  for itself -- six workgroups per patch would leave 250 CUs idle; a query row's arithmetic is the same wherever it runs)
+    for (int qt = wave + 4 * blockIdx.y; qt < nqt; qt += 4 * gridDim.y) {
         // ---- Q fragments straight from global: row q, chunks g + 4*ks ----
         int q = qt * 16 + li;
         const bool qvalid = q < ntok;
@@ -197,7 +199,7 @@ int launch(const void* qkv, void* out, float* probs, int B, int ntok, int heads,
     using G = Geo<T, DH>;
     constexpr int lds = NKT * 16 * (G::RB + G::VRB);
     const float sl2e = scale * 1.4426950408889634f;
-    const dim3 grid(B * heads), block(256);
+    const dim3 grid(B * heads, B * heads <= 48 ? (((ntok + 15) >> 4) + 3) / 4 : 1), block(256);  // few sequences: one query tile per wave
     if (probs) {
         auto k = attn_kernel<T, DH, NKT, true>;
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
