@@ -106,7 +106,8 @@ def test_linear_fp32(M, Nn, K, mode):
     assert md(out, ref) < 2e-5
 
 
-@pytest.mark.parametrize("M,Nn,K", [(257, 576, 192), (1000, 1152, 384), (300, 384, 1536), (1500, 384, 1536), (2056, 1152, 384)])
+# ((100, 512, 1024): 32 k-steps, not a multiple of the small-M kernel's ring of six -- its guarded instantiation)
+@pytest.mark.parametrize("M,Nn,K", [(257, 576, 192), (1000, 1152, 384), (300, 384, 1536), (1500, 384, 1536), (2056, 1152, 384), (100, 512, 1024)])
 def test_linear_bf16(M, Nn, K):
     a = synth.hash_uniform_np((M, K), 41)
     w = synth.hash_uniform_np((Nn, K), 42, 0.05)
