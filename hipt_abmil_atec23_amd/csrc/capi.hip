@@ -109,7 +109,7 @@ BlockScratch carve_blocks(Carver& c, const hipt_vit_weights* w, int nseq) {
 
 int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, void* out,
            int64_t ldc, int M, int N, int K, int dtype, int flags, hipStream_t st, int rpt = 0, const float* ln_w = nullptr,
-           const float* ln_b = nullptr, float ln_eps = 0.f) {
+           const float* ln_b = nullptr, float ln_eps = 0.f, int a_row_step = 0) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A;
@@ -127,6 +127,7 @@ int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* 
     p.ln_w = ln_w;  // (set: A is the fp32 residual rows and the GEMM normalises them itself -- small calls, gemm.hip)
     p.ln_b = ln_b;
     p.ln_eps = ln_eps;
+    p.a_row_step = a_row_step;  // (> 0: A is a bf16 activation image and row r is its row r * a_row_step)
     return hipt_gemm_launch(p, dtype, ALOAD_PLAIN, flags, st);
 }
 
@@ -190,9 +191,14 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             if (fuse) {
                 char* qa = (char*)s.hid + 4096 + al256((size_t)nseq * D * 4);   // (the hidden slot is free on this path; its head holds tile queues)
                 char* qcls = qa + al256((size_t)nseq * D * 2);                   // [nseq, 3 D] bf16 + 1 KiB the kernel's row DMA may read past the end
-                PROF(PC_CLSROWS, hipt_gather_cls_bf16_launch(s.att, qa, nseq, w->ntok, D, st, 1));
-                // (nseq rows are a handful of the streaming kernel's 192-row tiles -- 11 CUs for 2 048 patches; the generic GEMM tiles N as well)
-                PROF(PC_CLSROWS, linear(qa, D, b.qkv_w, D, b.qkv_b, nullptr, qcls, 3 * D, nseq, 3 * D, D, dt, 0, st));
+                // (nseq rows are a handful of the streaming kernel's 192-row tiles -- 11 CUs for 2 048 patches; the generic GEMM tiles N as well.
+                //  Up to 1 088 sequences the small-M GEMM reads the [CLS] rows out of the image itself: one launch, not two)
+                if (!hipt_generic_only() && hipt_gemm_arows_supported(nseq, D, dt, ALOAD_PLAIN, 0)) {
+                    PROF(PC_CLSROWS, linear(s.att, D, b.qkv_w, D, b.qkv_b, nullptr, qcls, 3 * D, nseq, 3 * D, D, dt, 0, st, 0, nullptr, nullptr, 0.f, w->ntok));
+                } else {
+                    PROF(PC_CLSROWS, hipt_gather_cls_bf16_launch(s.att, qa, nseq, w->ntok, D, st, 1));
+                    PROF(PC_CLSROWS, linear(qa, D, b.qkv_w, D, b.qkv_b, nullptr, qcls, 3 * D, nseq, 3 * D, D, dt, 0, st));
+                }
                 PROF(PC_QKVATT, hipt_qkv_attn_launch(s.att, b.qkv_att_pk, b.qkv_b, qcls, s.qkv, nseq, scale, st));
                 att_out = s.qkv;
             } else if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue

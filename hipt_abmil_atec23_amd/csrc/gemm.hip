@@ -211,7 +211,12 @@ constexpr int SMALL_RING = 6;  // k-steps of operands in flight per wave (6 divi
 // element offset of step s inside an operand row, for the lane whose pointer already holds + 2 EPC g  (paired order, see above)
 template <int EPC> __device__ __forceinline__ constexpr int pair_off(int s) { return (s >> 1) * 8 * EPC + (s & 1) * EPC; }
 
-template <typename T, int FLAGS, bool EVEN>
+// AIMG (bf16, K = 384, EVEN): A is a bf16 activation image (kernels.h) and GEMM row r is image row r * p.a_row_step -- the [CLS] rows
+// of the sequences, read where the fused MLP left them (the side GEMM of the fused attention unit; a gather launch before it otherwise).
+// Eight consecutive columns from a multiple of 8 are 16 consecutive bytes of the image too: fragment (R >> 4) * 6144 elements, row R & 15
+// at + 8 (R & 15), chunk m = col / 8 at (m >> 2) * 512 + ((m >> 1) & 1) * 256 + (m & 1) * 128; in the paired k order chunk m of step s,
+// lane group g is 8 (s >> 1) + 2 g + (s & 1): step part (s >> 1) * 1024 + (s & 1) * 128, lane part (g >> 1) * 512 + (g & 1) * 256.
+template <typename T, int FLAGS, bool EVEN, bool AIMG = false>
 __global__ __launch_bounds__(64) void gemm_small_kernel(const GemmParams p) {
     const int lane = threadIdx.x;
     const int li = lane & 15, g = lane >> 4;
@@ -221,6 +226,10 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(const GemmParams p) {
     int r = row0 + li;
     r = r < p.M ? r : p.M - 1;                      // (padding rows re-read the last valid row: never stored)
     const T* ap = (const T*)p.A + (int64_t)r * p.lda + g * (EVEN ? 2 * EPC : EPC);
+    if constexpr (AIMG) {
+        const int64_t R = (int64_t)r * p.a_row_step;
+        ap = (const T*)p.A + (R >> 4) * (16 * 384) + (int)(R & 15) * 8 + (g >> 1) * 512 + (g & 1) * 256;
+    }
     const T* wp[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -241,23 +250,23 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(const GemmParams p) {
         // channels at any one k -- staggered starts spread the waves of a row tile over all of them.  The summation order of an
         // output element depends on its column only, not on which rows share the call.
         const int rot = ((n0 >> 5) * 4) % nk;
-        auto koff = [&](int j) {
+        auto kstep = [&](int j) {
             int kk = rot + j;
-            kk = kk >= nk ? kk - nk : kk;
-            return pair_off<EPC>(kk);
+            return kk >= nk ? kk - nk : kk;
         };
+        auto aoff = [&](int kk) { return AIMG ? (kk >> 1) * 1024 + (kk & 1) * 128 : pair_off<EPC>(kk); };
 #pragma unroll
         for (int d = 0; d < RING; ++d) {
-            const int kn = koff(d);
-            a[d] = *(const u32x4*)(ap + kn), w0[d] = *(const u32x4*)(wp[0] + kn), w1[d] = *(const u32x4*)(wp[1] + kn);
+            const int kk = kstep(d), kn = pair_off<EPC>(kk);
+            a[d] = *(const u32x4*)(ap + aoff(kk)), w0[d] = *(const u32x4*)(wp[0] + kn), w1[d] = *(const u32x4*)(wp[1] + kn);
         }
         for (int k = 0; k + RING < nk; k += RING) {
 #pragma unroll
             for (int d = 0; d < RING; ++d) {
                 Tr<T>::mma16(acc[0], w0[d], a[d]);
                 Tr<T>::mma16(acc[1], w1[d], a[d]);
-                const int kn = koff(k + d + RING);
-                a[d] = *(const u32x4*)(ap + kn), w0[d] = *(const u32x4*)(wp[0] + kn), w1[d] = *(const u32x4*)(wp[1] + kn);
+                const int kk = kstep(k + d + RING), kn = pair_off<EPC>(kk);
+                a[d] = *(const u32x4*)(ap + aoff(kk)), w0[d] = *(const u32x4*)(wp[0] + kn), w1[d] = *(const u32x4*)(wp[1] + kn);
             }
         }
 #pragma unroll
@@ -417,6 +426,13 @@ int launch(const GemmParams& p, hipStream_t st) {
                 return HIPT_OK;
             }
         }
+        if (p.a_row_step > 0) {  // (checked by hipt_gemm_launch: bf16, small M, K = 384, plain epilogue)
+            if constexpr (FLAGS == 0 && sizeof(T) == 2) {
+                hipLaunchKernelGGL((gemm_small_kernel<T, 0, true, true>), sgrid, dim3(64), 0, st, p);
+                HIPT_CHECK_LAUNCH();
+                return HIPT_OK;
+            }
+        }
         if (p.M <= SMALL_M && p.K % (4 * Tr<T>::EPC) == 0) {
             if (p.K % (SMALL_RING * 4 * Tr<T>::EPC) == 0)
                 hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS, true>), sgrid, dim3(64), 0, st, p);
@@ -462,6 +478,10 @@ int dispatch(const GemmParams& p, int aload, int flags, hipStream_t st) {
 
 }  // namespace
 
+bool hipt_gemm_arows_supported(int M, int K, int dtype, int aload, int flags) {
+    return dtype == HIPT_BF16 && M <= SMALL_M && K == 384 && aload == ALOAD_PLAIN && flags == 0;
+}
+
 bool hipt_gemm_ln_supported(int M, int K, int aload, int flags) {
     return M <= SMALL_M && (K == 384 || K == 192) && aload == ALOAD_PLAIN && (flags == 0 || flags == HIPT_EPI_GELU);
 }
@@ -484,6 +504,9 @@ int hipt_gemm_launch(const GemmParams& p_in, int dtype, int aload, int flags, hi
                            (p.im.batch_stride * esz) % 16 == 0 && p.K == 768,
                        "gemm/im2col: image strides must be 16-byte multiples and K == 768");
     HIPT_CHECK_ARG((p.ldw * esz) % 16 == 0, "gemm: ldw rows must be 16-byte multiples");
+    if (p.a_row_step > 0)
+        HIPT_CHECK_ARG(hipt_gemm_arows_supported(p.M, p.K, dtype, aload, flags) && !p.ln_w,
+                       "gemm: rows gathered from an activation image take bf16, M <= %d, K = 384, plain loader and epilogue", SMALL_M);
     if (p.ln_w)
         HIPT_CHECK_ARG(hipt_gemm_ln_supported(p.M, p.K, aload, flags) && p.ln_b && (p.lda * 4) % 16 == 0 && ((uintptr_t)p.ln_w % 16) == 0 &&
                            ((uintptr_t)p.ln_b % 16) == 0,

@@ -29,7 +29,11 @@ struct GemmParams {
     // the product is taken with LayerNorm(A) rounded to the compute dtype -- what misc.hip's ln_kernel + this GEMM give in two launches
     const float *ln_w, *ln_b;
     float ln_eps;
+    // rows gathered from an activation image (small calls only, hipt_gemm_arows_supported): A is a bf16 image [.., 384] and GEMM row r
+    // is image row r * a_row_step (the [CLS] rows of the sequences: a_row_step = tokens per sequence)
+    int a_row_step;
 };
+bool hipt_gemm_arows_supported(int M, int K, int dtype, int aload, int flags);
 
 bool hipt_gemm_ln_supported(int M, int K, int aload, int flags);
 int hipt_gemm_launch(const GemmParams& p, int dtype, int aload, int flags, hipStream_t st);
