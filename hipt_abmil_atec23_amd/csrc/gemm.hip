@@ -478,6 +478,9 @@ int dispatch(const GemmParams& p, int aload, int flags, hipStream_t st) {
 
 }  // namespace
 
+// (M: the sequence-tiled kernel's DMA could address the rows too -- built and measured -- but every one of its N / 128 column tiles then re-reads
+//  each row as 48 separate 16-byte pieces of as many cache lines: 34 us per block at 2 048 [CLS] rows against 5 + 15 for a gather
+//  launch and the dense GEMM.  Up to SMALL_M rows the launch saved is worth more than the scattered reads cost.)
 bool hipt_gemm_arows_supported(int M, int K, int dtype, int aload, int flags) {
     return dtype == HIPT_BF16 && M <= SMALL_M && K == 384 && aload == ALOAD_PLAIN && flags == 0;
 }
@@ -504,9 +507,10 @@ int hipt_gemm_launch(const GemmParams& p_in, int dtype, int aload, int flags, hi
                            (p.im.batch_stride * esz) % 16 == 0 && p.K == 768,
                        "gemm/im2col: image strides must be 16-byte multiples and K == 768");
     HIPT_CHECK_ARG((p.ldw * esz) % 16 == 0, "gemm: ldw rows must be 16-byte multiples");
-    if (p.a_row_step > 0)
+    if (p.a_row_step > 0) {
         HIPT_CHECK_ARG(hipt_gemm_arows_supported(p.M, p.K, dtype, aload, flags) && !p.ln_w,
                        "gemm: rows gathered from an activation image take bf16, M <= %d, K = 384, plain loader and epilogue", SMALL_M);
+    }
     if (p.ln_w)
         HIPT_CHECK_ARG(hipt_gemm_ln_supported(p.M, p.K, aload, flags) && p.ln_b && (p.lda * 4) % 16 == 0 && ((uintptr_t)p.ln_w % 16) == 0 &&
                            ((uintptr_t)p.ln_b % 16) == 0,
