@@ -216,7 +216,13 @@ template <int EPC> __device__ __forceinline__ constexpr int pair_off(int s) { re
 // Eight consecutive columns from a multiple of 8 are 16 consecutive bytes of the image too: fragment (R >> 4) * 6144 elements, row R & 15
 // at + 8 (R & 15), chunk m = col / 8 at (m >> 2) * 512 + ((m >> 1) & 1) * 256 + (m & 1) * 128; in the paired k order chunk m of step s,
 // lane group g is 8 (s >> 1) + 2 g + (s & 1): step part (s >> 1) * 1024 + (s & 1) * 128, lane part (g >> 1) * 512 + (g & 1) * 256.
-template <typename T, int FLAGS, bool EVEN, bool AIMG = false>
+// AI2C (EVEN, K = 768): the patch embedding of a few patches -- A is the image tensor in the compute dtype and row m is token m of
+// the call (the sequence-tiled kernel's im2col addressing: k = 256 c + 16 ky + kx -> channel c, pixel (16 ty + ky, 16 tx + kx) of the
+// patch); a 16-byte chunk never crosses a pixel row.  One patch is 256 tokens: three workgroups of the tiled kernel (115 us in fp32), 192 here.
+// k order: ASCENDING in steps of KC consecutive values, no pairing, no staggered start -- the k sets and the order of the tiled kernel's
+// MFMAs (and of embed32.hip's), so that the tokens are the same bits whichever of the three kernels a call's size selects; and nothing is
+// lost: the 16 rows of a wave are the 16 tokens of one token row, whose 64-byte pixel runs are consecutive in the image.
+template <typename T, int FLAGS, bool EVEN, bool AIMG = false, bool AI2C = false>
 __global__ __launch_bounds__(64) void gemm_small_kernel(const GemmParams p) {
     const int lane = threadIdx.x;
     const int li = lane & 15, g = lane >> 4;
@@ -230,12 +236,19 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(const GemmParams p) {
         const int64_t R = (int64_t)r * p.a_row_step;
         ap = (const T*)p.A + (R >> 4) * (16 * 384) + (int)(R & 15) * 8 + (g >> 1) * 512 + (g & 1) * 256;
     }
+    const int i2c_rs = (int)p.im.row_stride, i2c_cs = (int)p.im.chan_stride;
+    if constexpr (AI2C) {  // pixel (0, 0) of token r's 16 x 16 window, channel 0 (ALoader::init above)
+        const int tps = p.im_nty * p.im_ntx;
+        const int b = p.im_seq0 + r / tps, t = r % tps, ty = t / p.im_ntx, tx = t % p.im_ntx;
+        const int gsz = p.im.grid_w * p.im.grid_h, bi = b / gsz, sq = b % gsz, p1 = sq / p.im.grid_h, p2 = sq % p.im.grid_h;
+        ap = (const T*)p.A + (int64_t)bi * p.im.batch_stride + (int64_t)(p1 * p.im.patch_h + ty * 16) * p.im.row_stride + p2 * p.im.patch_w + tx * 16;
+    }
     const T* wp[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         int n = n0 + j * 16 + li;
         n = n < p.N ? n : p.N - 1;
-        wp[j] = (const T*)p.W + (int64_t)n * p.ldw + g * (EVEN ? 2 * EPC : EPC);
+        wp[j] = (const T*)p.W + (int64_t)n * p.ldw + g * (EVEN && !AI2C ? 2 * EPC : EPC);
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const int nk = p.K / KC;
@@ -249,15 +262,22 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(const GemmParams p) {
         // COLUMN tile (and wraps): with a row pitch of 3072 B (K = 1536 in bf16) the 16 rows of a request fall on 4 of the 16 L2
         // channels at any one k -- staggered starts spread the waves of a row tile over all of them.  The summation order of an
         // output element depends on its column only, not on which rows share the call.
-        const int rot = ((n0 >> 5) * 4) % nk;
+        const int rot = AI2C ? 0 : ((n0 >> 5) * 4) % nk;
         auto kstep = [&](int j) {
             int kk = rot + j;
             return kk >= nk ? kk - nk : kk;
         };
-        auto aoff = [&](int kk) { return AIMG ? (kk >> 1) * 1024 + (kk & 1) * 128 : pair_off<EPC>(kk); };
+        auto woff = [&](int kk) { return AI2C ? kk * KC : pair_off<EPC>(kk); };
+        auto aoff = [&](int kk) {
+            if constexpr (AI2C) {
+                const int k = kk * KC + g * EPC;  // (the lane part is not in `ap` here)
+                return (k >> 8) * i2c_cs + ((k >> 4) & 15) * i2c_rs + (k & 15);
+            }
+            return AIMG ? (kk >> 1) * 1024 + (kk & 1) * 128 : pair_off<EPC>(kk);
+        };
 #pragma unroll
         for (int d = 0; d < RING; ++d) {
-            const int kk = kstep(d), kn = pair_off<EPC>(kk);
+            const int kk = kstep(d), kn = woff(kk);
             a[d] = *(const u32x4*)(ap + aoff(kk)), w0[d] = *(const u32x4*)(wp[0] + kn), w1[d] = *(const u32x4*)(wp[1] + kn);
         }
         for (int k = 0; k + RING < nk; k += RING) {
@@ -265,7 +285,7 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(const GemmParams p) {
             for (int d = 0; d < RING; ++d) {
                 Tr<T>::mma16(acc[0], w0[d], a[d]);
                 Tr<T>::mma16(acc[1], w1[d], a[d]);
-                const int kk = kstep(k + d + RING), kn = pair_off<EPC>(kk);
+                const int kk = kstep(k + d + RING), kn = woff(kk);
                 a[d] = *(const u32x4*)(ap + aoff(kk)), w0[d] = *(const u32x4*)(wp[0] + kn), w1[d] = *(const u32x4*)(wp[1] + kn);
             }
         }
@@ -414,6 +434,14 @@ __global__ __launch_bounds__(64) void lngemm_small_kernel(const GemmParams p) {
 
 template <typename T, int ALOAD, int FLAGS>
 int launch(const GemmParams& p, hipStream_t st) {
+    if constexpr (ALOAD == ALOAD_IM2COL) {
+        // (image strides that fit the kernel's 32-bit offsets: any tensor of up to 2^31 elements)
+        if (p.M <= SMALL_M && p.K == 768 && p.im.chan_stride < (1ll << 30) && p.im.row_stride < (1 << 24) && !hipt_generic_only()) {
+            hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS, true, false, true>), dim3(((p.M + 15) / 16) * ((p.N + 31) / 32)), dim3(64), 0, st, p);
+            HIPT_CHECK_LAUNCH();
+            return HIPT_OK;
+        }
+    }
     if constexpr (ALOAD == ALOAD_PLAIN) {
         const dim3 sgrid(((p.M + 15) / 16) * ((p.N + 31) / 32));
         if (p.ln_w) {  // (checked by hipt_gemm_launch: small M, K = 384 or 192, the two plain epilogues)
