@@ -283,6 +283,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the job has WORLD_SIZE={world} rank(s): refusing to report a number for a "
                          f"different GPU count than asked for")
+    # a launcher (torch.distributed.run, also with ONE rank) means a live process group: every barrier / reduction / gather below is
+    # then a real collective (RCCL on the GPU); plain `python bench.py` has none and they are local
+    grp = [D.grouped()]
+    group_info = D.group_info()
     if dry:
         # the rehearsal: every line of the multi-rank leg below runs, on CPU tensors over gloo, with stand-in models and small shapes
         dev = torch.device("cpu")
@@ -327,7 +331,7 @@ def main():
         return f, logits, a_raw
 
     def barrier():
-        if world > 1:
+        if grp[0]:
             torch.distributed.barrier()
         if not dry:
             torch.cuda.synchronize()
@@ -338,15 +342,69 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = step(i, True)
-    if world > 1:  # the one collective of a job: per-slide logits + attention logits of every rank
+    if grp[0]:  # the one collective of a job: per-slide logits + attention logits of every rank
         D.gather_slide_outputs([rank], [last[1]], [last[2]], world, device=dev)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if grp[0]:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
     abmil_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else None
+
+    # ---- config 5 (BASELINE configs[4]): slides sharded over the ranks, one all-gather ----
+    cfg5 = None
+    if args.slides > 0:
+        slides = PL.synthetic_slides(args.slides, args.slide_regions)
+        ns = min(args.slide_sample, R)
+        calls = [0]
+
+        def resident(spec, idx):  # resident pixels: nothing is generated inside the timed region
+            s = (calls[0] * ns) % max(1, R - ns + 1)
+            calls[0] += 1
+            return region[s:s + len(idx)]
+
+        run5 = lambda: PL.process_slides(model, clam192, slides, rank, world, device=dev, regions_per_call=ns, sample_regions=ns,
+                                         region_source=resident, expand_bag=True)
+        run5()  # warm-up (first CLAM_SB [192,128,64] call, gather buffers)
+        barrier()
+        t5 = time.perf_counter()
+        r5 = run5()
+        barrier()
+        t5_local = time.perf_counter() - t5  # (incl. the wait at the closing barrier: the job's time as this rank saw it)
+        d5 = torch.tensor([t5_local], dtype=torch.float64, device=dev)
+        nreg = torch.tensor([r5.local_regions], dtype=torch.float64, device=dev)
+        # per-rank load: regions, slides and the seconds a rank spent in its own slides (before the gather) -- min / max over the
+        # ranks show the imbalance of the slide-level sharding directly
+        mine = torch.tensor([float(r5.local_regions), float(len(r5.local_slides)), float(r5.local_seconds)],
+                            dtype=torch.float64, device=dev)
+        lo, hi = mine.clone(), mine.clone()
+        if grp[0]:
+            torch.distributed.all_reduce(d5, op=torch.distributed.ReduceOp.MAX)
+            torch.distributed.all_reduce(nreg, op=torch.distributed.ReduceOp.SUM)
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        d5, nreg = float(d5.item()), float(nreg.item())
+        per_rank = {"regions_min": int(lo[0].item()), "regions_max": int(hi[0].item()), "slides_min": int(lo[1].item()),
+                    "slides_max": int(hi[1].item()), "seconds_min": float(lo[2].item()), "seconds_max": float(hi[2].item())}
+        total_regions = sum(s.n_regions for s in slides)
+        cfg5 = {"slides": args.slides, "regions_per_slide_nominal": args.slide_regions, "regions_sampled_per_slide": ns,
+                "seconds": d5, "regions_per_s": nreg / d5, "sampled_slides_per_s": args.slides / d5,
+                "slides_per_s_extrapolated": args.slides / (d5 * total_regions / nreg),
+                "per_rank": per_rank,
+                "note": "a PLUMBING check of BASELINE configs[4], not a throughput figure: slide i -> rank i mod G; per slide only the stated "
+                        "sample of its regions goes through HIPT_4K (bf16), the features are tiled to the slide's n regions, CLAM_SB "
+                        "[192,128,64] and ONE all-gather of logits + ragged A_raw carry their true sizes.  slides_per_s_extrapolated = "
+                        "measured time x (all regions / sampled regions): it charges the per-slide CLAM_SB + gather at the sampled rate and "
+                        "is dominated by the 8 sampled regions per slide -- the headline `value` is the measured throughput",
+                "gathered_logits_shape": list(r5.logits.shape), "gathered_a_raw_total": int(sum(a.numel() for a in r5.a_raw))}
+
+    if grp[0] and world == 1:
+        # a one-rank group has done its work (timed gather, config 5): end it here, so that the single-GPU legs below run as in a
+        # plain launch (a HIP-graph capture with RCCL's watchdog thread alive is not safe)
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        grp[0] = False
 
     # the CLAM kernel's own pace: K forwards captured in ONE HIP graph (the arrival ticket of the in-kernel merge returns to zero by
     # itself, so the launch replays) and replayed between ONE HIP-event pair on the stream they run on -- no host time between the
@@ -383,53 +441,6 @@ def main():
         except Exception as e:  # a graph that cannot be captured on this stack is reported, not fatal
             abmil_graph = {"error": repr(e)[:200]}
 
-    # ---- config 5 (BASELINE configs[4]): slides sharded over the ranks, one all-gather ----
-    cfg5 = None
-    if args.slides > 0:
-        slides = PL.synthetic_slides(args.slides, args.slide_regions)
-        ns = min(args.slide_sample, R)
-        calls = [0]
-
-        def resident(spec, idx):  # resident pixels: nothing is generated inside the timed region
-            s = (calls[0] * ns) % max(1, R - ns + 1)
-            calls[0] += 1
-            return region[s:s + len(idx)]
-
-        run5 = lambda: PL.process_slides(model, clam192, slides, rank, world, device=dev, regions_per_call=ns, sample_regions=ns,
-                                         region_source=resident, expand_bag=True)
-        run5()  # warm-up (first CLAM_SB [192,128,64] call, gather buffers)
-        barrier()
-        t5 = time.perf_counter()
-        r5 = run5()
-        barrier()
-        t5_local = time.perf_counter() - t5  # (incl. the wait at the closing barrier: the job's time as this rank saw it)
-        d5 = torch.tensor([t5_local], dtype=torch.float64, device=dev)
-        nreg = torch.tensor([r5.local_regions], dtype=torch.float64, device=dev)
-        # per-rank load: regions, slides and the seconds a rank spent in its own slides (before the gather) -- min / max over the
-        # ranks show the imbalance of the slide-level sharding directly
-        mine = torch.tensor([float(r5.local_regions), float(len(r5.local_slides)), float(r5.local_seconds)],
-                            dtype=torch.float64, device=dev)
-        lo, hi = mine.clone(), mine.clone()
-        if world > 1:
-            torch.distributed.all_reduce(d5, op=torch.distributed.ReduceOp.MAX)
-            torch.distributed.all_reduce(nreg, op=torch.distributed.ReduceOp.SUM)
-            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
-            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-        d5, nreg = float(d5.item()), float(nreg.item())
-        per_rank = {"regions_min": int(lo[0].item()), "regions_max": int(hi[0].item()), "slides_min": int(lo[1].item()),
-                    "slides_max": int(hi[1].item()), "seconds_min": float(lo[2].item()), "seconds_max": float(hi[2].item())}
-        total_regions = sum(s.n_regions for s in slides)
-        cfg5 = {"slides": args.slides, "regions_per_slide_nominal": args.slide_regions, "regions_sampled_per_slide": ns,
-                "seconds": d5, "regions_per_s": nreg / d5, "sampled_slides_per_s": args.slides / d5,
-                "slides_per_s_extrapolated": args.slides / (d5 * total_regions / nreg),
-                "per_rank": per_rank,
-                "note": "a PLUMBING check of BASELINE configs[4], not a throughput figure: slide i -> rank i mod G; per slide only the stated "
-                        "sample of its regions goes through HIPT_4K (bf16), the features are tiled to the slide's n regions, CLAM_SB "
-                        "[192,128,64] and ONE all-gather of logits + ragged A_raw carry their true sizes.  slides_per_s_extrapolated = "
-                        "measured time x (all regions / sampled regions): it charges the per-slide CLAM_SB + gather at the sampled rate and "
-                        "is dominated by the 8 sampled regions per slide -- the headline `value` is the measured throughput",
-                "gathered_logits_shape": list(r5.logits.shape), "gathered_a_raw_total": int(sum(a.numel() for a in r5.a_raw))}
-
     if rank != 0:
         if world > 1:
             torch.distributed.barrier()  # rank 0's single-GPU legs below: keep the group alive until it is done
@@ -445,6 +456,8 @@ def main():
                "abmil_fwd_ms": abmil_ms}
         if cfg5:
             out["config5"] = cfg5
+        if group_info:
+            out["group_ranks"], out["collective_backend"] = group_info["ranks"], group_info["backend"]
         print(json.dumps(out))
         sys.stdout.flush()
         if world > 1:
@@ -470,6 +483,10 @@ def main():
     }
     if cfg5:
         out["config5"] = cfg5
+    if group_info:
+        # the process group the timed gather and config 5 ran over (backend "nccl" = RCCL on ROCm), as the group itself reports it
+        out["rccl_ranks" if group_info["backend"] == "nccl" else "group_ranks"] = group_info["ranks"]
+        out["collective_backend"] = group_info["backend"]
 
     # ---- per-kernel roofline leg: same workload, HIP events around every launch, ONE stream ----
     prof = {}

@@ -21,7 +21,7 @@ _LAZY = {
     "VisionTransformer4K": ("vision_transformer4k", "VisionTransformer4K"), "vit4k_xs": ("vision_transformer4k", "vit4k_xs"),
     "install": ("dropin", "install"), "build_native": ("_native", "build"),
     "FeatureWriter": ("feature_store", "FeatureWriter"), "extract_slide": ("feature_store", "extract_slide"),
-    "load_bag": ("feature_store", "load_bag"),
+    "load_bag": ("feature_store", "load_bag"), "load_coords": ("feature_store", "load_coords"),
 }
 
 

@@ -238,7 +238,10 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             continue;
         } else {
             // (small calls: both LayerNorms run in the prologue of the GEMM that consumes them -- five launches a block instead of seven)
-            const bool ln_in_gemm = small && !hipt_generic_only() && hipt_gemm_ln_supported(M, D, ALOAD_PLAIN, 0);
+            // (the kernel loads gamma / beta 16 bytes at a time: parameters that are views into a flat buffer off that grid keep the
+            //  separate LayerNorm launch, which has no alignment requirement)
+            const bool ln_al = (((uintptr_t)b.ln1_w | (uintptr_t)b.ln1_b | (uintptr_t)b.ln2_w | (uintptr_t)b.ln2_b) & 15) == 0;
+            const bool ln_in_gemm = small && ln_al && !hipt_generic_only() && hipt_gemm_ln_supported(M, D, ALOAD_PLAIN, 0);
             if (ln_in_gemm) {
                 PROF(PC_QKV, linear(x, D, b.qkv_w, D, b.qkv_b, nullptr, s.qkv, 3 * D, M, 3 * D, D, dt, 0, st, w->ntok, b.ln1_w, b.ln1_b, w->ln_eps));
             } else {
@@ -877,8 +880,19 @@ int hipt_vit4k_forward(const hipt_vit_weights* w, const float* tokens_in, int ns
         if ((rc = hipt_f32_to_bf16_launch(tokens_in, tokT, n, st))) return rc;
         tok = tokT;
     }
-    if ((rc = embed4k(w, tok, nseq, x, st))) return rc;
-    if ((rc = run_blocks(w, x, nseq, 0, w->depth, nullptr, s, st))) return rc;
+    // The regions of a call go through the blocks in groups that are small calls (run_blocks: at most 1 088 token rows, i.e. four
+    // 16 x 16 grids): which kernels a region's 257 rows meet then does not depend on how many regions share the call -- one region
+    // alone, eight gathered by extract_slide and a ragged tail of three write the same bits (the small-call kernels are row
+    // independent bit for bit) -- and eight regions take 2 x 30 launches of ~6 us instead of 24 latency-sized streaming launches.
+    // (a grid of more than 1 087 tokens is no small call for any count: one region per group, the same kernels every time)
+    const int group = w->ntok <= 1088 ? 1088 / w->ntok : 1;
+    const size_t tsz = esz(w->dtype);
+    for (int s0 = 0; s0 < nseq; s0 += group) {
+        const int g = nseq - s0 < group ? nseq - s0 : group;
+        float* xg = x + (size_t)s0 * w->ntok * w->dim;
+        if ((rc = embed4k(w, (const char*)tok + (size_t)s0 * (w->ntok - 1) * w->embed_k * tsz, g, xg, st))) return rc;
+        if ((rc = run_blocks(w, xg, g, 0, w->depth, nullptr, s, st))) return rc;
+    }
     return hipt_layernorm_launch(x, (int64_t)w->ntok * w->dim, w->norm_w, w->norm_b, out, HIPT_F32, w->dim, nseq, w->dim, w->ln_eps, st);
 }
 

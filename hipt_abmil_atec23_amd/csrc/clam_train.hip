@@ -232,10 +232,12 @@ __global__ void clam_pool_init(float* __restrict__ stats, float* __restrict__ M,
 // (the slot starts at -inf)
 // -0.0 is canonicalised to +0.0 first (as a negative bit pattern it would go down the unsigned branch and, being the SMALLEST
 // negative pattern, win against every real negative maximum only by accident of the comparison direction; as 0x80000000 on the
-// signed branch it would never replace -inf), and the branch is taken on the SIGN BIT: a NaN block maximum then lands as a NaN
-// (a positive NaN pattern is above +inf as an int, a negative one below every negative float as an unsigned) instead of being dropped.
+// signed branch it would never replace -inf) and a NaN to the positive quiet NaN (0x7fc00000: above +inf as a signed int, so it
+// wins and stays; a negative NaN pattern -- 0xffc00000, the default NaN -- is ABOVE every negative float as an unsigned int and
+// atomicMin would never store it); the branch is taken on the sign bit.
 __device__ __forceinline__ void atomic_max_f32(float* p, float v) {
     v += 0.f;
+    if (v != v) v = __int_as_float(0x7fc00000);
     if (__float_as_int(v) >= 0) atomicMax((int*)p, __float_as_int(v));
     else atomicMin((unsigned*)p, __float_as_uint(v));
 }

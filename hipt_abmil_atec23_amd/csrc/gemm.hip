@@ -435,8 +435,9 @@ __global__ __launch_bounds__(64) void lngemm_small_kernel(const GemmParams p) {
 template <typename T, int ALOAD, int FLAGS>
 int launch(const GemmParams& p, hipStream_t st) {
     if constexpr (ALOAD == ALOAD_IM2COL) {
-        // (image strides that fit the kernel's 32-bit offsets: any tensor of up to 2^31 elements)
-        if (p.M <= SMALL_M && p.K == 768 && p.im.chan_stride < (1ll << 30) && p.im.row_stride < (1 << 24) && !hipt_generic_only()) {
+        // (image strides whose largest in-patch offset, 2 channel planes + 15 pixel rows + 15, fits the kernel's 32-bit arithmetic)
+        if (p.M <= SMALL_M && p.K == 768 && p.im.chan_stride >= 0 && p.im.row_stride >= 0 &&
+            2 * (int64_t)p.im.chan_stride + 15 * (int64_t)p.im.row_stride + 16 < (1ll << 31) && !hipt_generic_only()) {
             hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS, true, false, true>), dim3(((p.M + 15) / 16) * ((p.N + 31) / 32)), dim3(64), 0, st, p);
             HIPT_CHECK_LAUNCH();
             return HIPT_OK;

@@ -20,12 +20,16 @@ import torch.distributed as dist
 
 
 def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
-    """(rank, world, local_rank) from the torchrun environment; initialises the process group when
-    WORLD_SIZE > 1.  RCCL needs dmabuf IPC on this pool, hence HSA_ENABLE_IPC_MODE_LEGACY=0."""
+    """(rank, world, local_rank) from the torchrun environment; initialises the process group whenever a launcher set one up
+    (RANK + WORLD_SIZE + MASTER_PORT present) -- also for ONE rank: `python -m torch.distributed.run --nproc-per-node 1 bench.py`
+    then carries its gather over a real 1-rank RCCL communicator, which is how the collective path is exercised on a one-GPU box.
+    Without a launcher environment (plain `python bench.py`) there is no group and the gather is a local copy.
+    RCCL needs dmabuf IPC on this pool, hence HSA_ENABLE_IPC_MODE_LEGACY=0."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    launched = all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_PORT"))
+    if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
@@ -34,6 +38,16 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def grouped() -> bool:
+    """Is a process group alive?  (Then every exchange below is a real collective, whatever the world size.)"""
+    return dist.is_available() and dist.is_initialized()
+
+
+def group_info() -> dict:
+    """{"backend": "nccl" | "gloo", "ranks": world size} of the live process group, {} without one.  "nccl" IS RCCL on ROCm."""
+    return {"backend": str(dist.get_backend()), "ranks": int(dist.get_world_size())} if grouped() else {}
 
 
 def world() -> int:
@@ -68,7 +82,7 @@ def gather_slide_outputs(slide_ids: Sequence[int], logits: Sequence[torch.Tensor
     n_local_max = max([int(a.numel()) for a in a_raw], default=0)
     ws = world()
     meta = torch.tensor([s_local, n_local_max, C], dtype=torch.int64, device=device)
-    if ws > 1:
+    if grouped():  # (a 1-rank group too: the same two collectives, over a one-rank communicator)
         dist.all_reduce(meta, op=dist.ReduceOp.MAX)
     S, n_max, C = (int(v) for v in meta.tolist())
     HDR = 4  # int64 id | int64 length, bit-cast into four fp32 slots
@@ -81,7 +95,7 @@ def gather_slide_outputs(slide_ids: Sequence[int], logits: Sequence[torch.Tensor
         block[j, HDR:HDR + C] = logits[j].reshape(-1).float()
         block[j, HDR + C:HDR + C + n] = a_raw[j].reshape(-1).float()
     block[:, :HDR] = hdr.view(torch.float32)  # raw bits: the collective moves bytes, nothing interprets these words as floats
-    if ws > 1:
+    if grouped():
         out = torch.empty((ws * S, block.shape[1]), dtype=torch.float32, device=device)  # concatenated along dim 0
         dist.all_gather_into_tensor(out, block)
     else:

@@ -7,8 +7,14 @@ Reader = the bag loader of ``datasets/dataset_generic.py:505-528``: ``torch.load
 has more than ``max_patches_per_slide`` rows, ``np.random.choice(n, max)`` (WITH replacement, as the reference)
 rows of it.
 
-The ``h5_files/{slide}.h5`` twin (datasets ``features`` / ``coords``, chunks ``(1, .)``, resizable first axis) is
-written only when ``h5py`` is importable; this image has none, and nothing on the GPU path reads it.
+``coords`` are integer data and pass through bit for bit: whatever integer dtype the loader hands over
+(the reference's h5 ``coords`` dataset: int64, or int32 from older patch files) is what is stored.  The reference keeps them
+in ``h5_files/{slide}.h5`` beside the features; ``h5py`` is not part of every host (this image has none), so the coordinates
+are ALWAYS written to a sidecar ``coords_files/{slide}.npy`` (plain ``numpy.save`` of the ``[n, 2]`` array, same row order as
+``pt_files/{slide}.pt``; ``load_coords`` reads it back) and the ``.h5`` twin (datasets ``features`` / ``coords``, chunks
+``(1, .)``, resizable first axis: ``utils/file_utils.py:16-35``) in addition where ``h5py`` is importable.  The directory is a
+sibling of ``pt_files/`` because the reference lists that directory to find finished slides
+(``extract_features_fp.py:231-238``) and loads bags from it by name: nothing else may live there.
 """
 from __future__ import annotations
 
@@ -35,11 +41,16 @@ class FeatureWriter:
 
     def append(self, features, coords) -> None:
         f = features.detach().float().cpu() if torch.is_tensor(features) else torch.as_tensor(np.asarray(features), dtype=torch.float32)
-        c = coords.detach().cpu() if torch.is_tensor(coords) else torch.as_tensor(np.asarray(coords))
-        if f.dim() != 2 or c.dim() != 2 or f.shape[0] != c.shape[0]:
+        c = coords.detach().cpu().numpy() if torch.is_tensor(coords) else np.asarray(coords)
+        if f.dim() != 2 or c.ndim != 2 or f.shape[0] != c.shape[0]:
             raise ValueError(f"features {tuple(f.shape)} / coords {tuple(c.shape)}: expected [n, d] and [n, 2]")
+        if c.dtype.kind not in "iu":
+            raise TypeError(f"slide {self.slide_id}: coords must be integers (got {c.dtype}); they are stored bit for bit, never rounded")
+        if self._coords and (c.dtype != self._coords[0].dtype or c.shape[1:] != self._coords[0].shape[1:]):
+            # (the reference's resizable h5 dataset keeps the dtype of the first batch and would cast silently: refuse instead)
+            raise TypeError(f"slide {self.slide_id}: coords {c.dtype}{list(c.shape[1:])} after {self._coords[0].dtype}{list(self._coords[0].shape[1:])}")
         self._feats.append(f)
-        self._coords.append(c.to(torch.int64))
+        self._coords.append(np.array(c, copy=True))  # (the caller may reuse its buffer)
 
     def __len__(self) -> int:
         return sum(f.shape[0] for f in self._feats)
@@ -47,17 +58,46 @@ class FeatureWriter:
     def close(self) -> str:
         if not self._feats:
             raise ValueError(f"slide {self.slide_id}: nothing was appended")
-        feats, coords = torch.cat(self._feats, 0), torch.cat(self._coords, 0)
-        os.makedirs(os.path.join(self.feat_dir, "pt_files"), exist_ok=True)
-        pt = os.path.join(self.feat_dir, "pt_files", self.slide_id + ".pt")
-        torch.save(feats, pt)  # extract_features_fp.py:255: the tensor itself, nothing else
+        feats, coords = torch.cat(self._feats, 0), np.concatenate(self._coords, 0)
+        for d in ("pt_files", "coords_files"):
+            os.makedirs(os.path.join(self.feat_dir, d), exist_ok=True)
+        # coordinates first: a slide counts as finished when its .pt exists (the auto-skip looks at pt_files only), so the .pt is
+        # written last and both files go through a rename -- a run killed in between leaves no half-written finished slide
+        cpath = coords_path(self.feat_dir, self.slide_id)
+        with open(cpath + ".tmp", "wb") as fh:
+            np.save(fh, coords, allow_pickle=False)
+        os.replace(cpath + ".tmp", cpath)
         if self.write_h5:
             import h5py
             os.makedirs(os.path.join(self.feat_dir, "h5_files"), exist_ok=True)
             with h5py.File(os.path.join(self.feat_dir, "h5_files", self.slide_id + ".h5"), "w") as fh:
-                for key, val in (("features", feats.numpy()), ("coords", coords.numpy())):
+                for key, val in (("features", feats.numpy()), ("coords", coords)):
                     fh.create_dataset(key, data=val, maxshape=(None,) + val.shape[1:], chunks=(1,) + val.shape[1:])
+        pt = os.path.join(self.feat_dir, "pt_files", self.slide_id + ".pt")
+        torch.save(feats, pt + ".tmp")  # extract_features_fp.py:255: the tensor itself, nothing else
+        os.replace(pt + ".tmp", pt)
         return pt
+
+
+def coords_path(feat_dir: str, slide_id: str) -> str:
+    return os.path.join(feat_dir, "coords_files", slide_id + ".npy")
+
+
+def load_coords(feat_dir: str, slide_id: str) -> np.ndarray:
+    """The slide's ``coords [n, 2]`` exactly as they were appended (dtype and bits); row i belongs to row i of
+    ``pt_files/{slide}.pt``.  Reads the sidecar, or the reference's ``h5_files/{slide}.h5`` where only that exists."""
+    p = coords_path(feat_dir, slide_id)
+    if os.path.isfile(p):
+        return np.load(p, allow_pickle=False)
+    h5 = os.path.join(feat_dir, "h5_files", slide_id + ".h5")
+    if os.path.isfile(h5):
+        try:
+            import h5py
+        except ImportError as e:
+            raise FileNotFoundError(f"{p} is missing and {h5} needs h5py, which this host lacks") from e
+        with h5py.File(h5, "r") as fh:
+            return fh["coords"][:]
+    raise FileNotFoundError(f"no coordinates for slide {slide_id} under {feat_dir} (coords_files/ or h5_files/)")
 
 
 def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], feat_dir: str, slide_id: str, coalesce: int = 8) -> str:

@@ -191,6 +191,47 @@ class HIPT_4K(torch.nn.Module):
         hipt_model_utils.py:113-118) is applied on the device."""
         return self._run(x, want_cls256=False)[0]
 
+    def _get_region_attention_scores(self, region, scale=1):
+        """hipt_4k.py:121-164: the hierarchical attention maps of one region, the input of the heat-map code.
+
+        ``region``: a ``PIL.Image`` / ``[W', H', 3] uint8`` array (goes through ``eval_transforms`` as in the reference) or an
+        already normalised ``[1, 3, W', H']`` float tensor.  Returns ``(patches [n, 256/s, 256/s, 3] uint8 array,
+        attention_256 [n, heads, 256/s, 256/s] array, attention_4k [heads, W/s, H/s] array)`` with ``n = w_256 * h_256`` patches.
+
+        What the reference takes from ``get_last_selfattention`` is ``[:, :, 0, 1:]`` -- the [CLS] query's row -- so both maps come
+        from the one-query kernels (``get_last_selfattention_cls``: ``hipt_vit_cls_attention``); the ``[n, 6, 257, 257]``
+        probability tensor (406 MB for a 4096 x 4096 region) is never built."""
+        import numpy as np
+
+        from .hipt_model_utils import eval_transforms, tensorbatch2im
+        if torch.is_tensor(region) and region.dim() == 4:
+            x = region
+        else:
+            x = eval_transforms()(region).unsqueeze(dim=0)  # :135
+        if x.shape[0] != 1:
+            raise ValueError("_get_region_attention_scores describes ONE region, as in the reference (hipt_4k.py:138-146)")
+        batch, w_256, h_256 = self.prepare_img_tensor(x)
+        if w_256 == 0 or h_256 == 0:
+            raise ValueError(f"region {tuple(x.shape)} is smaller than one 256x256 patch")
+        d256, d4k = self.model256.weight_device, self.model4k.weight_device
+        n = w_256 * h_256
+        # 'b c p1 p2 w h -> (b p1 p2) c w h' (:137-139): patch k = p1 * h_256 + p2
+        b256 = batch.to(d256).float().unfold(2, 256, 256).unfold(3, 256, 256).permute(0, 2, 3, 1, 4, 5).reshape(n, 3, 256, 256).contiguous()
+        with torch.no_grad():
+            features_cls256 = self.model256(b256)  # :141
+            a256 = self.model256.get_last_selfattention_cls(b256)  # [n, heads, 257] = get_last_selfattention(b256)[:, :, 0, :]  (:143)
+            nh = a256.shape[1]
+            a256 = a256[:, :, 1:].reshape(n, nh, 16, 16)  # :145-146
+            a256 = torch.nn.functional.interpolate(a256, scale_factor=int(16 / scale), mode="nearest").cpu().numpy()  # :147
+            grid = features_cls256.reshape(w_256, h_256, -1).transpose(0, 1).transpose(0, 2).unsqueeze(dim=0).to(d4k)  # :149-150
+            a4k = self.model4k.get_last_selfattention_cls(grid)  # [1, heads, 1 + n]  (:153)
+            nh = a4k.shape[1]
+            a4k = a4k[0, :, 1:].reshape(nh, w_256, h_256)  # :155-156
+            a4k = torch.nn.functional.interpolate(a4k.unsqueeze(0), scale_factor=int(256 / scale), mode="nearest")[0].cpu().numpy()  # :157
+            if scale != 1:
+                b256 = torch.nn.functional.interpolate(b256, scale_factor=(1 / scale), mode="nearest")  # :159-160
+        return tensorbatch2im(b256), np.asarray(a256), np.asarray(a4k)
+
     def forward_asset_dict(self, x: torch.Tensor):
         """hipt_4k.py:79-118: intermediate features as numpy arrays."""
         if x.shape[0] != 1:

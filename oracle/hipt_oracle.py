@@ -290,6 +290,32 @@ def hipt4k_forward(x, p256, p4k, heads256=6, heads4k=6, return_cls256=False):
     return (out, f256) if return_cls256 else out
 
 
+def nearest_upsample(a, f):
+    """F.interpolate(a, scale_factor=f, mode="nearest") for an integer factor on the two last axes: out[i, j] = a[i // f, j // f]."""
+    return np.repeat(np.repeat(a, f, axis=-2), f, axis=-1)
+
+
+def region_attention_scores(x, p256, p4k, scale=1, heads256=6, heads4k=6):
+    """The tensor half of HIPT_4K._get_region_attention_scores (hipt_4k.py:135-160) for a normalised region x [1,3,W,H]:
+    returns (patches [n,3,256/s,256/s] float, attention_256 [n,heads,256/s,256/s], attention_4k [heads,W/s,H/s]).
+    attention_* are the [CLS] query's row of the last block's attention map without its own column ([:, :, 0, 1:]), laid out on
+    the token grid and blown up with nearest-neighbour copies by int(16/scale) / int(256/scale)."""
+    img, w_256, h_256 = prepare_img_tensor(x)
+    batch = patchify_256(img, w_256, h_256)  # :138-139
+    n = batch.shape[0]
+    tok = vit256_prepare_tokens(batch, p256)
+    a256 = vit_last_selfattention(tok, p256, heads256)[:, :, 0, 1:]  # :143-145
+    a256 = nearest_upsample(a256.reshape(n, heads256, 16, 16), int(16 / scale))  # :146-147
+    f256 = vit256_forward(batch, p256, heads256)  # :141
+    grid = cls_grid(f256, w_256, h_256)  # :149
+    a4k = vit_last_selfattention(vit4k_prepare_tokens(grid, p4k), p4k, heads4k)[0, :, 0, 1:]  # :153-155
+    a4k = nearest_upsample(a4k.reshape(heads4k, w_256, h_256), int(256 / scale))  # :156-157
+    if scale != 1:  # :159-160: F.interpolate(scale_factor=1/scale, nearest) on the patches: out[i] = in[floor(i * scale)]
+        idx = np.floor(np.arange(int(256 * (1 / scale))) * scale).astype(np.int64)
+        batch = batch[:, :, idx][:, :, :, idx]
+    return batch, a256, a4k
+
+
 # --------------------------------------------------------------------------------------
 # CLAM / ABMIL aggregator (models/model_clam.py)
 # --------------------------------------------------------------------------------------

@@ -59,7 +59,13 @@ def load(model, specs, base_seed=0):
     return model.eval()
 
 
+SKIP_EXISTING = False
+
+
 def save(name, **arrs):
+    if SKIP_EXISTING and os.path.isfile(os.path.join(HERE, name + ".npz")):
+        print(f"kept {name}.npz")
+        return
     out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
@@ -111,9 +117,11 @@ def clam_train_goldens(clam):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="", help="'train': only the CLAM training-step fixtures")
+    ap.add_argument("--only", default="", help="'train': only the CLAM training-step fixtures; 'new': skip fixtures that already exist")
     ap.add_argument("--skip-4096", action="store_true")
     args = ap.parse_args()
+    global SKIP_EXISTING
+    SKIP_EXISTING = args.only == "new"
     vits, vits4k, clam = import_reference(args.ref)
     clam_train_goldens(clam)
     if args.only == "train":
@@ -177,6 +185,30 @@ def main():
         r4k = synth.hash_uniform_torch((1, 3, 4096, 4096), seed=3)
         o, f = hipt_forward(r4k)
         save("hipt4k_4096", out=o, cls256=f)
+
+    # ---- (5b) HIPT_4K._get_region_attention_scores: hipt_4k.py:135-160 re-issued around the reference ViTs (tensor half only) ----
+    def region_attention(x, scale):
+        _, _, w, h = x.shape
+        w_256, h_256 = w // 256, h // 256
+        b = x.unfold(2, 256, 256).unfold(3, 256, 256)  # :138
+        b = rearrange(b, 'b c p1 p2 w h -> (b p1 p2) c w h')  # :139
+        cls = m256(b)  # :141
+        a256 = m256.get_last_selfattention(b)  # :143
+        nh = a256.shape[1]
+        a256 = a256[:, :, 0, 1:].reshape(w_256 * h_256, nh, -1)  # :145 (the reference writes 256 = its w_256 * h_256)
+        a256 = a256.reshape(w_256 * h_256, nh, 16, 16)  # :146
+        a256 = torch.nn.functional.interpolate(a256, scale_factor=int(16 / scale), mode="nearest")  # :147
+        grid = cls.reshape(w_256, h_256, 384).transpose(0, 1).transpose(0, 2).unsqueeze(dim=0)  # :149
+        a4k = m4k.get_last_selfattention(grid)  # :153
+        nh = a4k.shape[1]
+        a4k = a4k[0, :, 0, 1:].reshape(nh, -1).reshape(nh, w_256, h_256)  # :155-156
+        a4k = torch.nn.functional.interpolate(a4k.unsqueeze(0), scale_factor=int(256 / scale), mode="nearest")[0]  # :157
+        if scale != 1:
+            b = torch.nn.functional.interpolate(b, scale_factor=(1 / scale), mode="nearest")  # :160
+        return b, a256, a4k
+
+    b, a256, a4k = region_attention(r1k, 4)
+    save("hipt4k_attn_1024x768_s4", attention_256=a256, attention_4k=a4k, patches_u8=((b.permute(0, 2, 3, 1) + 1) / 2.0 * 255.0).numpy().astype(np.uint8))
 
     # ---- (6)+(7) CLAM_SB / Attn_Net_Gated ----
     def clam_pack(model, h, label=None, k=8):

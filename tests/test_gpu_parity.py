@@ -720,6 +720,53 @@ def test_extract_slide_gathered_calls_write_the_same_bits(hipt, tmp_path):
         assert a.shape == (5, 192) and torch.equal(a, b), dt
 
 
+def test_extract_slide_4096_regions_gathered_ragged_tail_same_bits(hipt, tmp_path):
+    """The same property at the size that matters: 4096 x 4096 regions, whose second-level ViT has 257 token rows per
+    region -- one region alone is a small call (<= 1 088 rows), eight gathered ones were not, and a ragged tail of three was
+    again.  hipt_vit4k_forward now walks the regions of a call in groups that are small calls, so the kernels a region meets
+    do not depend on its company: coalesce = 1, coalesce = 8 (8 + a tail of 3) and coalesce = 5 (5 + 5 + 1) write the same
+    features bit for bit, and the coordinates stay aligned.  bf16 = the bench configuration."""
+    from hipt_abmil_atec23_amd.feature_store import extract_slide, load_coords
+    regions = [synth.hash_uniform_torch((1, 3, 4096, 4096), 900 + i, device=DEV) for i in range(11)]
+    batches = [(r, torch.tensor([[4096 * i, 4096 * (i % 3)]], dtype=torch.int64)) for i, r in enumerate(regions)]
+    hipt.set_compute_dtype("bf16")
+    try:
+        one = torch.load(extract_slide(hipt, batches, str(tmp_path), "co1", coalesce=1))
+        for co in (8, 5):
+            got = torch.load(extract_slide(hipt, batches, str(tmp_path), f"co{co}", coalesce=co))
+            assert got.shape == (11, 192) and torch.equal(one, got), f"coalesce={co}: max diff {float((one - got).abs().max())}"
+            assert np.array_equal(load_coords(str(tmp_path), f"co{co}"), load_coords(str(tmp_path), "co1"))
+    finally:
+        hipt.set_compute_dtype("fp32")
+    assert load_coords(str(tmp_path), "co1").tolist() == [[4096 * i, 4096 * (i % 3)] for i in range(11)]
+
+
+def test_region_attention_scores_vs_reference_golden(hipt):
+    """HIPT_4K._get_region_attention_scores (hipt_4k.py:121-164), the consumer SURVEY.md 8 f-4 names: attention_256
+    [n, 6, 256/s, 256/s] and attention_4k [6, W/s, H/s] of a 1024 x 768 region at scale 4 against the maps of the REFERENCE's
+    own ViTs (tests/golden/make_golden.py re-issues hipt_4k.py:135-160 around them): 1e-4 in fp32.  Both maps come from the
+    one-query kernels; the [n, 6, 257, 257] tensor is never built."""
+    g = golden("hipt4k_attn_1024x768_s4")
+    x = synth.hash_uniform_torch((1, 3, 1024, 768), 3, device=DEV)
+    hipt.set_compute_dtype("fp32")
+    before = N.calls
+    patches, a256, a4k = hipt._get_region_attention_scores(x, scale=4)
+    assert N.calls > before
+    assert isinstance(a256, np.ndarray) and a256.shape == (12, 6, 64, 64) and a4k.shape == (6, 256, 192)
+    assert patches.shape == (12, 64, 64, 3) and patches.dtype == np.uint8 and np.array_equal(patches, g["patches_u8"])
+    e256, e4k = md(a256, g["attention_256"]), md(a4k, g["attention_4k"])
+    print(f"region attention scores vs reference: attention_256 {e256:.1e}, attention_4k {e4k:.1e}")
+    assert e256 < TOL and e4k < TOL
+    # a raw uint8 image (what the reference passes: a PIL region) goes through eval_transforms and gives the same shapes
+    img = ((x[0].permute(1, 2, 0) * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
+    p2, b256, b4k = hipt._get_region_attention_scores(img, scale=1)
+    assert p2.shape == (12, 256, 256, 3) and b256.shape == (12, 6, 256, 256) and b4k.shape == (6, 1024, 768)
+    from hipt_abmil_atec23_amd.hipt_model_utils import eval_transforms, tensorbatch2im
+    want = tensorbatch2im(eval_transforms()(img).reshape(3, 4, 256, 3, 256).permute(1, 3, 0, 2, 4).reshape(12, 3, 256, 256))
+    assert np.array_equal(p2, want)  # patch k = p1 * h_256 + p2 (index work: bit-exact)
+    assert abs(float(b256[:, :, ::16, ::16].sum(axis=(2, 3)).max()) - 1.0) < 0.05  # probabilities minus the [CLS] column
+
+
 def test_hipt4k_full_region_fp32_and_bf16(hipt):
     """BASELINE config 3 shape: one 4096x4096 region = 256 patches -> ViT-4K over the 16x16 grid."""
     g = golden("hipt4k_4096")

@@ -334,9 +334,46 @@ def test_extract_slide_coalesces_batch_one_loader_batches(tmp_path):
     assert calls == [(3, 3, 8, 8), (2, 3, 4, 4), (3, 3, 8, 8)] and out.shape == (8, 4)
     assert torch.equal(out[:, 0], torch.tensor([0., 1., 2., 0., 1., 0., 1., 0.]))
     calls.clear()
-    big = [(torch.ones(3, 3, 8, 8), torch.zeros(3, 2)), (torch.ones(6, 3, 8, 8), torch.zeros(6, 2)), (torch.ones(1, 3, 8, 8), torch.zeros(1, 2))]
+    big = [(torch.ones(n, 3, 8, 8), torch.zeros(n, 2, dtype=torch.int64)) for n in (3, 6, 1)]
     torch.load(extract_slide(model, big, str(tmp_path), "big", coalesce=8))             # loader batches are never split
     assert calls == [(9, 3, 8, 8), (1, 3, 8, 8)]
+
+
+def test_coords_survive_bit_for_bit(tmp_path):
+    """coords [n, 2] are integer pass-through data (extract_features_fp.py:169-171, utils/file_utils.py:16-35).
+    They are persisted on a host without h5py too (sidecar coords_files/{slide}.npy), in append order, in the dtype the loader
+    handed over, bit for bit -- values above 2**53 included, which a detour through floats would destroy."""
+    from hipt_abmil_atec23_amd.feature_store import FeatureWriter, coords_path, extract_slide, load_coords
+    big = np.array([[2**62 + 1, -(2**61) - 3], [2**53 + 1, 7], [0, -1]], dtype=np.int64)
+    w = FeatureWriter(str(tmp_path), "s64", write_h5=False)
+    w.append(torch.zeros(3, 4), torch.from_numpy(big))          # a tensor batch ...
+    w.append(np.ones((2, 4), np.float32), big[:2][::-1])         # ... and a (non-contiguous) numpy one
+    w.close()
+    got = load_coords(str(tmp_path), "s64")
+    assert got.dtype == np.int64 and got.shape == (5, 2) and np.array_equal(got, np.concatenate([big, big[:2][::-1]]))
+    assert got.tobytes() == np.concatenate([big, big[:2][::-1]]).tobytes()
+    assert os.path.isfile(coords_path(str(tmp_path), "s64")) and sorted(os.listdir(tmp_path / "pt_files")) == ["s64.pt"]
+    # the dtype of the loader survives (older patch files hold int32 coordinates); mixing dtypes or handing floats is an error
+    w = FeatureWriter(str(tmp_path), "s32", write_h5=False)
+    w.append(torch.zeros(2, 4), np.array([[1, 2], [3, 4]], dtype=np.int32))
+    with pytest.raises(TypeError, match="int64"):
+        w.append(torch.zeros(1, 4), np.array([[5, 6]], dtype=np.int64))
+    w.close()
+    assert load_coords(str(tmp_path), "s32").dtype == np.int32
+    with pytest.raises(TypeError, match="integers"):
+        FeatureWriter(str(tmp_path), "sf", write_h5=False).append(torch.zeros(1, 4), torch.zeros(1, 2))
+    with pytest.raises(FileNotFoundError):
+        load_coords(str(tmp_path), "never_written")
+    # through the driver loop: one region per loader batch, gathered 8 per call with a ragged tail -- coordinates stay aligned
+    # with the feature rows (the stand-in model writes a region's id into its feature, the loader the same id into its coords)
+    model = lambda r: r.float().mean(dim=(1, 2, 3)).unsqueeze(1).repeat(1, 4)
+    loader = [(torch.full((1, 3, 8, 8), float(k)), torch.tensor([[1000003 * k, -k]], dtype=torch.int64)) for k in range(19)]
+    for name, co in (("co8", 8), ("co1", 1), ("co5", 5)):
+        feats = torch.load(extract_slide(model, loader, str(tmp_path), name, coalesce=co))
+        c = load_coords(str(tmp_path), name)
+        assert c.dtype == np.int64 and c.shape == (19, 2)
+        assert np.array_equal(c[:, 0], 1000003 * np.arange(19)) and np.array_equal(c[:, 1], -np.arange(19))
+        assert torch.equal(feats[:, 0], torch.arange(19.))       # row i of the features <-> row i of the coordinates
 
 
 def test_prepare_img_tensor_uint8_interleaved():

@@ -85,6 +85,18 @@ def test_hipt4k_composite_small_region():
     assert maxdiff(out, g["out"]) < TOL
 
 
+def test_region_attention_scores():
+    """HIPT_4K._get_region_attention_scores (hipt_4k.py:135-160), tensor half, against the reference ViTs' own maps."""
+    g = golden("hipt4k_attn_1024x768_s4")
+    p256 = P(synth.vit_param_specs("vit256"), 256)
+    p4k = P(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096)
+    x = synth.hash_uniform_np((1, 3, 1024, 768), 3)
+    b, a256, a4k = O.region_attention_scores(x, p256, p4k, scale=4)
+    assert a256.shape == g["attention_256"].shape == (12, 6, 64, 64) and a4k.shape == g["attention_4k"].shape == (6, 256, 192)
+    assert maxdiff(a256, g["attention_256"]) < 1e-6 and maxdiff(a4k, g["attention_4k"]) < 1e-6
+    assert np.array_equal(((b.transpose(0, 2, 3, 1) + 1) / 2.0 * 255.0).astype(np.uint8), g["patches_u8"])  # index work: bit-exact
+
+
 def test_patchify_and_grid_order_bit_exact():
     """Index work is bit-exact: patch k = p1*h_256 + p2 and grid[0,:,i,j] = f[i*h_256+j]."""
     img = np.arange(1 * 2 * 512 * 768, dtype=np.float32).reshape(1, 2, 512, 768)

@@ -1,8 +1,10 @@
 """Slide-level driver (BASELINE configs[4] / SURVEY.md §8d config 5, §8e): sharding, feature store, per-slide CLAM_SB,
 the one all-gather.  CPU part: two gloo ranks with stand-in callables (the driver holds no device code).  GPU part
 (-m gpu): the real HIP models at world size 1 against the numpy oracle, and at world size 2 over RCCL when two GPUs exist."""
+import json
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -78,6 +80,8 @@ def test_process_slides_two_gloo_ranks_equal_one_process(tmp_path):
     for i, s in enumerate(slides):  # the feature store holds each slide's [n, d] features (extract_features_fp.py:248-255)
         f = FS.load_bag(str(tmp_path), s.slide_id)
         assert torch.equal(f, ref.local_features[i].float())
+        c = FS.load_coords(str(tmp_path), s.slide_id)  # ... and its coords [n, 2], int64, row for row (extract_features_fp.py:169-171)
+        assert c.dtype == np.int64 and np.array_equal(c, s.coords(range(s.n_regions)).numpy())
 
 
 def test_process_slides_sampling_skip_existing_and_coords(tmp_path):
@@ -244,6 +248,75 @@ def _nccl_worker(rank, world, port, q):
     q.put((rank, run.local_slides, run.logits.cpu().numpy(), [a.cpu().numpy() for a in run.a_raw]))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
+
+
+def _nccl_one_rank_worker(port, q):
+    """ONE rank under the launcher's environment: init_from_env creates a real 1-rank RCCL communicator, and the driver's
+    all-reduce + all-gather run over it on DEVICE tensors (no local-copy shortcut: distributed.grouped())."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from hipt_abmil_atec23_amd import distributed as D
+    from hipt_abmil_atec23_amd import pipeline as PL
+    r, w, local = D.init_from_env()
+    info = D.group_info()
+    calls = {"all_reduce": 0, "all_gather": 0}
+    real_ar, real_ag = torch.distributed.all_reduce, torch.distributed.all_gather_into_tensor
+
+    def ar(t, *a, **k):
+        calls["all_reduce"] += int(t.is_cuda)
+        return real_ar(t, *a, **k)
+
+    def ag(o, t, *a, **k):
+        calls["all_gather"] += int(t.is_cuda and o.is_cuda)
+        return real_ag(o, t, *a, **k)
+
+    torch.distributed.all_reduce, torch.distributed.all_gather_into_tensor = ar, ag
+    dev = torch.device("cuda", local)
+    m, c = _gpu_models(dev)
+    run = PL.process_slides(m, c, _gpu_slides(), r, w, device=dev, regions_per_call=2, keep_features=True)
+    q.put((info, calls, run.local_slides, run.logits.cpu().numpy(), [a.cpu().numpy() for a in run.a_raw],
+           {i: f.cpu().numpy() for i, f in run.local_features.items()}))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_config5_pipeline_one_rank_rccl_matches_oracle():
+    """First RCCL contact on the hardware at hand: the slide driver + gather_slide_outputs over a ONE-rank
+    process group with backend "nccl" (= RCCL), device tensors through the collectives, outputs against the numpy oracle as in
+    test_config5_pipeline_world1_matches_oracle.  In a child process: the group must not outlive the test."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    info, calls, local_slides, logits, a_raw, feats = q.get(timeout=500)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert info == {"backend": "nccl", "ranks": 1}
+    assert calls["all_reduce"] >= 1 and calls["all_gather"] == 1, calls  # the shape agreement + THE one all-gather, on the device
+    assert local_slides == [0, 1, 2, 3] and logits.shape == (4, 2)
+    _check_against_oracle(logits, a_raw, feats, _gpu_slides())
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_one_rank_through_the_launcher_reports_rccl_ranks():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (the driver's launch form, at the one GPU there is):
+    the same JSON line as a plain launch plus "rccl_ranks" taken from the live process group; the timed gather and config 5 ran
+    over RCCL."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--regions", "3", "--profile-steps", "0",
+           "--no-cpu-baseline", "--no-extras", "--slides", "4", "--slide-sample", "2"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["rccl_ranks"] == 1 and d["collective_backend"] == "nccl" and d["n_gpus"] == 1 and d["value"] > 0
+    assert d["config5"]["gathered_logits_shape"] == [4, 2]
+    assert d["selfcheck"] in ("ok", "skipped"), d.get("selfcheck_detail")
 
 
 @pytest.mark.gpu
