@@ -131,6 +131,25 @@ int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* 
     return hipt_gemm_launch(p, dtype, ALOAD_PLAIN, flags, st);
 }
 
+// Linears over ONE row per sequence (the [CLS] rows: M = nseq): always in slices the small-M GEMM takes (gemm.hip: a wave per 16 x 32
+// output tile, an element's summation order depends on its column only), however many sequences the call holds -- so that a
+// sequence's bits do not depend on its company (feature_store.extract_slide gathers loader batches on that promise), and 2 048 rows
+// are two launches as the gather + tiled GEMM they replace were.  a_row_step > 0: A is a bf16 activation image, GEMM row r its row
+// r * a_row_step (slices start on whole 16-row fragments, which occupy the bytes of their rows).
+constexpr int ROWS_SLICE = 1024;
+int rows_linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc, int M, int N, int K, int dtype,
+                hipStream_t st, int a_row_step = 0) {
+    const size_t e = esz(dtype);
+    for (int r0 = 0; r0 < M; r0 += ROWS_SLICE) {
+        const int m = M - r0 < ROWS_SLICE ? M - r0 : ROWS_SLICE;
+        const size_t arow = (size_t)r0 * (a_row_step > 0 ? a_row_step : 1);
+        int rc = linear((const char*)A + arow * lda * e, lda, W, ldw, bias, nullptr, (char*)out + (size_t)r0 * ldc * e, ldc, m, N, K, dtype, 0, st, 0, nullptr,
+                        nullptr, 0.f, a_row_step);
+        if (rc) return rc;
+    }
+    return HIPT_OK;
+}
+
 // emit_last: the MLP of block b1-1 also writes LayerNorm-1 of block b1 on its output rows (bf16, s.att), for a caller
 // that runs block b1 itself (the [CLS]-pruned last block); *have_xn tells it whether that happened
 // img_ok / x_img_out: the caller owns x and accepts it back as an fp32 activation image (kernels.h): blocks after the
@@ -193,8 +212,8 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
                 char* qcls = qa + al256((size_t)nseq * D * 2);                   // [nseq, 3 D] bf16 + 1 KiB the kernel's row DMA may read past the end
                 // (nseq rows are a handful of the streaming kernel's 192-row tiles -- 11 CUs for 2 048 patches; the generic GEMM tiles N as well.
                 //  Up to 1 088 sequences the small-M GEMM reads the [CLS] rows out of the image itself: one launch, not two)
-                if (!hipt_generic_only() && hipt_gemm_arows_supported(nseq, D, dt, ALOAD_PLAIN, 0)) {
-                    PROF(PC_CLSROWS, linear(s.att, D, b.qkv_w, D, b.qkv_b, nullptr, qcls, 3 * D, nseq, 3 * D, D, dt, 0, st, 0, nullptr, nullptr, 0.f, w->ntok));
+                if (!hipt_generic_only() && hipt_gemm_arows_supported(nseq < ROWS_SLICE ? nseq : ROWS_SLICE, D, dt, ALOAD_PLAIN, 0)) {
+                    PROF(PC_CLSROWS, rows_linear(s.att, D, b.qkv_w, D, b.qkv_b, qcls, 3 * D, nseq, 3 * D, D, dt, st, w->ntok));
                 } else {
                     PROF(PC_CLSROWS, hipt_gather_cls_bf16_launch(s.att, qa, nseq, w->ntok, D, st, 1));
                     PROF(PC_CLSROWS, linear(qa, D, b.qkv_w, D, b.qkv_b, nullptr, qcls, 3 * D, nseq, 3 * D, D, dt, 0, st));
@@ -298,7 +317,7 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
             char* qa = (char*)s.hid + 4096 + al256((size_t)nseq * D * 4);
             char* qcls = qa + al256((size_t)nseq * D * 2);
             PROF(PC_LASTCLS, hipt_gather_cls_bf16_launch(s.att, qa, nseq, w->ntok, D, st, 1));
-            PROF(PC_LASTCLS, linear(qa, D, b.qkv_w, D, b.qkv_b, nullptr, qcls, 3 * D, nseq, 3 * D, D, w->dtype, 0, st));
+            PROF(PC_LASTCLS, rows_linear(qa, D, b.qkv_w, D, b.qkv_b, qcls, 3 * D, nseq, 3 * D, D, w->dtype, st));
             q.img = 0;
             PROF(PC_LASTCLS, hipt_qkv_attn_cls_launch(s.att, b.qkv_att_pk, b.qkv_b, qcls, s.qkv, nseq, attn_scale(w), st));
             att_rows = s.qkv;
@@ -329,7 +348,7 @@ static int run_last_block_cls(const hipt_vit_weights* w, float* x, int nseq, con
     }
     PROF(PC_OTHER, hipt_gather_cls_launch(x, xc, nseq, (int64_t)w->ntok * D, D, st, x_img ? 1 : 0));
     // (nseq rows: the generic GEMM tiles N as well -- see the side GEMM of the fused blocks)
-    PROF(PC_LASTCLS, linear(att_rows, D, b.proj_w, D, b.proj_b, nullptr, s.xn, D, nseq, D, D, w->dtype, 0, st));
+    PROF(PC_LASTCLS, rows_linear(att_rows, D, b.proj_w, D, b.proj_b, s.xn, D, nseq, D, D, w->dtype, st));
     MlpParams m;
     memset(&m, 0, sizeof(m));
     m.x = xc; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;

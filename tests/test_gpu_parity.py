@@ -730,13 +730,19 @@ def test_extract_slide_4096_regions_gathered_ragged_tail_same_bits(hipt, tmp_pat
     regions = [synth.hash_uniform_torch((1, 3, 4096, 4096), 900 + i, device=DEV) for i in range(11)]
     batches = [(r, torch.tensor([[4096 * i, 4096 * (i % 3)]], dtype=torch.int64)) for i, r in enumerate(regions)]
     hipt.set_compute_dtype("bf16")
+    old_streams = hipt.streams
     try:
+        hipt.streams = 2  # (the class default: one region per call = two patch ranges on two streams)
         one = torch.load(extract_slide(hipt, batches, str(tmp_path), "co1", coalesce=1))
-        for co in (8, 5):
+        # one stream: a gathered call is 2 048 patches in ONE pass (its [CLS]-row GEMMs are sliced into small-M launches: capi.hip
+        # rows_linear); two streams: two groups of four regions
+        for streams, co in ((1, 8), (2, 8), (1, 5)):
+            hipt.streams = streams
             got = torch.load(extract_slide(hipt, batches, str(tmp_path), f"co{co}", coalesce=co))
-            assert got.shape == (11, 192) and torch.equal(one, got), f"coalesce={co}: max diff {float((one - got).abs().max())}"
+            assert got.shape == (11, 192) and torch.equal(one, got), f"coalesce={co}, {streams} stream(s): max diff {float((one - got).abs().max())}"
             assert np.array_equal(load_coords(str(tmp_path), f"co{co}"), load_coords(str(tmp_path), "co1"))
     finally:
+        hipt.streams = old_streams
         hipt.set_compute_dtype("fp32")
     assert load_coords(str(tmp_path), "co1").tolist() == [[4096 * i, 4096 * (i % 3)] for i in range(11)]
 
