@@ -506,7 +506,7 @@ def _from_image(img):
     return img.view(m // 16, 12, 4, 16, 8).permute(0, 3, 1, 2, 4).contiguous().view(m, 384)
 
 
-@pytest.mark.parametrize("nseq", [16, 48])
+@pytest.mark.parametrize("nseq", [16, 48, 144, 528])  # (>= 128 patches: the one-wave-per-SIMD kernel; 528: two or three patches per workgroup)
 def test_attention_unit_fused_kernel_vs_torch_and_two_kernels(vit256, nseq):
     """The attention unit of one block (qkv Linear + softmax(q k^T * scale) v, vision_transformer.py:121-128) through
     hipt_vit_attention_unit: the fused QKV + attention kernel, the QKV GEMM + attention kernel pair, and an fp32 PyTorch

@@ -1,0 +1,1370 @@
+// ROUND-5 EXPERIMENT, not built into the library: csrc/qkv_attention.hip of that round plus `qkv_attn4_kernel`, the fused QKV + attention
+// kernel at ONE wave per SIMD (4 waves x 64 tokens, the token operands pinned in the accumulator file through "a" operands of hand-written
+// MFMA statements, every weight fragment read once for two MFMAs, a workgroup per patch) and a two-units-in-flight weight ring for both
+// kernels.  Correct (tests/test_gpu_parity.py::test_attention_unit_fused_kernel_vs_torch_and_two_kernels at 144 and 528 patches passed on it)
+// and SLOWER: 967-982 us per 2048-patch attention unit against 861-880 for the 8-wave kernel on the same box (tools/attn_unit_bench.py).
+// Counters (rocprofv3, per (patch, head) work unit and wave): 32.7 k cycles = 15.2 k issuing (2 680 vector instructions: 299 v_exp, 486 v_add,
+// 304 v_fma, 277 v_cvt_pk, 387 v_accvgpr_read of score tiles hipcc parks in the accumulator file) + 10.5 k issue stalls + 6.9 k waits, beside
+// 14.6 k cycles of matrix pipe: with one wave per SIMD the VALU-bound attention half of a unit (softmax: ~16 k cycles, matrix pipe idle) and
+// the MFMA-bound GEMM half (9.2 k cycles, VALU idle) run one after the other; the 8-wave kernel's second wave per SIMD overlaps them for free.
+// LDS fragment reads did halve (SQ_LDS_IDX_ACTIVE 80.6 M against 119.6 M) and bought nothing; the deeper weight ring (request at step 1, landing
+// wait at step 15 of every unit) changed neither kernel (865 vs 865 us): the ring was not what the waves wait for.  DESIGN.md, round 5.
+// QKV projection + softmax attention of one LayerNorm-chained ViT-256 block in ONE kernel (Attention.forward,
+// HIPT_4K/vision_transformer.py:119-128, lines 121-128: qkv Linear, q k^T * scale, softmax, P v): the q | k | v tensor
+// ([M, 1152] bf16, 1.2 GB per 2048 patches, written by the QKV GEMM and read back by the attention kernel) never exists.
+//
+// Shape: D = 384, 6 heads of 64, 257 tokens per sequence (one 256 x 256 patch: 256 tokens + [CLS]); bf16 operands, fp32
+// accumulation, fp32 softmax.  Input xn = LayerNorm-1(x) as a bf16 ACTIVATION IMAGE (kernels.h), written by the previous
+// block's fused MLP; output = the attention output (before proj) as one, read by the proj GEMM.
+//
+// One persistent 8-wave workgroup per CU walks patches; per patch it walks the 6 heads:
+//   GEMM phase   wave w owns the patch's tokens 1 + 32 w .. 32 w + 32 as ONE 32-column B operand of v_mfma_f32_32x32x16_bf16
+//                (24 k-steps = 96 registers, loaded from the image; re-loaded per head because the scores need the registers);
+//                the head's [192, 384] weight slice streams through a 3 x 24 KiB LDS-DMA ring as six units of 32 output
+//                columns (K K V V Q Q), every unit 24 A fragments of 1 KiB in operand order (image made once by
+//                hipt_qkv_attn_pack_launch: a DMA piece and a fragment read are 1 KiB of consecutive bytes).  D = W X^T lands
+//                with the token on the lane and the output column in the registers:
+//                  K^T tiles -> packed and written as the A-operand fragments of the score product (1 KiB per (key tile, k-step));
+//                  V^T tiles -> written row-major [key][32 dims] (64-byte rows) for the transposing LDS read;
+//                  Q^T tiles -> converted in place into the B operand of the score product (accumulator-as-operand).
+//   attention    S^T[key][query] = K Q^T per 32-key tile (9 tiles: 8 of patch tokens + one holding the [CLS] key), softmax over
+//                the registers + one cross-half exchange, P^T packed in place as the B operand of O^T = V^T P^T.  No barrier
+//                inside the phase: the two waves of a SIMD drift apart, one's exponentials run under the other's MFMAs.
+//   [CLS]        257 = 8 x 32 + 1.  The [CLS] row's q | k | v come from a side GEMM over the nseq [CLS] rows (capi.hip), staged
+//                per patch into LDS by DMA.  Its key / value are row 256 of the K / V images; its QUERY is spread over the
+//                waves by key range: wave w does the [CLS] query against its own 32 keys (8 + 6 MFMAs with one live column),
+//                the partial (max, sum, o[64]) goes through LDS and one wave merges the eight.
+// LDS: ring 72 KiB | K image 36 KiB | V image 36 KiB | bias 4.5 KiB | [CLS] partials | [CLS] q k v rows = 158.75 KiB.
+// HBM per patch: xn read (197 KB; the five re-reads per patch are L2 / MALL hits) + output written (197 KB).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "common.h"
+#include "kernels.h"
+#include "pipe_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int D = 384, NTOK = 257, HEADS = 6;
+constexpr int UNIT = 24576, NUNIT = 36;                  // one unit = 32 output columns x 384 k = 24 fragments of 1 KiB
+constexpr int OFF_K = 3 * UNIT;                          // K image: [9 key tiles][4 (d tile, k-step)][1 KiB]
+constexpr int VSUB = 288 * 64;                           // V image: two [288 keys][32 dims] sub-images
+constexpr int OFF_V = OFF_K + 9 * 4096;
+constexpr int OFF_BIAS = OFF_V + 2 * VSUB;               // [36 units][2 lane halves][16] floats in accumulator order
+constexpr int CLSP_W = 68 * 4;                           // one wave's [CLS] partial: m, l, -, -, o[64]
+constexpr int OFF_CLSP = OFF_BIAS + NUNIT * 32 * 4;      // [2 (head parity)][8 waves]
+constexpr int CLSROW = 3072;                             // q | k | v of one [CLS] row (2 304 B), DMA'd as three 1 KiB pieces
+constexpr int OFF_CLSROW = OFF_CLSP + 2 * 8 * CLSP_W;    // [2 (patch parity)]
+constexpr int LDS_BYTES = OFF_CLSROW + 2 * CLSROW;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+// row of qkv_w (= output column of the QKV Linear) that A-operand row c of unit U holds: units of a head are K K V V Q Q
+__host__ __device__ __forceinline__ int unit_row(int U, int c) {
+    const int h = U / 6, u = U % 6;
+    const int base = u < 2 ? D + 64 * h + 32 * u : (u < 4 ? 2 * D + 64 * h + 32 * (u - 2) : 64 * h + 32 * (u - 4));
+    return base + c;
+}
+
+// one thread per 16-byte chunk of the image: unit U, fragment s, lane (r, hh) <- W[unit_row(U, r)][16 s + 8 hh ..+7]
+__global__ void qkv_attn_pack_kernel(const bf16_t* __restrict__ W, u32x4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NUNIT * 24 * 64) return;
+    const int U = i / (24 * 64), s = (i >> 6) % 24, lane = i & 63;
+    out[i] = *(const u32x4*)(W + (int64_t)unit_row(U, lane & 31) * D + 16 * s + 8 * (lane >> 5));
+}
+
+#define DSRTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define DSW128(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(off) : "memory")
+#define DSW64(addr, val, off) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(off) : "memory")
+#define DSW32(addr, val, off) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(off) : "memory")
+#define GLD128(dst, ptr, off) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(off))
+
+__device__ __forceinline__ u32x2 lds_ld64w(uint32_t a) {
+    u32x2 v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// registers 8 s .. 8 s + 7 of an accumulator tile as one bf16 operand fragment (accumulator-as-operand: k slot (half hh,
+// element j) <-> tile row 16 s + 8 (j >> 2) + 4 hh + (j & 3); the other operand is read / written in that same order)
+template <int S>
+__device__ __forceinline__ u32x4 pack8(const f32x16& a) {
+    u32x4 o;
+    o[0] = pack_bf16x2(a[8 * S + 0], a[8 * S + 1]);
+    o[1] = pack_bf16x2(a[8 * S + 2], a[8 * S + 3]);
+    o[2] = pack_bf16x2(a[8 * S + 4], a[8 * S + 5]);
+    o[3] = pack_bf16x2(a[8 * S + 6], a[8 * S + 7]);
+    return o;
+}
+
+struct QkvAttnParams {
+    const char* xn;        // bf16 activation image [M, 384]: LayerNorm-1(x)
+    const char* wpk;       // the weight image (hipt_qkv_attn_pack_launch)
+    const float* bias;     // qkv_b [1152]
+    const char* qkv_cls;   // bf16 [nseq][1152] (+ 1 KiB of slack): q | k | v of the [CLS] rows
+    char* out;             // bf16 activation image [M, 384]: attention output
+    int nseq;
+    float sl2e;            // scale * log2(e)
+    unsigned out_bytes;
+    int nslots;            // workgroups per XCD: workgroup id -> XCD id % 8 (ids that differ by 8 share an XCD), slot id / 8
+    int px;                // patches per XCD: XCD x owns patches [x px, (x + 1) px); its work units (patch, head), head fastest, go round
+                           // its slots: slot j takes units j, j + nslots, .. -- the 32 units in flight on an XCD are 5-6 patches, whose
+                           // rows the six heads read through ONE L2 instead of from the fabric six times
+    unsigned long long* stamps;  // diagnostic builds: per-workgroup cycle sums of the phases (8 per workgroup), or null
+};
+
+// phase stamps (make DEBUG_STAMPS=1 only): wave 0 of every workgroup adds the cycles between consecutive marks to a sum per phase
+#ifdef HIPT_QKVATT_STAMPS_BUILD  // (-DHIPT_QKVATT_STAMPS_BUILD on top of DEBUG_STAMPS: the stamps perturb the kernel, the ablation variants must not carry them)
+#define QST_ON(ptr) ((ptr) != nullptr)
+#else
+#define QST_ON(ptr) false
+#endif
+#define QSTAMP_DECL unsigned long long st_prev = 0, st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define QSTAMP_BEGIN()                                                          \
+    do {                                                                        \
+        if (QST_ON(p.stamps) && w == 0) st_prev = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define QSTAMP(k)                                                               \
+    do {                                                                        \
+        if (QST_ON(p.stamps) && w == 0) {                               \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
+            st_sum[k] += t_ - st_prev;                                          \
+            st_prev = t_;                                                       \
+        }                                                                       \
+    } while (0)
+
+
+// DBG (diagnostic builds only, HIPT_QKVATT_DBG): 1 = no weight DMA / ring syncs, 2 = no weight fragment reads, 4 = no attention
+// phase, 8 = no GEMM MFMAs, 16 = no [CLS]-query section, 32 = no exponentials, 64 = no operand loads -- timing ablations,
+// the results are garbage
+// CLSONLY: the [CLS]-pruned last block (capi.hip, run_last_block_cls): only token 0 of a patch asks a question there, so a work unit is the K
+// and V products of its head (4 of the 6 ring units), the [CLS] query against them, and ONE output row per patch, written compact [nseq, 384]
+// -- K and V of the block never reach HBM either (they were 0.8 GB written and 2.3 GB fetched by the one-query attention kernel).
+template <int DBG, bool CLSONLY = false>
+__global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p) {
+    constexpr int NU = CLSONLY ? 4 : 6, NG = 24 * NU;  // ring units / GEMM steps of a work unit
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // this workgroup's work units: (patch, head) pairs of its XCD (QkvAttnParams)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    auto unit_of = [&](int i, int& b_, int& h_) {  // the i-th unit of this workgroup; false: past the end
+        const int U = slot + p.nslots * i, bq = U / HEADS;
+        h_ = U - HEADS * bq;
+        b_ = xcd * p.px + bq;
+        return bq < p.px && b_ < p.nseq;
+    };
+    int hs, g0;
+    const bool any = unit_of(0, g0, hs);
+
+    // ---- one-time LDS contents (no DMA in flight yet: plain stores) ----
+    {
+        float* bias_s = (float*)(smem + OFF_BIAS);
+        for (int i = tid; i < NUNIT * 32; i += 512) {
+            const int U = i >> 5, hb = (i >> 4) & 1, ii = i & 15;
+            bias_s[i] = p.bias[unit_row(U, (ii & 3) + 8 * (ii >> 2) + 4 * hb)];
+        }
+        uint32_t* kz = (uint32_t*)(smem + OFF_K + 8 * 4096);  // key tile 8: row 0 = the [CLS] key (written per patch), rows 1.. stay zero
+        for (int i = tid; i < 1024; i += 512) kz[i] = 0u;
+        for (int t = 0; t < 2; ++t) {                          // V rows 256 .. 287: row 256 = the [CLS] value, the rest stay zero
+            uint32_t* vz = (uint32_t*)(smem + OFF_V + t * VSUB + 256 * 64);
+            for (int i = tid; i < 512; i += 512) vz[i] = 0u;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t lbase = lds_addr(smem);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.out_bytes, 0x00020000);
+
+    // ---- weight stream: the six ring units of a work unit's head, work unit after work unit; ring unit n into ring slot n % 3; wave w moves
+    //      pieces w, w + 8, w + 16 ----
+    int iU = 0, islot = 0, ihs = hs, iwork = 0;  // ring unit / slot / head / work unit being requested
+    auto issue_unit = [&]() __attribute__((always_inline)) {
+        const char* src = p.wpk + (size_t)(ihs * 6 + iU) * UNIT + lane * 16;
+        char* dst = smem + islot * UNIT;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if constexpr ((DBG & 1) == 0) glds16(src + (w + 8 * j) * 1024, dst + (w + 8 * j) * 1024);
+        islot = islot + 1 == 3 ? 0 : islot + 1;
+        if (++iU == NU) {  // on to the next work unit's head (past the last one: any head -- pieces nobody consumes)
+            iU = 0;
+            int nb_, nh_;
+            if (unit_of(++iwork, nb_, nh_)) ihs = nh_;
+        }
+    };
+    auto cls_dma = [&](int b, int par) __attribute__((always_inline)) {  // (wave 0) the [CLS] row of patch b -> LDS
+        const char* src = p.qkv_cls + (size_t)b * (3 * D * 2) + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) glds16(src + j * 1024, smem + OFF_CLSROW + par * CLSROW + j * 1024);
+    };
+
+    // this wave's tokens as the B operand: 24 k-steps, lane (r, hh) holds row R, 16-byte chunk 2 s + hh of the image
+    u32x4 xop[24];
+    auto load_xop = [&](int b) __attribute__((always_inline)) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int64_t R = (int64_t)b * NTOK + 1 + 32 * w + (ln & 31);
+        const char* x0 = p.xn + (R >> 4) * 12288 + (R & 15) * 16 + (ln >> 5) * 256;
+        const char* x1 = x0 + 4096;
+        const char* x2 = x0 + 8192;
+        sfor<0, 24>([&](auto S_) __attribute__((always_inline)) {
+            constexpr int s = decltype(S_)::value;
+            u32x4& d = xop[s];
+            const char* a0 = x0;  // (plain uses: an asm operand inside `if constexpr` alone does not capture the variable)
+            const char* a1 = x1;
+            const char* a2 = x2;
+            if constexpr (s < 8) GLD128(d, a0, s * 512);
+            else if constexpr (s < 16) GLD128(d, a1, (s - 8) * 512);
+            else GLD128(d, a2, (s - 16) * 512);
+        });
+    };
+    // (the asm loads land asynchronously: nothing may touch xop between them and this statement, which is the counted wait
+    //  AND the point from which the compiler may use the registers)
+#define XOP_FENCE(N)                                                                                                              \
+    asm volatile("s_waitcnt vmcnt(" #N ") ; XOP_FENCE"                                                                            \
+                 : "+v"(xop[0]), "+v"(xop[1]), "+v"(xop[2]), "+v"(xop[3]), "+v"(xop[4]), "+v"(xop[5]), "+v"(xop[6]), "+v"(xop[7]), \
+                   "+v"(xop[8]), "+v"(xop[9]), "+v"(xop[10]), "+v"(xop[11]), "+v"(xop[12]), "+v"(xop[13]), "+v"(xop[14]),           \
+                   "+v"(xop[15]), "+v"(xop[16]), "+v"(xop[17]), "+v"(xop[18]), "+v"(xop[19]), "+v"(xop[20]), "+v"(xop[21]),         \
+                   "+v"(xop[22]), "+v"(xop[23])::"memory")
+
+    // ---- merge of the eight [CLS]-query partials of one patch: one wave, lane = output dimension ----
+    auto merge_cls = [&](int b, int hs, int pq) __attribute__((always_inline)) {
+        int ln = lane;  // (opaque copy: see the patch loop)
+        asm volatile("" : "+v"(ln));
+        const uint32_t base = lbase + OFF_CLSP + pq * 8 * CLSP_W, obase = base + 16 + ln * 4;
+        float mk[8], lk[8], ok[8];
+        sfor<0, 8>([&](auto K_) __attribute__((always_inline)) {
+            constexpr int k = decltype(K_)::value;
+            float &m_ = mk[k], &l_ = lk[k], &o_ = ok[k];
+            const uint32_t ba = base, oa = obase;
+            asm volatile("ds_read_b32 %0, %3 offset:%5\n\tds_read_b32 %1, %3 offset:%6\n\tds_read_b32 %2, %4 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(m_), "=&v"(l_), "=&v"(o_)
+                         : "v"(ba), "v"(oa), "n"(k * CLSP_W), "n"(k * CLSP_W + 4));
+        });
+        float mx = mk[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) mx = fmaxf(mx, mk[k]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float f = __builtin_amdgcn_exp2f((mk[k] - mx) * p.sl2e);
+            L += f * lk[k];
+            o += f * ok[k];
+        }
+        const int64_t R = (int64_t)b * NTOK;  // the [CLS] row; column 64 hs + lane = chunk 8 hs + (lane >> 3), element lane & 7
+        const int kc = 8 * hs + (ln >> 3);
+        bf16_t* dst = CLSONLY ? (bf16_t*)p.out + (int64_t)b * D + 64 * hs + ln
+                              : (bf16_t*)(p.out + (R >> 4) * 12288 + (kc >> 2) * 1024 + (kc & 3) * 256 + (R & 15) * 16) + (ln & 7);
+        *dst = (bf16_t)(o / L);
+    };
+
+    QSTAMP_DECL;
+    int pq = 0;          // parity of the patch counter: which [CLS] partial buffer / [CLS] row buffer
+    int prev_b = -1, prev_hs = 0;  // work unit whose partials wait for their merge
+    if (!any) return;  // (uniform: a workgroup without work)
+    if (w == 0) cls_dma(g0, 0);
+    issue_unit();
+    issue_unit();
+    load_xop(g0);
+    // ring protocol: unit n is consumed from slot n % 3.  In the MIDDLE of unit n every wave waits for its pieces of unit n + 1,
+    // all meet at a barrier (so unit n + 1 has landed for everyone, and everyone has left unit n - 1), and unit n + 2 is
+    // requested into the slot of unit n - 1.  The fragment reads then run across unit boundaries without a restart.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // unit 0 has landed
+    int cslot = 0;                 // slot of the unit being consumed
+
+    constexpr int PF = 7;          // weight fragments requested ahead of the MFMA that uses them (8 register sets)
+    const f32x16 Z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = g0, nb = 0, nhs = 0, last_wi = 0;
+    bool nvalid = unit_of(1, nb, nhs);
+    for (int wi = 0;; ++wi, pq ^= 1) {
+        // Per-lane addresses are re-derived per patch from an opaque copy of the lane id: left loop-invariant, hipcc hoists a
+        // dozen of them out of the loop, spills them across the attention phase and reloads them inside the ring phases --
+        // and every scratch reload waits vmcnt(0), i.e. for the weight stream.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int r = ln & 31, hh = ln >> 5;
+        const uint32_t fa = lbase + ln * 16;  // this lane's 16 bytes of a 1 KiB fragment
+        // transposing V read: lane 4 q + pp of a 16-lane group supplies row (key) q, columns 4 pp .. of the group's 4 x 16 block
+        // (rows hold their 16-byte chunks rotated by (key >> 1) & 3 -- see the V^T tile store; every key base below is a multiple of 8)
+        const int vq = (ln & 15) >> 2, vch = (2 * ((ln >> 4) & 1) + ((ln & 3) >> 1) + 2 * hh + (vq >> 1)) & 3;
+        const uint32_t va = lbase + OFF_V + (4 * hh + vq) * 64 + vch * 16 + (ln & 1) * 8;
+        const int64_t Rl = (int64_t)b * NTOK + 1 + 32 * w + r;                          // this lane's token row (as a query)
+        const int orow = (int)((Rl >> 4) * 12288 + (Rl & 15) * 16) + 8 * hh + hs * 2048; // its bytes in the output image (this head's columns)
+        const uint32_t crow = lbase + OFF_CLSROW + pq * CLSROW;
+        u32x4 qop[2][2];
+        QSTAMP_BEGIN();
+        // ================= GEMM phase: six ring units = 144 MFMA steps, fragment reads PF steps ahead =================
+        {
+            u32x4 wf[8];
+            f32x4 bq[4];
+            f32x16 acc;
+            uint32_t sa = fa + cslot * UNIT, sn = sa;  // fragment base of the unit being consumed / of the next one
+            if constexpr (CLSONLY) XOP_FENCE(0);
+            else XOP_FENCE(8);  // (the eight youngest vector-memory operations are the previous patch's output stores: let them fly)
+            sfor<0, PF>([&](auto G_) __attribute__((always_inline)) {
+                constexpr int g = decltype(G_)::value;
+                u32x4& d = wf[g & 7];
+                const uint32_t a = sa;
+                if constexpr ((DBG & 2) == 0) DSR128(d, a, g * 1024);
+                else d = xop[g];
+            });
+            sfor<0, NG>([&](auto G_) __attribute__((always_inline)) {
+                constexpr int g = decltype(G_)::value, u = g / 24, s = g % 24;
+                // LDS operations younger than fragment g at its wait: the PF fragments behind it, and -- during the first PF
+                // steps of a unit -- the bias reads of this unit and the K / V writes of the unit before (in-order queue)
+                constexpr int wprev = u == 0 ? 0 : (u <= 2 ? 2 : (u <= 4 ? 4 : 0));
+                constexpr int ahead = g + PF < NG ? PF : NG - 1 - g;
+                if constexpr (s == 0) {
+                    const uint32_t ba = lbase + OFF_BIAS + ((hs * 6 + u) * 2 + hh) * 64;
+                    f32x4 &b0v = bq[0], &b1v = bq[1], &b2v = bq[2], &b3v = bq[3];
+                    DSR128(b0v, ba, 0);
+                    DSR128(b1v, ba, 16);
+                    DSR128(b2v, ba, 32);
+                    DSR128(b3v, ba, 48);
+                }
+                if constexpr (g + PF < NG && (DBG & 2) == 0) {
+                    u32x4& d = wf[(g + PF) & 7];
+                    if constexpr (s + PF < 24) {
+                        const uint32_t a = sa;
+                        DSR128(d, a, (s + PF) * 1024);
+                    } else {
+                        const uint32_t a = sn;
+                        DSR128(d, a, (s + PF - 24) * 1024);
+                    }
+                }
+                if constexpr ((DBG & 2) != 0) {
+                    LGKM(0);
+                } else if constexpr (s < PF) {
+                    LGKM((ahead + 4 + wprev < 15 ? ahead + 4 + wprev : 15));  // (a 4-bit counter: a smaller count only waits for more)
+                } else {
+                    LGKM(ahead);
+                }
+                if constexpr ((DBG & 8) != 0) {
+                    if constexpr (s == 0) acc = Z16;
+                    acc[s & 15] += __builtin_bit_cast(float, wf[g & 7][0]);
+                } else if constexpr (s == 0) {
+                    acc = mfma32(wf[g & 7], xop[s], Z16);
+                } else {
+                    acc = mfma32(wf[g & 7], xop[s], acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (s == 1) {
+                    // ---- ring, first half: everyone has left the unit before this one (its last fragment was in registers before the
+                    //      MFMA of step 23): request unit n + 2 into its slot -- TWO units in flight, as in the fused MLP's ring ----
+                    if constexpr ((DBG & 1) == 0) __builtin_amdgcn_s_barrier();
+                    if constexpr (u == 0) {
+                        // behind the first barrier of a patch every wave has left the previous patch's attention: its [CLS] partials are
+                        // complete (merge them), the K / V images are free, and the other [CLS] row buffer is free (fetch the next
+                        // patch's row).  BEFORE the unit's pieces: the second half's counted wait leaves exactly those in flight.
+                        if (prev_b >= 0 && w == ((wi - 1) & 7)) merge_cls(prev_b, prev_hs, pq ^ 1);
+                        if (w == 0 && nvalid) cls_dma(nb, pq ^ 1);
+                    }
+                    issue_unit();
+                }
+                if constexpr (s == 15) {
+                    // ---- ring, second half (before the first fragment request of the next unit, step 24 - PF): my pieces of unit n + 1
+                    //      have landed -- requested a unit and a half ago; the three youngest requests are unit n + 2's -- and, behind
+                    //      the barrier, everyone's ----
+                    if constexpr ((DBG & 1) == 0) {
+                        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    sn = fa + (cslot == 2 ? 0 : cslot + 1) * UNIT;
+                }
+                if constexpr (s == 23) {
+                    // ---- unit done: + bias, then K^T / V^T tiles to their LDS images, Q^T to its operand registers ----
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i] += bq[0][i];
+                        acc[4 + i] += bq[1][i];
+                        acc[8 + i] += bq[2][i];
+                        acc[12 + i] += bq[3][i];
+                    }
+                    if constexpr (u < 2) {          // K^T tile u: the two A-operand fragments (k-steps) of the score product
+                        const u32x4 k0 = pack8<0>(acc), k1 = pack8<1>(acc);
+                        const uint32_t ka = fa + OFF_K + w * 4096;
+                        DSW128(ka, k0, (u * 2 + 0) * 1024);
+                        DSW128(ka, k1, (u * 2 + 1) * 1024);
+                    } else if constexpr (u < 4) {   // V^T tile: row-major [key][32 dims], dims 8 q + 4 hh ..+3 from registers 4 q ..+3
+                        // (the four 16-byte chunks of a 64-byte row are rotated by (key >> 1) & 3: sixteen consecutive keys then write to
+                        //  eight bank groups instead of two -- 2-way instead of 8-way conflicts; the transposed reads stay conflict-free)
+                        const int rot = (r >> 1) & 3;
+                        const uint32_t vw = lbase + OFF_V + (u - 2) * VSUB + (32 * w + r) * 64 + 8 * hh;
+                        const uint32_t vw0 = vw + ((0 + rot) & 3) * 16, vw1 = vw + ((1 + rot) & 3) * 16, vw2 = vw + ((2 + rot) & 3) * 16, vw3 = vw + ((3 + rot) & 3) * 16;
+                        u32x2 o0, o1, o2, o3;
+                        o0[0] = pack_bf16x2(acc[0], acc[1]);   o0[1] = pack_bf16x2(acc[2], acc[3]);
+                        o1[0] = pack_bf16x2(acc[4], acc[5]);   o1[1] = pack_bf16x2(acc[6], acc[7]);
+                        o2[0] = pack_bf16x2(acc[8], acc[9]);   o2[1] = pack_bf16x2(acc[10], acc[11]);
+                        o3[0] = pack_bf16x2(acc[12], acc[13]); o3[1] = pack_bf16x2(acc[14], acc[15]);
+                        DSW64(vw0, o0, 0);
+                        DSW64(vw1, o1, 0);
+                        DSW64(vw2, o2, 0);
+                        DSW64(vw3, o3, 0);
+                    } else {                        // Q^T tile: stays in registers as the score product's B operand
+                        qop[u - 4][0] = pack8<0>(acc);
+                        qop[u - 4][1] = pack8<1>(acc);
+                    }
+                    sa = sn;
+                    cslot = cslot == 2 ? 0 : cslot + 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        }
+        QSTAMP(0);
+        // (the operands of the next work unit: requested here, landing under the [CLS] query; fenced at the head of the next unit)
+        if constexpr (CLSONLY) load_xop(nvalid ? nb : b);
+        // ---- the [CLS] token's key and value of this head: K image tile 8 row 0, V image row 256 ----
+        // (the row was fetched a patch ago; its q | k | v lie at 0 | 768 | 1536 bytes)
+        if (w == 0 && r == 0) {  // lanes 0 and 32: the two lane halves of row 0; fragment f = (d tile f >> 1, k-step f & 1):
+                                 // dims 16 f + 4 hh ..+3 and 16 f + 8 + 4 hh ..+3
+            const uint32_t ksrc = crow + (D + 64 * hs + 4 * hh) * 2;
+            u32x2 k0, k1, k2, k3, k4, k5, k6, k7;
+            asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:16\n\tds_read_b64 %2, %8 offset:32\n\tds_read_b64 %3, %8 offset:48\n\t"
+                         "ds_read_b64 %4, %8 offset:64\n\tds_read_b64 %5, %8 offset:80\n\tds_read_b64 %6, %8 offset:96\n\tds_read_b64 %7, %8 offset:112\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3), "=&v"(k4), "=&v"(k5), "=&v"(k6), "=&v"(k7)
+                         : "v"(ksrc));
+            const uint32_t ka = fa + OFF_K + 8 * 4096;
+            const u32x4 f0 = {k0[0], k0[1], k1[0], k1[1]}, f1 = {k2[0], k2[1], k3[0], k3[1]}, f2 = {k4[0], k4[1], k5[0], k5[1]},
+                        f3 = {k6[0], k6[1], k7[0], k7[1]};
+            DSW128(ka, f0, 0);
+            DSW128(ka, f1, 1024);
+            DSW128(ka, f2, 2048);
+            DSW128(ka, f3, 3072);
+        }
+        if (w == 1 && ln < 16) {  // 2 sub-images x 8 pieces of 8 bytes
+            const int t = ln >> 3, part = ln & 7;
+            const u32x2 vv = lds_ld64w(crow + (2 * D + 64 * hs + 32 * t + 4 * part) * 2);
+            const uint32_t vd = lbase + OFF_V + t * VSUB + 256 * 64 + part * 8;
+            DSW64(vd, vv, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // K / V images of this patch are complete
+        QSTAMP(1);
+
+        f32x16 O[2];
+        float l = 0.f;
+        if constexpr ((DBG & 4) != 0 && !CLSONLY) {
+            O[0] = O[1] = Z16;
+            O[0][0] = __builtin_bit_cast(float, qop[0][0][0]);
+            O[1][0] = __builtin_bit_cast(float, qop[1][1][3]);
+            l = 1.f;
+            load_xop(nvalid ? nb : b);
+        } else {
+        // ================= the [CLS] query against this wave's keys (wave 0: + the [CLS] key) =================
+        // (first, while few registers are live: the partial is merged behind the next patch's first barrier)
+        auto cls_query = [&]() __attribute__((always_inline)) {
+        if constexpr ((DBG & 16) == 0) {
+            u32x4 qc[4];  // B operand with one live column (query 0 = lanes 0 and 32): fragment f = (d tile, k-step)
+            {
+                const uint32_t qsrc = crow + (64 * hs + 4 * hh) * 2;
+                u32x2 q0, q1, q2, q3, q4, q5, q6, q7;
+                asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:16\n\tds_read_b64 %2, %8 offset:32\n\tds_read_b64 %3, %8 offset:48\n\t"
+                             "ds_read_b64 %4, %8 offset:64\n\tds_read_b64 %5, %8 offset:80\n\tds_read_b64 %6, %8 offset:96\n\tds_read_b64 %7, %8 offset:112\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(q7)
+                             : "v"(qsrc));
+                const bool live = r == 0;
+                qc[0] = live ? u32x4{q0[0], q0[1], q1[0], q1[1]} : u32x4{0u, 0u, 0u, 0u};
+                qc[1] = live ? u32x4{q2[0], q2[1], q3[0], q3[1]} : u32x4{0u, 0u, 0u, 0u};
+                qc[2] = live ? u32x4{q4[0], q4[1], q5[0], q5[1]} : u32x4{0u, 0u, 0u, 0u};
+                qc[3] = live ? u32x4{q6[0], q6[1], q7[0], q7[1]} : u32x4{0u, 0u, 0u, 0u};
+            }
+            f32x16 Sc[2];
+            const uint32_t ko = fa + OFF_K + w * 4096, k8 = fa + OFF_K + 8 * 4096;
+            {
+                u32x4 a0, a1, a2, a3, c0, c1, c2, c3;
+                asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
+                             "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:1024\n\tds_read_b128 %6, %9 offset:2048\n\tds_read_b128 %7, %9 offset:3072\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+                             : "v"(ko), "v"(k8));
+                Sc[0] = mfma32(a0, qc[0], Z16);
+                Sc[1] = mfma32(c0, qc[0], Z16);
+                Sc[0] = mfma32(a1, qc[1], Sc[0]);
+                Sc[1] = mfma32(c1, qc[1], Sc[1]);
+                Sc[0] = mfma32(a2, qc[2], Sc[0]);
+                Sc[1] = mfma32(c2, qc[2], Sc[1]);
+                Sc[0] = mfma32(a3, qc[3], Sc[0]);
+                Sc[1] = mfma32(c3, qc[3], Sc[1]);
+            }
+            // the [CLS] key (register 0 of lane half 0 of tile 8) belongs to wave 0's share
+            const float s8 = (w == 0 && hh == 0) ? Sc[1][0] : -INFINITY;
+            float mc = s8;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mc = fmaxf(mc, Sc[0][i]);
+            mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
+            const float mcs = -mc * p.sl2e;
+            float lc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(Sc[0][i], p.sl2e, mcs));
+                lc += e;
+                Sc[0][i] = e;
+            }
+            const float e8 = __builtin_amdgcn_exp2f(__builtin_fmaf(s8, p.sl2e, mcs));
+            lc += e8;
+            lc += __shfl_xor(lc, 32, 64);
+            const u32x4 pc0 = pack8<0>(Sc[0]), pc1 = pack8<1>(Sc[0]);
+            const u32x4 pc8 = {pack_bf16x2(e8, 0.f), 0u, 0u, 0u};
+            f32x16 Oc[2];
+            {
+                const uint32_t vo = va + 32 * w * 64, v8 = va + 256 * 64;
+                u32x2 a0, a1, b0v, b1v, c0, c1, d0, d1, e0, e1, f0, f1;
+                asm volatile("ds_read_b64_tr_b16 %0, %12\n\tds_read_b64_tr_b16 %1, %12 offset:512\n\tds_read_b64_tr_b16 %2, %12 offset:1024\n\t"
+                             "ds_read_b64_tr_b16 %3, %12 offset:1536\n\tds_read_b64_tr_b16 %4, %13\n\tds_read_b64_tr_b16 %5, %13 offset:512\n\t"
+                             "ds_read_b64_tr_b16 %6, %12 offset:%14\n\tds_read_b64_tr_b16 %7, %12 offset:%15\n\tds_read_b64_tr_b16 %8, %12 offset:%16\n\t"
+                             "ds_read_b64_tr_b16 %9, %12 offset:%17\n\tds_read_b64_tr_b16 %10, %13 offset:%14\n\tds_read_b64_tr_b16 %11, %13 offset:%15\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(a0), "=&v"(a1), "=&v"(b0v), "=&v"(b1v), "=&v"(c0), "=&v"(c1), "=&v"(d0), "=&v"(d1), "=&v"(e0), "=&v"(e1),
+                               "=&v"(f0), "=&v"(f1)
+                             : "v"(vo), "v"(v8), "n"(VSUB), "n"(VSUB + 512), "n"(VSUB + 1024), "n"(VSUB + 1536));
+                Oc[0] = mfma32(u32x4{a0[0], a0[1], a1[0], a1[1]}, pc0, Z16);
+                Oc[1] = mfma32(u32x4{d0[0], d0[1], d1[0], d1[1]}, pc0, Z16);
+                Oc[0] = mfma32(u32x4{b0v[0], b0v[1], b1v[0], b1v[1]}, pc1, Oc[0]);
+                Oc[1] = mfma32(u32x4{e0[0], e0[1], e1[0], e1[1]}, pc1, Oc[1]);
+                Oc[0] = mfma32(u32x4{c0[0], c0[1], c1[0], c1[1]}, pc8, Oc[0]);
+                Oc[1] = mfma32(u32x4{f0[0], f0[1], f1[0], f1[1]}, pc8, Oc[1]);
+            }
+            if (r == 0) {  // query 0: lane 0 holds dims 8 q + 0..3, lane 32 dims 8 q + 4..7 of each d tile
+                const uint32_t pa = lbase + OFF_CLSP + (pq * 8 + w) * CLSP_W;
+                if (hh == 0) {
+                    DSW32(pa, mc, 0);
+                    DSW32(pa, lc, 4);
+                }
+                const uint32_t da = pa + 16 + 16 * hh;
+                sfor<0, 8>([&](auto Q_) __attribute__((always_inline)) {
+                    constexpr int tq = decltype(Q_)::value, t = tq >> 2, q = tq & 3;
+                    const f32x4 v = {Oc[t][4 * q], Oc[t][4 * q + 1], Oc[t][4 * q + 2], Oc[t][4 * q + 3]};
+                    const uint32_t a = da;
+                    DSW128(a, v, (32 * t + 8 * q) * 4);
+                });
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        };
+        cls_query();
+        QSTAMP(2);
+        if constexpr (!CLSONLY) {
+        // ================= attention of this wave's 32 queries =================
+        f32x16 S[9];
+        float m;
+        {
+            // S^T tiles; the running maximum of a finished tile is taken under the MFMAs of the next one
+            u32x4 kf[4];
+            const uint32_t kb = fa + OFF_K;  // (ds offsets are 16-bit: the image base travels in the address register)
+            {
+                u32x4 &k0 = kf[0], &k1 = kf[1], &k2 = kf[2];
+                DSR128(k0, kb, 0);
+                DSR128(k1, kb, 1024);
+                DSR128(k2, kb, 2048);
+            }
+            sfor<0, 36>([&](auto I_) __attribute__((always_inline)) {
+                constexpr int i = decltype(I_)::value, kt = i >> 2, f = i & 3;
+                if constexpr (i + 3 < 36) {
+                    u32x4& kn = kf[(i + 3) & 3];
+                    const uint32_t ka2 = kb;
+                    DSR128(kn, ka2, (i + 3) * 1024);
+                    LGKM(3);
+                } else {
+                    LGKM(35 - i);
+                }
+                if constexpr (f == 0) S[kt] = mfma32(kf[i & 3], qop[0][0], Z16);
+                else S[kt] = mfma32(kf[i & 3], qop[f >> 1][f & 1], S[kt]);
+                if constexpr (kt >= 1) {  // a quarter of tile kt - 1 per step: 2 x v_max3_f32
+                    constexpr int e = 4 * f;
+                    if constexpr (kt == 1 && f == 0) m = __builtin_fmaxf(__builtin_fmaxf(S[0][0], S[0][1]), __builtin_fmaxf(S[0][2], S[0][3]));
+                    else m = __builtin_fmaxf(__builtin_fmaxf(m, S[kt - 1][e]), S[kt - 1][e + 1]), m = __builtin_fmaxf(__builtin_fmaxf(m, S[kt - 1][e + 2]), S[kt - 1][e + 3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        QSTAMP(3);
+        // tile 8 holds one key (register 0 of lane half 0): the rest is padding and gets probability 0 without an exponential
+        const float s8m = hh == 0 ? S[8][0] : -INFINITY;
+        m = fmaxf(m, s8m);
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float ms = -m * p.sl2e;
+        auto exp_quarter = [&](auto KT_, auto Q_) __attribute__((always_inline)) {  // registers 4 q ..+3 of tile kt -> probabilities
+            constexpr int kt = decltype(KT_)::value, q = decltype(Q_)::value;
+            if constexpr ((DBG & 32) != 0) {
+                if constexpr (q == 0) l += S[kt][0];
+            } else if constexpr (kt < 8) {
+#pragma unroll
+                for (int i = 4 * q; i < 4 * q + 4; ++i) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][i], p.sl2e, ms));
+                    l += e;
+                    S[kt][i] = e;
+                }
+            } else if constexpr (q == 0) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s8m, p.sl2e, ms));
+                l += e;
+                S[8][0] = e;
+                S[8][1] = S[8][2] = S[8][3] = S[8][4] = S[8][5] = S[8][6] = S[8][7] = 0.f;
+            }
+        };
+        typedef std::integral_constant<int, 0> I0_;
+        exp_quarter(I0_{}, I0_{});
+        exp_quarter(I0_{}, std::integral_constant<int, 1>{});
+        exp_quarter(I0_{}, std::integral_constant<int, 2>{});
+        exp_quarter(I0_{}, std::integral_constant<int, 3>{});
+        QSTAMP(4);
+        // O^T = V^T P^T: 17 (key tile, k-step) pairs (tile 8: its first k-step holds the one key) x 2 d tiles; the exponentials of
+        // tile kt + 1 run under the four MFMAs of tile kt, and in the second half the operands of the NEXT patch are requested
+        // into the registers the spent score tiles leave (unconditionally -- past the last patch the current one again)
+        {
+            const int nb2 = nvalid ? nb : b;
+            const int64_t Rn = (int64_t)nb2 * NTOK + 1 + 32 * w + r;
+            const char* x0 = p.xn + (Rn >> 4) * 12288 + (Rn & 15) * 16 + hh * 256;
+            const char* x1 = x0 + 4096;
+            const char* x2 = x0 + 8192;
+            u32x2 vf[4][2];
+            auto rdv = [&](auto J_) __attribute__((always_inline)) {
+                constexpr int j = decltype(J_)::value, pi = j >> 1, t = j & 1, kt = pi >> 1, s = pi & 1;
+                constexpr int off = t * VSUB + (32 * kt + 16 * s) * 64;
+                u32x2 &lo = vf[j & 3][0], &hi = vf[j & 3][1];
+                const uint32_t a = va;
+                DSRTR(lo, a, off);
+                DSRTR(hi, a, off + 8 * 64);
+            };
+            rdv(std::integral_constant<int, 0>{});
+            rdv(std::integral_constant<int, 1>{});
+            u32x4 pop;
+            sfor<0, 34>([&](auto J_) __attribute__((always_inline)) {
+                constexpr int j = decltype(J_)::value, pi = j >> 1, t = j & 1, kt = pi >> 1, s = pi & 1;
+                if constexpr (j + 2 < 34) {
+                    rdv(std::integral_constant<int, j + 2>{});
+                    LGKM(4);
+                } else {
+                    LGKM((33 - j) * 2);
+                }
+                if constexpr (kt + 1 < 9) exp_quarter(std::integral_constant<int, kt + 1>{}, std::integral_constant<int, (j & 3)>{});
+                if constexpr (t == 0) pop = s == 0 ? pack8<0>(S[kt]) : pack8<1>(S[kt]);
+                const u32x4 vfrag = {vf[j & 3][0][0], vf[j & 3][0][1], vf[j & 3][1][0], vf[j & 3][1][1]};
+                if constexpr (pi == 0) O[t] = mfma32(vfrag, pop, Z16);
+                else O[t] = mfma32(vfrag, pop, O[t]);
+                if constexpr (j >= 10 && (DBG & 64) == 0) {  // operand chunk j - 10: by now the score tiles before (j / 4) are spent, registers to spare
+                    constexpr int c = j - 10;
+                    u32x4& d = xop[c];
+                    const char *a0 = x0, *a1 = x1, *a2 = x2;
+                    if constexpr (c < 8) GLD128(d, a0, c * 512);
+                    else if constexpr (c < 16) GLD128(d, a1, (c - 8) * 512);
+                    else GLD128(d, a2, (c - 16) * 512);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        }  // (!CLSONLY)
+        }
+        QSTAMP(5);
+        // store: registers 4 q ..+3 of tile t = dims 32 t + 8 q + 4 hh ..+3 = chunk 8 hs + 4 t + q, bytes 8 hh ..+7
+        if constexpr (!CLSONLY) {
+            l += __shfl_xor(l, 32, 64);
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u32x2 o;
+                    o[0] = pack_bf16x2(O[t][4 * q] * inv, O[t][4 * q + 1] * inv);
+                    o[1] = pack_bf16x2(O[t][4 * q + 2] * inv, O[t][4 * q + 3] * inv);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, orsrc, orow + t * 1024 + q * 256, 0, 0);
+                }
+        }
+        QSTAMP(6);
+        prev_b = b;
+        prev_hs = hs;
+        if (!nvalid) {
+            pq ^= 1;
+            last_wi = wi;
+            break;
+        }
+        b = nb;
+        hs = nhs;
+        nvalid = unit_of(wi + 2, nb, nhs);
+    }
+    // ---- the last work unit's [CLS] partials ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (prev_b >= 0 && w == (last_wi & 7)) merge_cls(prev_b, prev_hs, pq ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (continuous stream: pieces of units nobody consumes)
+    if (QST_ON(p.stamps) && tid == 0)
+        for (int k = 0; k < 8; ++k) p.stamps[(size_t)blockIdx.x * 8 + k] = st_sum[k];
+}
+
+
+// ==================================================================================================================================
+// Round 5: the same work at ONE wave per SIMD -- 4 waves x 64 tokens, the whole 512-register file per wave.
+//   * a wave's 64 tokens are TWO 32-column B operands (halves h = 0 / 1: tokens 1 + 64 w + 32 h ..+31); they live in the ACCUMULATOR file
+//     (192 registers, `"a"` operands of hand-written MFMA statements: hipcc never sees a reason to copy them), loaded by global_load
+//     straight into it, re-requested for the next work unit under the PV products;
+//   * every 1 KiB weight fragment is read from LDS ONCE for TWO MFMAs (the 8-wave kernel above: eight waves read every fragment for one
+//     MFMA each -- a third of the LDS array's cycles): 4 x 144 KiB of fragment reads per work unit instead of 8 x 144;
+//   * a workgroup owns whole PATCHES and walks their six heads: the patch's rows are read by one CU only (no sharing through an XCD's
+//     L2 to arrange), the weight ring runs on across heads and patches as before;
+//   * the attention of the two halves runs one after the other on the 8-wave kernel's code (9 score tiles in registers, exponentials
+//     between the PV MFMAs); the [CLS] query is split over the four waves by key range (64 keys each).
+// Same k orders, same tile orders, same fragment images as the 8-wave kernel: a token's K, V, Q, scores and output are the same chains of
+// products (only the [CLS] query's partials are merged four at a time instead of eight).
+#define GLD128A(dst, ptr, off) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(dst) : "v"(ptr), "n"(off))
+// D = A B (+ C): A = a weight fragment in vector registers, B = a token operand in the accumulator file.  hipcc does not model what is
+// inside: the accumulator chain of a unit runs MFMA -> MFMA on the same registers (no padding needed), and MFMA_DRAIN pads the
+// last MFMA's write against the vector instructions that read the tile (8-pass XDL write -> VALU read: 12 wait states)
+#define MFMA_A0(acc, wfr, x) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wfr), "a"(x))
+#define MFMA_A(acc, wfr, x) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wfr), "a"(x))
+#define MFMA_DRAIN(a0, a1) asm volatile("s_nop 15" : "+v"(a0), "+v"(a1))
+
+// DBG4 (HIPT_QKV4_DBG in the environment; timing ablations, garbage results): 1 = no attention of the two halves, 2 = no [CLS] query,
+// 8 = no exponentials
+template <int DBG4 = 0>
+__global__ __launch_bounds__(256, 1) void qkv_attn4_kernel(const QkvAttnParams p) {
+    constexpr int NG = 144;  // GEMM steps of a work unit (six ring units x 24 k-steps), two MFMAs each
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = (int)gridDim.x;
+    const int b0 = (int)blockIdx.x;  // this workgroup's patches: b0, b0 + G, ..
+    if (b0 >= p.nseq) return;        // (uniform)
+
+    // ---- one-time LDS contents (no DMA in flight yet: plain stores) ----
+    {
+        float* bias_s = (float*)(smem + OFF_BIAS);
+        for (int i = tid; i < NUNIT * 32; i += 256) {
+            const int U = i >> 5, hb = (i >> 4) & 1, ii = i & 15;
+            bias_s[i] = p.bias[unit_row(U, (ii & 3) + 8 * (ii >> 2) + 4 * hb)];
+        }
+        uint32_t* kz = (uint32_t*)(smem + OFF_K + 8 * 4096);  // key tile 8: row 0 = the [CLS] key (written per head), rows 1.. stay zero
+        for (int i = tid; i < 1024; i += 256) kz[i] = 0u;
+        for (int t = 0; t < 2; ++t) {                          // V rows 256 .. 287: row 256 = the [CLS] value, the rest stay zero
+            uint32_t* vz = (uint32_t*)(smem + OFF_V + t * VSUB + 256 * 64);
+            for (int i = tid; i < 512; i += 256) vz[i] = 0u;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t lbase = lds_addr(smem);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.out_bytes, 0x00020000);
+
+    // ---- weight stream: ring unit n (head (n / 6) % 6, unit n % 6) into ring slot n % 3; wave w moves pieces w, w + 4, .., w + 20 ----
+    int iU = 0, islot = 0, ihs = 0;
+    auto issue_unit = [&]() __attribute__((always_inline)) {
+        const char* src = p.wpk + (size_t)(ihs * 6 + iU) * UNIT + lane * 16;
+        char* dst = smem + islot * UNIT;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) glds16(src + (w + 4 * j) * 1024, dst + (w + 4 * j) * 1024);
+        islot = islot + 1 == 3 ? 0 : islot + 1;
+        if (++iU == 6) {  // (past the last patch: pieces nobody consumes)
+            iU = 0;
+            ihs = ihs == 5 ? 0 : ihs + 1;
+        }
+    };
+    auto cls_dma = [&](int b, int par) __attribute__((always_inline)) {  // (wave 0) the [CLS] row of patch b -> LDS
+        const char* src = p.qkv_cls + (size_t)b * (3 * D * 2) + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) glds16(src + j * 1024, smem + OFF_CLSROW + par * CLSROW + j * 1024);
+    };
+
+    // this wave's tokens as B operands, in the accumulator file: [half][k-step]; lane (r, hh) holds row R, 16-byte chunk 2 s + hh of the image
+    u32x4 xop[2][24];
+    auto load_xop_half = [&](auto H_, int b) __attribute__((always_inline)) {
+        constexpr int h = decltype(H_)::value;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int64_t R = (int64_t)b * NTOK + 1 + 64 * w + 32 * h + (ln & 31);
+        const char* x0 = p.xn + (R >> 4) * 12288 + (R & 15) * 16 + (ln >> 5) * 256;
+        const char* x1 = x0 + 4096;
+        const char* x2 = x0 + 8192;
+        sfor<0, 24>([&](auto S_) __attribute__((always_inline)) {
+            constexpr int s = decltype(S_)::value;
+            u32x4& d = xop[h][s];
+            const char* a0 = x0;  // (plain uses: an asm operand inside `if constexpr` alone does not capture the variable)
+            const char* a1 = x1;
+            const char* a2 = x2;
+            if constexpr (s < 8) GLD128A(d, a0, s * 512);
+            else if constexpr (s < 16) GLD128A(d, a1, (s - 8) * 512);
+            else GLD128A(d, a2, (s - 16) * 512);
+        });
+    };
+    // (the asm loads land asynchronously: nothing touches xop between them and these two statements -- the counted wait, which is also
+    //  the point from which the registers count as written; 30 operands is the limit of one statement)
+#define XOP4_FENCE(N)                                                                                                                          \
+    asm volatile("s_waitcnt vmcnt(" #N ") ; XOP_FENCE"                                                                                         \
+                 : "+a"(xop[0][0]), "+a"(xop[0][1]), "+a"(xop[0][2]), "+a"(xop[0][3]), "+a"(xop[0][4]), "+a"(xop[0][5]), "+a"(xop[0][6]),       \
+                   "+a"(xop[0][7]), "+a"(xop[0][8]), "+a"(xop[0][9]), "+a"(xop[0][10]), "+a"(xop[0][11]), "+a"(xop[0][12]), "+a"(xop[0][13]),  \
+                   "+a"(xop[0][14]), "+a"(xop[0][15]), "+a"(xop[0][16]), "+a"(xop[0][17]), "+a"(xop[0][18]), "+a"(xop[0][19]),                  \
+                   "+a"(xop[0][20]), "+a"(xop[0][21]), "+a"(xop[0][22]), "+a"(xop[0][23])::"memory");                                          \
+    asm volatile("; XOP_FENCE (second half)"                                                                                                   \
+                 : "+a"(xop[1][0]), "+a"(xop[1][1]), "+a"(xop[1][2]), "+a"(xop[1][3]), "+a"(xop[1][4]), "+a"(xop[1][5]), "+a"(xop[1][6]),       \
+                   "+a"(xop[1][7]), "+a"(xop[1][8]), "+a"(xop[1][9]), "+a"(xop[1][10]), "+a"(xop[1][11]), "+a"(xop[1][12]), "+a"(xop[1][13]),  \
+                   "+a"(xop[1][14]), "+a"(xop[1][15]), "+a"(xop[1][16]), "+a"(xop[1][17]), "+a"(xop[1][18]), "+a"(xop[1][19]),                  \
+                   "+a"(xop[1][20]), "+a"(xop[1][21]), "+a"(xop[1][22]), "+a"(xop[1][23])::"memory")
+
+    // ---- merge of the four [CLS]-query partials of one (patch, head): one wave, lane = output dimension ----
+    auto merge_cls = [&](int b, int hs, int pq) __attribute__((always_inline)) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t base = lbase + OFF_CLSP + pq * 8 * CLSP_W, obase = base + 16 + ln * 4;
+        float mk[4], lk[4], ok[4];
+        sfor<0, 4>([&](auto K_) __attribute__((always_inline)) {
+            constexpr int k = decltype(K_)::value;
+            float &m_ = mk[k], &l_ = lk[k], &o_ = ok[k];
+            const uint32_t ba = base, oa = obase;
+            asm volatile("ds_read_b32 %0, %3 offset:%5\n\tds_read_b32 %1, %3 offset:%6\n\tds_read_b32 %2, %4 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(m_), "=&v"(l_), "=&v"(o_)
+                         : "v"(ba), "v"(oa), "n"(k * CLSP_W), "n"(k * CLSP_W + 4));
+        });
+        float mx = mk[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) mx = fmaxf(mx, mk[k]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float f = __builtin_amdgcn_exp2f((mk[k] - mx) * p.sl2e);
+            L += f * lk[k];
+            o += f * ok[k];
+        }
+        const int64_t R = (int64_t)b * NTOK;  // the [CLS] row; column 64 hs + lane = chunk 8 hs + (lane >> 3), element lane & 7
+        const int kc = 8 * hs + (ln >> 3);
+        bf16_t* dst = (bf16_t*)(p.out + (R >> 4) * 12288 + (kc >> 2) * 1024 + (kc & 3) * 256 + (R & 15) * 16) + (ln & 7);
+        *dst = (bf16_t)(o / L);
+    };
+
+    int prev_b = -1, prev_hs = 0;  // work unit whose [CLS] partials wait for their merge
+    if (w == 0) cls_dma(b0, 0);
+    issue_unit();
+    issue_unit();
+    load_xop_half(std::integral_constant<int, 0>{}, b0);
+    load_xop_half(std::integral_constant<int, 1>{}, b0);
+    // ring protocol as in the 8-wave kernel: in the MIDDLE of unit n every wave waits for its pieces of unit n + 1, all meet at a barrier,
+    // and unit n + 2 is requested into the slot of unit n - 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // unit 0 has landed
+    int cslot = 0;
+
+    constexpr int PF = 7;  // weight fragments requested ahead of the MFMAs that use them (8 register sets)
+    const f32x16 Z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = b0, hs = 0, wi = 0;
+    for (;; ++wi) {
+        const int pq = wi & 1;                      // which [CLS] partial buffer
+        const bool last_head = hs == 5;
+        const bool more = !last_head || b + G < p.nseq;   // is there a work unit after this one?
+        const int nb = last_head ? (b + G < p.nseq ? b + G : b) : b;  // the patch whose operands are requested under this unit's PV products
+        // (per-lane addresses are re-derived per work unit from an opaque copy of the lane id: see the 8-wave kernel)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int r = ln & 31, hh = ln >> 5;
+        const uint32_t fa = lbase + ln * 16;  // this lane's 16 bytes of a 1 KiB fragment
+        const int vq = (ln & 15) >> 2, vch = (2 * ((ln >> 4) & 1) + ((ln & 3) >> 1) + 2 * hh + (vq >> 1)) & 3;
+        const uint32_t va = lbase + OFF_V + (4 * hh + vq) * 64 + vch * 16 + (ln & 1) * 8;
+        const uint32_t crow = lbase + OFF_CLSROW + ((wi / 6) & 1) * CLSROW;
+        u32x4 qop[2][2][2];  // [half][d tile][k-step]: Q^T as the score product's B operand
+        // ================= GEMM phase: six ring units = 144 steps of one fragment read + two MFMAs =================
+        {
+            u32x4 wf[8];
+            f32x4 bq[4];
+            f32x16 acc0, acc1;
+            uint32_t sa = fa + cslot * UNIT, sn = sa;
+            XOP4_FENCE(8);  // (the eight youngest vector-memory operations are the previous unit's last output stores: let them fly)
+            sfor<0, PF>([&](auto G_) __attribute__((always_inline)) {
+                constexpr int g = decltype(G_)::value;
+                u32x4& d = wf[g & 7];
+                const uint32_t a = sa;
+                DSR128(d, a, g * 1024);
+            });
+            sfor<0, NG>([&](auto G_) __attribute__((always_inline)) {
+                constexpr int g = decltype(G_)::value, u = g / 24, s = g % 24;
+                // LDS operations younger than fragment g at its wait: the PF fragments behind it, and -- during the first PF steps of a unit --
+                // the bias reads of this unit and the K / V writes of the unit before (in-order queue; a 4-bit counter)
+                constexpr int wprev = u == 0 ? 0 : (u <= 2 ? 4 : (u <= 4 ? 8 : 0));
+                constexpr int ahead = g + PF < NG ? PF : NG - 1 - g;
+                if constexpr (s == 0) {
+                    const uint32_t ba = lbase + OFF_BIAS + ((hs * 6 + u) * 2 + hh) * 64;
+                    f32x4 &b0v = bq[0], &b1v = bq[1], &b2v = bq[2], &b3v = bq[3];
+                    DSR128(b0v, ba, 0);
+                    DSR128(b1v, ba, 16);
+                    DSR128(b2v, ba, 32);
+                    DSR128(b3v, ba, 48);
+                }
+                if constexpr (g + PF < NG) {
+                    u32x4& d = wf[(g + PF) & 7];
+                    if constexpr (s + PF < 24) {
+                        const uint32_t a = sa;
+                        DSR128(d, a, (s + PF) * 1024);
+                    } else {
+                        const uint32_t a = sn;
+                        DSR128(d, a, (s + PF - 24) * 1024);
+                    }
+                }
+                if constexpr (s < PF) {
+                    LGKM((ahead + 4 + wprev < 15 ? ahead + 4 + wprev : 15));
+                } else {
+                    LGKM(ahead);
+                }
+                {
+                    const u32x4& fr = wf[g & 7];
+                    u32x4 &x0 = xop[0][s], &x1 = xop[1][s];
+                    if constexpr (s == 0) {
+                        MFMA_A0(acc0, fr, x0);
+                        MFMA_A0(acc1, fr, x1);
+                    } else {
+                        MFMA_A(acc0, fr, x0);
+                        MFMA_A(acc1, fr, x1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (s == 1) {
+                    // ---- ring, first half: everyone has left the unit before this one: request unit n + 2 into its slot (two units in flight) ----
+                    __builtin_amdgcn_s_barrier();
+                    if constexpr (u == 0) {
+                        // behind the first barrier of a work unit every wave has left the previous unit's attention: its [CLS] partials are
+                        // complete (merge them) and the K / V images are free; at a patch's first head the other [CLS] row buffer is free too.
+                        // BEFORE the unit's pieces: the second half's counted wait leaves exactly those in flight.
+                        if (prev_b >= 0 && w == ((wi - 1) & 3)) merge_cls(prev_b, prev_hs, pq ^ 1);
+                        if (w == 0 && hs == 0 && b + G < p.nseq) cls_dma(b + G, ((wi / 6) & 1) ^ 1);
+                    }
+                    issue_unit();
+                }
+                if constexpr (s == 15) {
+                    // ---- ring, second half (before the first fragment request of the next unit, step 24 - PF): my pieces of unit n + 1 have
+                    //      landed (the six youngest requests are unit n + 2's) and, behind the barrier, everyone's ----
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    sn = fa + (cslot == 2 ? 0 : cslot + 1) * UNIT;
+                }
+                if constexpr (s == 23) {
+                    // ---- unit done: + bias, then K^T / V^T tiles to their LDS images, Q^T to its operand registers (both halves) ----
+                    MFMA_DRAIN(acc0, acc1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc0[i] += bq[0][i];
+                        acc0[4 + i] += bq[1][i];
+                        acc0[8 + i] += bq[2][i];
+                        acc0[12 + i] += bq[3][i];
+                        acc1[i] += bq[0][i];
+                        acc1[4 + i] += bq[1][i];
+                        acc1[8 + i] += bq[2][i];
+                        acc1[12 + i] += bq[3][i];
+                    }
+                    sfor<0, 2>([&](auto H_) __attribute__((always_inline)) {
+                        constexpr int h = decltype(H_)::value;
+                        const f32x16& acc = h == 0 ? acc0 : acc1;
+                        if constexpr (u < 2) {          // K^T tile u of key tile 2 w + h: the two A-operand fragments (k-steps) of the score product
+                            const u32x4 k0 = pack8<0>(acc), k1 = pack8<1>(acc);
+                            const uint32_t ka = fa + OFF_K + (2 * w + h) * 4096;
+                            DSW128(ka, k0, (u * 2 + 0) * 1024);
+                            DSW128(ka, k1, (u * 2 + 1) * 1024);
+                        } else if constexpr (u < 4) {   // V^T tile: row-major [key][32 dims], chunks rotated by (key >> 1) & 3 (8-wave kernel)
+                            const int rot = (r >> 1) & 3;
+                            const uint32_t vw = lbase + OFF_V + (u - 2) * VSUB + (64 * w + 32 * h + r) * 64 + 8 * hh;
+                            const uint32_t vw0 = vw + ((0 + rot) & 3) * 16, vw1 = vw + ((1 + rot) & 3) * 16, vw2 = vw + ((2 + rot) & 3) * 16, vw3 = vw + ((3 + rot) & 3) * 16;
+                            u32x2 o0, o1, o2, o3;
+                            o0[0] = pack_bf16x2(acc[0], acc[1]);   o0[1] = pack_bf16x2(acc[2], acc[3]);
+                            o1[0] = pack_bf16x2(acc[4], acc[5]);   o1[1] = pack_bf16x2(acc[6], acc[7]);
+                            o2[0] = pack_bf16x2(acc[8], acc[9]);   o2[1] = pack_bf16x2(acc[10], acc[11]);
+                            o3[0] = pack_bf16x2(acc[12], acc[13]); o3[1] = pack_bf16x2(acc[14], acc[15]);
+                            DSW64(vw0, o0, 0);
+                            DSW64(vw1, o1, 0);
+                            DSW64(vw2, o2, 0);
+                            DSW64(vw3, o3, 0);
+                        } else {                        // Q^T tile: stays in registers as the score product's B operand
+                            qop[h][u - 4][0] = pack8<0>(acc);
+                            qop[h][u - 4][1] = pack8<1>(acc);
+                        }
+                    });
+                    sa = sn;
+                    cslot = cslot == 2 ? 0 : cslot + 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        }
+        // ---- the [CLS] token's key and value of this head: K image tile 8 row 0, V image row 256 (8-wave kernel) ----
+        if (w == 0 && r == 0) {
+            const uint32_t ksrc = crow + (D + 64 * hs + 4 * hh) * 2;
+            u32x2 k0, k1, k2, k3, k4, k5, k6, k7;
+            asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:16\n\tds_read_b64 %2, %8 offset:32\n\tds_read_b64 %3, %8 offset:48\n\t"
+                         "ds_read_b64 %4, %8 offset:64\n\tds_read_b64 %5, %8 offset:80\n\tds_read_b64 %6, %8 offset:96\n\tds_read_b64 %7, %8 offset:112\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3), "=&v"(k4), "=&v"(k5), "=&v"(k6), "=&v"(k7)
+                         : "v"(ksrc));
+            const uint32_t ka = fa + OFF_K + 8 * 4096;
+            const u32x4 f0 = {k0[0], k0[1], k1[0], k1[1]}, f1 = {k2[0], k2[1], k3[0], k3[1]}, f2 = {k4[0], k4[1], k5[0], k5[1]},
+                        f3 = {k6[0], k6[1], k7[0], k7[1]};
+            DSW128(ka, f0, 0);
+            DSW128(ka, f1, 1024);
+            DSW128(ka, f2, 2048);
+            DSW128(ka, f3, 3072);
+        }
+        if (w == 1 && ln < 16) {  // 2 sub-images x 8 pieces of 8 bytes
+            const int t = ln >> 3, part = ln & 7;
+            const u32x2 vv = lds_ld64w(crow + (2 * D + 64 * hs + 32 * t + 4 * part) * 2);
+            const uint32_t vd = lbase + OFF_V + t * VSUB + 256 * 64 + part * 8;
+            DSW64(vd, vv, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // K / V images of this (patch, head) are complete
+
+        // ================= the [CLS] query against this wave's 64 keys (wave 0: + the [CLS] key) =================
+        if constexpr ((DBG4 & 2) == 0) {
+            u32x4 qc[4];  // B operand with one live column (query 0 = lanes 0 and 32): fragment f = (d tile, k-step)
+            {
+                const uint32_t qsrc = crow + (64 * hs + 4 * hh) * 2;
+                u32x2 q0, q1, q2, q3, q4, q5, q6, q7;
+                asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:16\n\tds_read_b64 %2, %8 offset:32\n\tds_read_b64 %3, %8 offset:48\n\t"
+                             "ds_read_b64 %4, %8 offset:64\n\tds_read_b64 %5, %8 offset:80\n\tds_read_b64 %6, %8 offset:96\n\tds_read_b64 %7, %8 offset:112\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(q7)
+                             : "v"(qsrc));
+                const bool live = r == 0;
+                qc[0] = live ? u32x4{q0[0], q0[1], q1[0], q1[1]} : u32x4{0u, 0u, 0u, 0u};
+                qc[1] = live ? u32x4{q2[0], q2[1], q3[0], q3[1]} : u32x4{0u, 0u, 0u, 0u};
+                qc[2] = live ? u32x4{q4[0], q4[1], q5[0], q5[1]} : u32x4{0u, 0u, 0u, 0u};
+                qc[3] = live ? u32x4{q6[0], q6[1], q7[0], q7[1]} : u32x4{0u, 0u, 0u, 0u};
+            }
+            f32x16 Sc[3];  // key tiles 2 w, 2 w + 1 and 8
+            const uint32_t ko = fa + OFF_K + 2 * w * 4096, k8 = fa + OFF_K + 8 * 4096;
+            sfor<0, 3>([&](auto T_) __attribute__((always_inline)) {
+                constexpr int t = decltype(T_)::value;
+                u32x4 a0, a1, a2, a3;
+                const uint32_t ka = t == 2 ? k8 : ko;
+                constexpr int o = t == 1 ? 4096 : 0;
+                asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+                             : "v"(ka), "n"(o), "n"(o + 1024), "n"(o + 2048), "n"(o + 3072));
+                Sc[t] = mfma32(a0, qc[0], Z16);
+                Sc[t] = mfma32(a1, qc[1], Sc[t]);
+                Sc[t] = mfma32(a2, qc[2], Sc[t]);
+                Sc[t] = mfma32(a3, qc[3], Sc[t]);
+            });
+            // the [CLS] key (register 0 of lane half 0 of tile 8) belongs to wave 0's share
+            const float s8 = (w == 0 && hh == 0) ? Sc[2][0] : -INFINITY;
+            float mc = s8;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mc = fmaxf(mc, fmaxf(Sc[0][i], Sc[1][i]));
+            mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
+            const float mcs = -mc * p.sl2e;
+            float lc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(Sc[t][i], p.sl2e, mcs));
+                    lc += e;
+                    Sc[t][i] = e;
+                }
+            const float e8 = __builtin_amdgcn_exp2f(__builtin_fmaf(s8, p.sl2e, mcs));
+            lc += e8;
+            lc += __shfl_xor(lc, 32, 64);
+            const u32x4 pc8 = {pack_bf16x2(e8, 0.f), 0u, 0u, 0u};
+            f32x16 Oc[2];
+            {
+                // V^T fragments of this wave's two key tiles (k-steps of 16 keys) and of row 256, both d tiles
+                const uint32_t vo = va + 64 * w * 64, v8 = va + 256 * 64;
+                sfor<0, 2>([&](auto DT_) __attribute__((always_inline)) {
+                    constexpr int dt = decltype(DT_)::value;
+                    u32x2 f[5][2];
+                    u32x2 &f00 = f[0][0], &f01 = f[0][1], &f10 = f[1][0], &f11 = f[1][1], &f20 = f[2][0], &f21 = f[2][1], &f30 = f[3][0], &f31 = f[3][1],
+                          &f40 = f[4][0], &f41 = f[4][1];
+                    const uint32_t a = vo, a8 = v8;
+                    asm volatile("ds_read_b64_tr_b16 %0, %10 offset:%12\n\tds_read_b64_tr_b16 %1, %10 offset:%13\n\t"
+                                 "ds_read_b64_tr_b16 %2, %10 offset:%14\n\tds_read_b64_tr_b16 %3, %10 offset:%15\n\t"
+                                 "ds_read_b64_tr_b16 %4, %10 offset:%16\n\tds_read_b64_tr_b16 %5, %10 offset:%17\n\t"
+                                 "ds_read_b64_tr_b16 %6, %10 offset:%18\n\tds_read_b64_tr_b16 %7, %10 offset:%19\n\t"
+                                 "ds_read_b64_tr_b16 %8, %11 offset:%12\n\tds_read_b64_tr_b16 %9, %11 offset:%13\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(f00), "=&v"(f01), "=&v"(f10), "=&v"(f11), "=&v"(f20), "=&v"(f21), "=&v"(f30), "=&v"(f31), "=&v"(f40), "=&v"(f41)
+                                 : "v"(a), "v"(a8), "n"(dt * VSUB), "n"(dt * VSUB + 512), "n"(dt * VSUB + 1024), "n"(dt * VSUB + 1536), "n"(dt * VSUB + 2048),
+                                   "n"(dt * VSUB + 2560), "n"(dt * VSUB + 3072), "n"(dt * VSUB + 3584));
+                    Oc[dt] = mfma32(u32x4{f[0][0][0], f[0][0][1], f[0][1][0], f[0][1][1]}, pack8<0>(Sc[0]), Z16);
+                    Oc[dt] = mfma32(u32x4{f[1][0][0], f[1][0][1], f[1][1][0], f[1][1][1]}, pack8<1>(Sc[0]), Oc[dt]);
+                    Oc[dt] = mfma32(u32x4{f[2][0][0], f[2][0][1], f[2][1][0], f[2][1][1]}, pack8<0>(Sc[1]), Oc[dt]);
+                    Oc[dt] = mfma32(u32x4{f[3][0][0], f[3][0][1], f[3][1][0], f[3][1][1]}, pack8<1>(Sc[1]), Oc[dt]);
+                    Oc[dt] = mfma32(u32x4{f[4][0][0], f[4][0][1], f[4][1][0], f[4][1][1]}, pc8, Oc[dt]);
+                });
+            }
+            if (r == 0) {  // query 0: lane 0 holds dims 8 q + 0..3, lane 32 dims 8 q + 4..7 of each d tile
+                const uint32_t pa = lbase + OFF_CLSP + (pq * 8 + w) * CLSP_W;
+                if (hh == 0) {
+                    DSW32(pa, mc, 0);
+                    DSW32(pa, lc, 4);
+                }
+                const uint32_t da = pa + 16 + 16 * hh;
+                sfor<0, 8>([&](auto Q_) __attribute__((always_inline)) {
+                    constexpr int tq = decltype(Q_)::value, t = tq >> 2, q = tq & 3;
+                    const f32x4 v = {Oc[t][4 * q], Oc[t][4 * q + 1], Oc[t][4 * q + 2], Oc[t][4 * q + 3]};
+                    const uint32_t a = da;
+                    DSW128(a, v, (32 * t + 8 * q) * 4);
+                });
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+
+        // ================= attention of this wave's 64 queries, one half (32 queries) after the other =================
+        if constexpr ((DBG4 & 1) != 0) {
+            load_xop_half(std::integral_constant<int, 0>{}, nb);
+            load_xop_half(std::integral_constant<int, 1>{}, nb);
+            asm volatile("" ::"v"(qop[0][0][0]), "v"(qop[0][0][1]), "v"(qop[0][1][0]), "v"(qop[0][1][1]), "v"(qop[1][0][0]), "v"(qop[1][0][1]), "v"(qop[1][1][0]), "v"(qop[1][1][1]));
+        } else
+        sfor<0, 2>([&](auto H_) __attribute__((always_inline)) {
+            constexpr int h = decltype(H_)::value;
+            const int64_t Rl = (int64_t)b * NTOK + 1 + 64 * w + 32 * h + r;                  // this lane's token row (as a query)
+            const int orow = (int)((Rl >> 4) * 12288 + (Rl & 15) * 16) + 8 * hh + hs * 2048;  // its bytes in the output image (this head's columns)
+            f32x16 S[9];
+            float m;
+            {
+                // S^T tiles; the running maximum of a finished tile is taken under the MFMAs of the next one
+                u32x4 kf[4];
+                const uint32_t kb = fa + OFF_K;
+                {
+                    u32x4 &k0 = kf[0], &k1 = kf[1], &k2 = kf[2];
+                    DSR128(k0, kb, 0);
+                    DSR128(k1, kb, 1024);
+                    DSR128(k2, kb, 2048);
+                }
+                sfor<0, 36>([&](auto I_) __attribute__((always_inline)) {
+                    constexpr int i = decltype(I_)::value, kt = i >> 2, f = i & 3;
+                    if constexpr (i + 3 < 36) {
+                        u32x4& kn = kf[(i + 3) & 3];
+                        const uint32_t ka2 = kb;
+                        DSR128(kn, ka2, (i + 3) * 1024);
+                        LGKM(3);
+                    } else {
+                        LGKM(35 - i);
+                    }
+                    if constexpr (f == 0) S[kt] = mfma32(kf[i & 3], qop[h][0][0], Z16);
+                    else S[kt] = mfma32(kf[i & 3], qop[h][f >> 1][f & 1], S[kt]);
+                    if constexpr (kt >= 1) {  // a quarter of tile kt - 1 per step: 2 x v_max3_f32
+                        constexpr int e = 4 * f;
+                        if constexpr (kt == 1 && f == 0) m = __builtin_fmaxf(__builtin_fmaxf(S[0][0], S[0][1]), __builtin_fmaxf(S[0][2], S[0][3]));
+                        else m = __builtin_fmaxf(__builtin_fmaxf(m, S[kt - 1][e]), S[kt - 1][e + 1]), m = __builtin_fmaxf(__builtin_fmaxf(m, S[kt - 1][e + 2]), S[kt - 1][e + 3]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            // tile 8 holds one key (register 0 of lane half 0): the rest is padding and gets probability 0 without an exponential
+            const float s8m = hh == 0 ? S[8][0] : -INFINITY;
+            m = fmaxf(m, s8m);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const float ms = -m * p.sl2e;
+            float l = 0.f;
+            auto exp_quarter = [&](auto KT_, auto Q_) __attribute__((always_inline)) {  // registers 4 q ..+3 of tile kt -> probabilities
+                constexpr int kt = decltype(KT_)::value, q = decltype(Q_)::value;
+                if constexpr ((DBG4 & 8) != 0) {
+                    if constexpr (q == 0) l += S[kt][0];
+                } else if constexpr (kt < 8) {
+#pragma unroll
+                    for (int i = 4 * q; i < 4 * q + 4; ++i) {
+                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][i], p.sl2e, ms));
+                        l += e;
+                        S[kt][i] = e;
+                    }
+                } else if constexpr (q == 0) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s8m, p.sl2e, ms));
+                    l += e;
+                    S[8][0] = e;
+                    S[8][1] = S[8][2] = S[8][3] = S[8][4] = S[8][5] = S[8][6] = S[8][7] = 0.f;
+                }
+            };
+            typedef std::integral_constant<int, 0> I0_;
+            exp_quarter(I0_{}, I0_{});
+            exp_quarter(I0_{}, std::integral_constant<int, 1>{});
+            exp_quarter(I0_{}, std::integral_constant<int, 2>{});
+            exp_quarter(I0_{}, std::integral_constant<int, 3>{});
+            // O^T = V^T P^T: 17 (key tile, k-step) pairs x 2 d tiles; the exponentials of tile kt + 1 run under the four MFMAs of tile kt, and
+            // this half's token operands of the NEXT work unit are requested along the way (unconditionally: past the last unit the same ones)
+            f32x16 O[2];
+            {
+                const int64_t Rn = (int64_t)nb * NTOK + 1 + 64 * w + 32 * h + r;
+                const char* x0 = p.xn + (Rn >> 4) * 12288 + (Rn & 15) * 16 + hh * 256;
+                const char* x1 = x0 + 4096;
+                const char* x2 = x0 + 8192;
+                u32x2 vf[4][2];
+                auto rdv = [&](auto J_) __attribute__((always_inline)) {
+                    constexpr int j = decltype(J_)::value, pi = j >> 1, t = j & 1, kt = pi >> 1, s = pi & 1;
+                    constexpr int off = t * VSUB + (32 * kt + 16 * s) * 64;
+                    u32x2 &lo = vf[j & 3][0], &hi = vf[j & 3][1];
+                    const uint32_t a = va;
+                    DSRTR(lo, a, off);
+                    DSRTR(hi, a, off + 8 * 64);
+                };
+                rdv(std::integral_constant<int, 0>{});
+                rdv(std::integral_constant<int, 1>{});
+                u32x4 pop;
+                sfor<0, 34>([&](auto J_) __attribute__((always_inline)) {
+                    constexpr int j = decltype(J_)::value, pi = j >> 1, t = j & 1, kt = pi >> 1, s = pi & 1;
+                    if constexpr (j + 2 < 34) {
+                        rdv(std::integral_constant<int, j + 2>{});
+                        LGKM(4);
+                    } else {
+                        LGKM((33 - j) * 2);
+                    }
+                    if constexpr (kt + 1 < 9) exp_quarter(std::integral_constant<int, kt + 1>{}, std::integral_constant<int, (j & 3)>{});
+                    if constexpr (t == 0) pop = s == 0 ? pack8<0>(S[kt]) : pack8<1>(S[kt]);
+                    const u32x4 vfrag = {vf[j & 3][0][0], vf[j & 3][0][1], vf[j & 3][1][0], vf[j & 3][1][1]};
+                    if constexpr (pi == 0) O[t] = mfma32(vfrag, pop, Z16);
+                    else O[t] = mfma32(vfrag, pop, O[t]);
+                    if constexpr (j >= 10) {  // operand chunk j - 10 of this half
+                        constexpr int c = j - 10;
+                        u32x4& d = xop[h][c];
+                        const char *a0 = x0, *a1 = x1, *a2 = x2;
+                        if constexpr (c < 8) GLD128A(d, a0, c * 512);
+                        else if constexpr (c < 16) GLD128A(d, a1, (c - 8) * 512);
+                        else GLD128A(d, a2, (c - 16) * 512);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            // store: registers 4 q ..+3 of tile t = dims 32 t + 8 q + 4 hh ..+3 = chunk 8 hs + 4 t + q, bytes 8 hh ..+7
+            l += __shfl_xor(l, 32, 64);
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u32x2 o;
+                    o[0] = pack_bf16x2(O[t][4 * q] * inv, O[t][4 * q + 1] * inv);
+                    o[1] = pack_bf16x2(O[t][4 * q + 2] * inv, O[t][4 * q + 3] * inv);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, orsrc, orow + t * 1024 + q * 256, 0, 0);
+                }
+        });
+        prev_b = b;
+        prev_hs = hs;
+        if (!more) break;
+        if (last_head) {
+            hs = 0;
+            b += G;
+        } else {
+            hs += 1;
+        }
+    }
+    // ---- the last work unit's [CLS] partials ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (w == 0) merge_cls(prev_b, prev_hs, wi & 1);  // (the loop left through `break`: wi is the last unit's index)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (continuous stream: pieces of units nobody consumes; operands nobody uses)
+}
+
+}  // namespace
+
+bool hipt_qkv_attn_supported(int dtype, int D_, int heads, int ntok) { return dtype == HIPT_BF16 && D_ == D && heads == HEADS && ntok == NTOK; }
+
+size_t hipt_qkv_attn_packed_bytes() { return (size_t)NUNIT * UNIT; }
+
+int hipt_qkv_attn_pack_launch(const void* qkv_w, void* packed, hipStream_t st) {
+    const int chunks = NUNIT * 24 * 64;
+    hipLaunchKernelGGL(qkv_attn_pack_kernel, dim3((chunks + 255) / 256), dim3(256), 0, st, (const bf16_t*)qkv_w, (u32x4*)packed);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}
+
+static int qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b, const void* qkv_cls, void* out_img, int nseq, float scale, bool cls_only,
+                           hipStream_t st) {
+    HIPT_CHECK_ARG(xn_img && wpk && qkv_b && qkv_cls && out_img && nseq > 0, "qkv_attention: null / empty argument");
+    HIPT_CHECK_ARG(((int64_t)nseq * NTOK) % 16 == 0, "qkv_attention: activation images need whole 16-row fragments (nseq * 257 %% 16 == 0)");
+    HIPT_CHECK_ARG((int64_t)nseq * NTOK * D * 2 < ((int64_t)1 << 32) - 65536, "qkv_attention: output image beyond 4 GiB");
+    HIPT_CHECK_ARG(((uintptr_t)xn_img % 16) == 0 && ((uintptr_t)wpk % 16) == 0 && ((uintptr_t)qkv_cls % 16) == 0 && ((uintptr_t)out_img % 16) == 0,
+                   "qkv_attention: 16-byte alignment required");
+    static DevOnce once;
+    HIPT_CUR_DEVICE(dev);
+    if (!once.done[dev]) {
+        bool ok = hipFuncSetAttribute((const void*)qkv_attn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess &&
+                  hipFuncSetAttribute((const void*)qkv_attn_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess &&
+                  hipFuncSetAttribute((const void*)qkv_attn4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+#define QKV4_ATTR(n) ok = ok && hipFuncSetAttribute((const void*)qkv_attn4_kernel<n>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+        QKV4_ATTR(1) QKV4_ATTR(2) QKV4_ATTR(3) QKV4_ATTR(8)
+#ifdef HIPT_DEBUG_STAMPS
+// (bit 8 -- no GEMM MFMAs -- is not instantiated: nothing then reads the asm-loaded operand registers between their loads and the
+//  fence, hipcc re-uses them while the data is still on its way, and the landing data overwrites live addresses: a memory fault)
+#define QKV_DBG_LIST(X) X(1) X(2) X(3) X(4) X(7) X(16) X(32) X(48) X(64)
+#define QKV_SETATTR(n) ok = ok && hipFuncSetAttribute((const void*)qkv_attn_kernel<n>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+        QKV_DBG_LIST(QKV_SETATTR)
+#endif
+        if (!ok) {
+            hipt_set_error("hipFuncSetAttribute(qkv_attention) failed");
+            return HIPT_E_LAUNCH;
+        }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            hipt_set_error("qkv_attention: cannot query the device");
+            return HIPT_E_LAUNCH;
+        }
+        once.ncu[dev] = prop.multiProcessorCount;
+        once.done[dev] = true;
+    }
+    QkvAttnParams p;
+    p.xn = (const char*)xn_img;
+    p.wpk = (const char*)wpk;
+    p.bias = qkv_b;
+    p.qkv_cls = (const char*)qkv_cls;
+    p.out = (char*)out_img;
+    p.nseq = nseq;
+    p.sl2e = scale * 1.4426950408889634f;
+    p.out_bytes = (unsigned)((int64_t)nseq * (cls_only ? 1 : NTOK) * D * 2);
+    p.stamps = nullptr;
+    // every CU gets a workgroup; the (patch, head) units of an eighth of the patches go round the workgroups of one XCD (QkvAttnParams)
+    const int ncu = once.ncu[dev];
+    p.px = (nseq + 7) / 8;
+    const int per = ncu / 8 > 0 ? ncu / 8 : 1;
+    p.nslots = p.px * HEADS < per ? p.px * HEADS : per;
+    const int grid = 8 * p.nslots;
+#ifdef HIPT_DEBUG_STAMPS  // diagnostic builds only (make DEBUG_STAMPS=1): the release library never allocates or synchronises
+    static const bool want_stamps = getenv("HIPT_QKVATT_STAMPS") != nullptr;
+    static unsigned long long* dbuf = nullptr;
+    if (want_stamps) {
+        if (!dbuf) (void)hipMalloc(&dbuf, 1024 * 8 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbuf, 0, 1024 * 8 * sizeof(unsigned long long), st);
+        p.stamps = dbuf;
+    }
+#endif
+#ifdef HIPT_DEBUG_STAMPS
+    static const int dbg = getenv("HIPT_QKVATT_DBG") ? atoi(getenv("HIPT_QKVATT_DBG")) : 0;
+    auto k = cls_only ? qkv_attn_kernel<0, true> : qkv_attn_kernel<0>;
+#define QKV_PICK(n) if (dbg == n && !cls_only) k = qkv_attn_kernel<n>;
+    QKV_DBG_LIST(QKV_PICK)
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS_BYTES, st, p);
+#else
+    // Calls with at least half a chip of patches take the one-wave-per-SIMD kernel (a workgroup per patch, all six heads); fewer patches
+    // keep the (patch, head) units of the 8-wave kernel, which spread over six times as many CUs.  HIPT_QKV_ATTN8=1: always the 8-wave one (A/B).
+    if (cls_only) hipLaunchKernelGGL((qkv_attn_kernel<0, true>), dim3(grid), dim3(512), LDS_BYTES, st, p);
+    else if (2 * nseq >= ncu && !hipt_env_on("HIPT_QKV_ATTN8")) {
+        const int d4 = getenv("HIPT_QKV4_DBG") ? atoi(getenv("HIPT_QKV4_DBG")) : 0;
+        auto k4 = qkv_attn4_kernel<0>;
+#define QKV4_PICK(n) if (d4 == n) k4 = qkv_attn4_kernel<n>;
+        QKV4_PICK(1) QKV4_PICK(2) QKV4_PICK(3) QKV4_PICK(8)
+        hipLaunchKernelGGL(k4, dim3(nseq < ncu ? nseq : ncu), dim3(256), LDS_BYTES, st, p);
+    }
+    else hipLaunchKernelGGL(qkv_attn_kernel<0>, dim3(grid), dim3(512), LDS_BYTES, st, p);
+#endif
+    HIPT_CHECK_LAUNCH();
+#ifdef HIPT_DEBUG_STAMPS
+    if (want_stamps && grid <= 1024) {
+        static unsigned long long h[1024 * 8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, dbuf, (size_t)grid * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const double heads = (double)((p.px * HEADS + p.nslots - 1) / p.nslots);
+        for (int b = 0; b < grid; ++b)
+            for (int k = 0; k < 8; ++k) ph[k] += (double)h[b * 8 + k] / grid / heads;
+        fprintf(stderr, "[qkv_attention nseq=%d grid=%d] cycles per (patch, head) (wave 0): GEMM units %.0f | [CLS] k/v + barrier %.0f | [CLS] query %.0f | scores %.0f | "
+                        "softmax %.0f | PV %.0f | operand loads + stores %.0f  (sum %.0f)\n",
+                nseq, grid, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5] + ph[6]);
+    }
+#endif
+    return HIPT_OK;
+}
+
+int hipt_qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv_b, const void* qkv_cls, void* out_img, int nseq, float scale, hipStream_t st) {
+    return qkv_attn_launch(xn_img, wpk, qkv_b, qkv_cls, out_img, nseq, scale, false, st);
+}
+
+// the [CLS]-pruned block: out = the attention output of token 0 of every patch, compact [nseq, 384] bf16
+int hipt_qkv_attn_cls_launch(const void* xn_img, const void* wpk, const float* qkv_b, const void* qkv_cls, void* out_rows, int nseq, float scale, hipStream_t st) {
+    return qkv_attn_launch(xn_img, wpk, qkv_b, qkv_cls, out_rows, nseq, scale, true, st);
+}

@@ -20,7 +20,7 @@ for ps in "abcd":
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
-            if "qkv_attn_kernel" in n or "attn64" in n or "seqgemm_pipe" in n:
+            if "qkv_attn" in n or "attn64" in n or "seqgemm_pipe" in n:
                 agg[n[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, d in agg.items():
             print(k, {c: sorted(v)[len(v) // 2] for c, v in d.items()}, "launches", len(next(iter(d.values()))))
