@@ -175,8 +175,8 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     // pipelined path: the MLP of block i applies LayerNorm-1 of block i+1 to the rows it finishes and leaves them in
     // s.att as bf16 operands; block i+1's QKV GEMM then skips the fp32 row load + LayerNorm
     // (only the streaming kernels have that epilogue / prologue: every block of the range needs its packed weight images)
-    bool chain = seq && !hipt_generic_only() && hipt_mlp32_supported(dt, D, w->hidden) && hipt_seqgemm_pipe_supported(dt, D, 3 * D, false, 0);
-    for (int i = b0; i < b1 && chain; ++i) chain = w->blocks[i].qkv_pk && w->blocks[i].proj_pk && w->blocks[i].mlp_pk && (w->blocks[i].mlp_pk_fmt == 1 || w->blocks[i].mlp_pk_fmt == 2);
+    bool chain = seq && !hipt_generic_only() && hipt_mlp16_supported(dt, D, w->hidden) && hipt_seqgemm_pipe_supported(dt, D, 3 * D, false, 0);
+    for (int i = b0; i < b1 && chain; ++i) chain = w->blocks[i].qkv_pk && w->blocks[i].proj_pk && w->blocks[i].mlp_pk && w->blocks[i].mlp_pk_fmt == 2;
     bool have_xn = false;
     // activation images: chained streaming blocks, whole 16-row fragments, no probability output
     const bool img = img_ok && chain && probs == nullptr && M % 16 == 0 && !hipt_env_on("HIPT_NO_IMG") && hipt_attention64_supported(dt, dh, w->ntok, false);
@@ -667,14 +667,11 @@ int hipt_vit_attention_unit(const hipt_vit_weights* w, int block, const void* xn
     return hipt_attention_launch(s.qkv, out_img, nullptr, nseq, w->ntok, w->heads, D / w->heads, attn_scale(w), w->dtype, st, 1, hm ? 1 : 0);
 }
 
-// The fused MLP exists on both bf16 MFMA shapes: format 2 = csrc/mlp16.hip (16x16x32, the default since round 4), format 1 =
-// csrc/mlp32.hip (32x32x16; HIPT_MLP32=1 at PACK time).  On the MLP launches themselves the two tie (1 375 us per 8 regions); the
-// 16x16x32 form draws less power, and the kernels between its launches run 3 % faster for it.  The format
-// travels with the image, so a model packed either way keeps running its own kernel whatever the environment says later.
-int hipt_vit_mlp_pack_format(const hipt_vit_weights* w) {
-    if (!(w && hipt_mlp32_supported(w->dtype, w->dim, w->hidden))) return 0;
-    return hipt_env_on("HIPT_MLP32") ? 1 : 2;
-}
+// Format of the fused MLP's weight image: 2 = csrc/mlp16.hip (16x16x32 MFMAs), 0 = this shape has no packed form.  (Format 1 was the
+// 32x32x16 form of rounds 2-4, tools/experiments/mlp32_r4.hip: a tie on the MLP launches themselves, 3 % behind on the kernels that run
+// between them -- DESIGN.md -- and retired in round 5; an image packed as format 1 is refused by the chain test in run_blocks and its
+// model falls back to the generic kernels.)
+int hipt_vit_mlp_pack_format(const hipt_vit_weights* w) { return w && hipt_mlp16_supported(w->dtype, w->dim, w->hidden) ? 2 : 0; }
 
 size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {
     if (!w || w->dtype != HIPT_BF16) return 0;
@@ -706,7 +703,6 @@ int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* 
         case HIPT_PACK_QKV_ATT: return hipt_qkv_attn_pack_launch(b.qkv_w, out, st);
         default:
             // the format the caller recorded beside the pointer (hipt_vit_mlp_pack_format): pack and launch read the same field
-            if (b.mlp_pk_fmt == 1 && hipt_mlp32_supported(w->dtype, D, w->hidden)) return hipt_mlp32_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
             if (b.mlp_pk_fmt == 2 && hipt_mlp16_supported(w->dtype, D, w->hidden)) return hipt_mlp16_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
             hipt_set_error("hipt_vit_pack_weights: blocks[%d].mlp_pk_fmt = %d is not a format this model has", block, b.mlp_pk_fmt);
             return HIPT_E_BADARG;

@@ -110,11 +110,11 @@ struct MlpParams {
     const void* w2;      // bf16 [D, hidden]
     const float* b2;
     int M, D, hidden;
-    const void* wpk;     // optional (streaming kernel only): both weights pre-packed in ring order (hipt_mlp32_pack_launch)
-    int wpk_fmt;         // format of wpk: 1 = mlp32.hip's fragment image, 2 = mlp16.hip's
+    const void* wpk;     // optional (streaming kernel only): both weights pre-packed in ring order (hipt_mlp16_pack_launch)
+    int wpk_fmt;         // format of wpk: 2 = mlp16.hip's fragment image (1 was the retired 32x32x16 form's)
     int img;             // (pipelined kernel only) activation images: bit 0 = y1, xn_out and the updated x, bit 1 = x on entry
     int* counter;        // device int the launcher zeroes on the stream: the kernel's tile queue
-    int counter_zeroed;  // 1: the caller guarantees *counter == 0 at launch (mlp32.hip / mlp_co.hip skip their memset); these kernels leave it 0 again
+    int counter_zeroed;  // 1: the caller guarantees *counter == 0 at launch (mlp16.hip skips its memset); these kernels leave it 0 again
     // optional (pipelined kernel only): LayerNorm-1 of the NEXT block applied to the updated rows, written as bf16
     // [M, D] -- the next block's QKV GEMM then loads operands directly instead of fp32 rows + LayerNorm
     const float* ln_next_w;
@@ -126,16 +126,11 @@ struct MlpParams {
     unsigned long long* stamps;
 };
 bool hipt_mlp_supported(int dtype, int D, int hidden);
-int hipt_mlp_launch(const MlpParams& p, hipStream_t st);  // dispatches to the packed-weight D = 384 kernel (mlp32.hip) when it applies
-// The streaming kernel (mlp32.hip, 32x32x16 MFMAs): its weight stream is ONE contiguous image (2 * hidden * D bf16 = the two
-// matrices, re-ordered): unit after unit in the order a tile pass consumes them, each unit byte for byte what its LDS ring slot
-// holds, so that a DMA piece reads 1 KiB of consecutive bytes instead of 8 row segments of 128 B (2.4x the L2 -> LDS rate).
-bool hipt_mlp32_supported(int dtype, int D, int hidden);
-int hipt_mlp32_launch(const MlpParams& p, hipStream_t st);
-int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);
-// The same kernel on 16x16x32 MFMAs (mlp16.hip; image format 2, same size; the default since round 4): the matrix pipes hold a higher
-// clock on that shape under the power cap, the waves pay twice the MFMA issue -- a tie on the fused MLP itself, +3 % on the kernels
-// that run between its launches.  HIPT_MLP32=1 at pack time selects format 1.
+int hipt_mlp_launch(const MlpParams& p, hipStream_t st);  // dispatches to the packed-weight D = 384 kernel (mlp16.hip) when it applies
+// The streaming kernel (mlp16.hip, 16x16x32 MFMAs): its weight stream is ONE contiguous image (2 * hidden * D bf16 = the two
+// matrices, re-ordered; format 2): unit after unit in the order a tile pass consumes them, each unit byte for byte what its LDS ring
+// slot holds, so that a DMA piece reads 1 KiB of consecutive bytes instead of 8 row segments of 128 B (2.4x the L2 -> LDS rate).
+// (Its 32x32x16 twin of rounds 2-4 -- format 1 -- lives in tools/experiments/mlp32_r4.hip: DESIGN.md.)
 bool hipt_mlp16_supported(int dtype, int D, int hidden);
 int hipt_mlp16_launch(const MlpParams& p, hipStream_t st);
 int hipt_mlp16_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);

@@ -708,11 +708,7 @@ int hipt_mlp16_pack_launch(const void* w1, const void* w2, int D_, int hidden, v
     return HIPT_OK;
 }
 
-#ifdef MLP16_AS_MLP32  // (A/B builds, tools/bench_ab.sh: this object stands in for mlp32.o and takes its format number)
-constexpr int MLP16_FMT = 1;
-#else
-constexpr int MLP16_FMT = 2;
-#endif
+constexpr int MLP16_FMT = 2;  // (include/hipt_abmil.h: hipt_block_weights.mlp_pk_fmt)
 template <int DBG>
 int hipt_mlp16_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     MlpParams p = p_in;
@@ -796,8 +792,3 @@ int hipt_mlp16_launch_dbg(const MlpParams& p_in, hipStream_t st) {
 
 int hipt_mlp16_launch(const MlpParams& p, hipStream_t st) { return hipt_mlp16_launch_dbg<0>(p, st); }
 
-#ifdef MLP16_AS_MLP32  // (A/B builds: this object stands in for mlp32.o -- tools/bench_ab.sh)
-bool hipt_mlp32_supported(int dtype, int D_, int hidden) { return hipt_mlp16_supported(dtype, D_, hidden); }
-int hipt_mlp32_pack_launch(const void* w1, const void* w2, int D_, int hidden, void* packed, hipStream_t st) { return hipt_mlp16_pack_launch(w1, w2, D_, hidden, packed, st); }
-int hipt_mlp32_launch(const MlpParams& p, hipStream_t st) { return hipt_mlp16_launch(p, st); }
-#endif

@@ -414,7 +414,7 @@ class CLAM_SB(nn.Module):
         K = self.attention_net[-1].attention_c.out_features
         if not _train_supported(self._sizes, K, self.n_classes, need_dbag=torch.is_grad_enabled() and h.requires_grad):
             return False
-        return self._multi or dropout_on or _needs_autograd(self, h)
+        return dropout_on or _needs_autograd(self, h)
 
     # ---- HIP inference path ---------------------------------------------------------------------------
     def __getstate__(self):  # the packed weight image (ctypes struct + tensors) is a cache: never pickled / deep-copied
@@ -467,8 +467,10 @@ class CLAM_SB(nn.Module):
         # ... and so does a bag the caller keeps on the CPU (the reference's relocate() chooses the CPU where there is no GPU,
         # models/model_clam.py:102-106): PyTorch ops on the CPU.  A bag on a HIP device never comes this way.
         # (a CPU bag handed to a module that lives on a HIP device is a caller's mistake and raises below)
-        if not self._gate or dropout_on or _needs_autograd(self, h) or self._multi or _all_on_cpu(self, h):
+        if not self._gate or dropout_on or _needs_autograd(self, h) or _all_on_cpu(self, h):
             return self._torch_forward(h, label, instance_eval, return_features, attention_only)
+        if self._multi:
+            return self._multi_infer(h, label, instance_eval, return_features, attention_only)
         N.require_cuda(h, "CLAM_SB")
         if h.dim() != 2 or h.shape[0] == 0:
             raise ValueError(f"expected a non-empty [N, {self.attention_net[0].in_features}] bag, got {tuple(h.shape)}")
@@ -511,8 +513,12 @@ class CLAM_SB(nn.Module):
 
 class CLAM_MB(CLAM_SB):
     """Multi-branch CLAM (model_clam.py:193-264): one attention branch and one ``Linear(S1, 1)`` bag classifier per class.
-    Every forward (training or not) runs the K-branch fp32 kernels of csrc/clam_train.hip; ``gate=False`` and CPU tensors
-    take the PyTorch-op sequence."""
+
+    Inference (eval mode, no gradient asked for) runs the SAME streaming kernels as ``CLAM_SB`` -- MFMA projections, one pass
+    over the bag per branch (``hipt_clam_sb_forward`` with the branch's ``attention_c`` row and its one-row classifier: the K
+    branches share W1 and [Wa; Wb], only ``wc [K, S2]``, ``bc [K]`` and the pooled sums differ), in both compute dtypes; a
+    forward that must be differentiable (or has active dropout) runs the K-branch fp32 training kernels of csrc/clam_train.hip;
+    ``gate=False`` and CPU tensors take the PyTorch-op sequence."""
 
     _multi = True
 
@@ -530,6 +536,79 @@ class CLAM_MB(CLAM_SB):
         for c in self.classifiers:
             out += [c.weight, c.bias]
         return out
+
+    def _pack_branches(self, device):
+        """One ``hipt_clam_weights`` per attention branch for the inference kernels: shared W1 / [Wa; Wb] tensors, the branch's row of
+        ``attention_c`` and its ``Linear(S1, 1)`` as a one-class bag classifier (cached like ``_pack``)."""
+        code = N.dtype_code(self._compute_dtype)
+        N.same_device(type(self).__name__, device, *self.parameters())
+        key = ("mb", code, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        if self._packed is None or self._packed[0] != key:
+            fc1, gated = self.attention_net[0], self.attention_net[-1]
+            wa, wb, wc = gated.attention_a[0], gated.attention_b[0], gated.attention_c
+            shared = dict(
+                w1=Fn.as_compute(fc1.weight, code), b1=Fn.f32c(fc1.bias),
+                wab=Fn.as_compute(torch.cat([wa.weight, wb.weight], dim=0), code),
+                bab=Fn.f32c(torch.cat([wa.bias, wb.bias], dim=0)))
+            wc_all, bc_all = Fn.f32c(wc.weight), Fn.f32c(wc.bias)
+            bounds = wc_all.abs().sum(dim=1).tolist()  # per branch: |A_raw[k] - bc[k]| <= sum_j |wc[k][j]| (one read-back per set of weights)
+            ws, keep = [], [shared, wc_all, bc_all]
+            for k in range(self.n_classes):
+                own = dict(wc=wc_all[k], bc=bc_all[k:k + 1], wcls=Fn.f32c(self.classifiers[k].weight), bcls=Fn.f32c(self.classifiers[k].bias))
+                w = N.ClamWeights()
+                w.dtype, w.s0, w.s1, w.s2, w.n_classes = code, fc1.in_features, fc1.out_features, wa.out_features, 1
+                for name, t in {**shared, **own}.items():
+                    setattr(w, name, t.data_ptr())
+                w.logit_bound = max(float(bounds[k]), 1e-30)
+                nb = N.lib().hipt_clam_stream_packed_bytes(C_.byref(w))
+                if nb:
+                    own["stream_pk"] = torch.empty(nb, dtype=torch.uint8, device=device)
+                    N.call("hipt_clam_stream_pack", C_.byref(w), N.ptr(own["stream_pk"]), N.stream_ptr(device))
+                    w.stream_pk = own["stream_pk"].data_ptr()
+                ws.append(w)
+                keep.append(own)
+            self._packed = (key, ws, keep)
+        return self._packed[1]
+
+    def _multi_infer(self, h, label, instance_eval, return_features, attention_only):
+        """model_clam.py:226-264 without autograd: A [K, N] -> softmax over N per branch -> M [K, S1] -> logits[0, c] =
+        classifiers[c](M[c]) -- branch by branch through the CLAM_SB inference kernels."""
+        N.require_cuda(h, "CLAM_MB")
+        if h.dim() != 2 or h.shape[0] == 0 or h.shape[1] != self._sizes[0]:
+            raise ValueError(f"expected a non-empty [N, {self._sizes[0]}] bag, got {tuple(h.shape)}")
+        ws = self._pack_branches(h.device)
+        dev, K, n = h.device, self.n_classes, h.shape[0]
+        bag = Fn.as_compute(h, ws[0].dtype)
+        st = N.stream_ptr(dev)
+        A_raw = torch.empty((K, n), dtype=torch.float32, device=dev)
+        scratch = Fn.workspace(dev, N.lib().hipt_clam_workspace_bytes(C_.byref(ws[0]), n), ("clam", st.value), zero=True)
+        if attention_only:
+            for k, w in enumerate(ws):
+                N.call("hipt_clam_sb_forward", C_.byref(w), N.ptr(bag), n, 1, N.ptr(A_raw[k]), None, None, None, None, N.ptr(scratch), scratch.numel(), st)
+            return A_raw
+        S1 = self._sizes[1]
+        M = torch.empty((K, S1), dtype=torch.float32, device=dev)
+        logits = torch.empty((1, K), dtype=torch.float32, device=dev)
+        junk_p = torch.empty((K,), dtype=torch.float32, device=dev)      # (the one-class softmax / argmax of a branch: 1 and 0)
+        junk_y = torch.empty((K,), dtype=torch.int64, device=dev)
+        for k, w in enumerate(ws):
+            N.call("hipt_clam_sb_forward", C_.byref(w), N.ptr(bag), n, 0, N.ptr(A_raw[k]), N.ptr(M[k]), N.ptr(logits[0, k:k + 1]), N.ptr(junk_p[k:k + 1]),
+                   N.ptr(junk_y[k:k + 1]), N.ptr(scratch), scratch.numel(), st)
+        Y_hat = torch.topk(logits, 1, dim=1)[1]      # :251-252, on K numbers
+        Y_prob = F.softmax(logits, dim=1)
+        results = {}
+        if instance_eval:
+            # validate_clam (core_utils.py:506-560): top-k / bottom-k ids per branch on the device, only the selected h1 rows recomputed
+            if self.k_sample > n:
+                raise RuntimeError(f"selected index k out of range: k_sample={self.k_sample} > {n} rows (torch.topk, model_clam.py:120)")
+            ids = torch.empty((K, 2, self.k_sample), dtype=torch.int64, device=dev)
+            N.call("hipt_topk_rows", N.ptr(A_raw), K, n, self.k_sample, N.ptr(ids), st)
+            rows = torch.empty((K, 2, self.k_sample, S1), dtype=torch.float32, device=dev)
+            N.call("hipt_clam_gather_h1", C_.byref(ws[0]), N.ptr(bag), N.ptr(ids), 2 * K * self.k_sample, N.ptr(rows), st)
+            results = self._instance_branch(lambda b: (rows[b, 0], rows[b, 1]), label)
+        if return_features:
+            results.update({'features': M})
+        return logits, Y_prob, Y_hat, A_raw, results
 
     def _bag_logits(self, M):  # :248-250
         logits = torch.empty(1, self.n_classes).float().to(M.device)

@@ -375,34 +375,29 @@ def test_vit256_streaming_kernels_vs_generic_kernels(vit256, monkeypatch):
         N.call("hipt_vit_pack_weights", pk32.ref, 0, N.PACK_MLP, N.ptr(x), N.stream_ptr(x.device))
 
 
-def test_vit256_fused_mlp_on_both_mfma_shapes(vit256, monkeypatch):
-    """The fused MLP exists on both bf16 MFMA shapes: csrc/mlp16.hip (16x16x32, image format 2, the default) and csrc/mlp32.hip
-    (32x32x16, format 1, HIPT_MLP32=1 when the weight images are packed).  Another fragment / accumulator layout and another
-    summation order over the same bf16 products: held to the bf16 bar against each other, bit-identical between batchings, and
-    the format travels with the image (no environment at launch)."""
+def test_vit256_fused_mlp_image_format_travels_with_the_image(vit256):
+    """The fused MLP's weight image is format 2 (csrc/mlp16.hip, 16x16x32 MFMAs).  Bit-identical between batchings; an image that claims
+    another format (1: the 32x32x16 form retired in round 5) is not run through the streaming kernel -- the model takes the generic
+    kernels and stays within the bf16 bar."""
     x = synth.hash_uniform_torch((16, 3, 256, 256), 23, device=DEV)
     vit256.set_compute_dtype("bf16")
     try:
         default = vit256(x)
-        assert all(vit256._tokens(x)[0].blocks[i].mlp_pk_fmt == 2 for i in range(12))
-        vit256._packed.clear()
-        monkeypatch.setenv("HIPT_MLP32", "1")
         pk = vit256._tokens(x)[0]
-        monkeypatch.delenv("HIPT_MLP32")
-        assert all(pk.blocks[i].mlp_pk_fmt == 1 and pk.blocks[i].mlp_pk for i in range(12))
-        m16 = vit256(x)
-        assert all(vit256._tokens(x)[0].blocks[i].mlp_pk_fmt == 1 for i in range(12))  # (the same images: still format 1)
-        sub = vit256(torch.cat([x[5:], x]))  # (27 patches: other tiles, other positions inside them, still whole fragments? no: 27 * 257 rows)
+        assert N.lib().hipt_vit_mlp_pack_format(pk.ref) == 2 and all(pk.blocks[i].mlp_pk_fmt == 2 and pk.blocks[i].mlp_pk for i in range(12))
         two = vit256(torch.cat([x, x]))      # 32 patches = whole 16-row fragments, like the 16: the same kernels, other tile positions
+        sub = vit256(torch.cat([x[5:], x]))  # 27 patches: 27 * 257 rows are no whole fragments: row-major path
+        for i in range(12):
+            pk.blocks[i].mlp_pk_fmt = 1     # a stale image format
+        stale = vit256(x)
     finally:
-        monkeypatch.delenv("HIPT_MLP32", raising=False)
         vit256._packed.clear()
         vit256.set_compute_dtype("fp32")
-    rel = float((m16 - default).norm() / default.norm())
-    print(f"fused MLP 32x32x16 vs 16x16x32: [CLS] features rel-L2 {rel:.2e}")
+    assert torch.equal(two[:16], default) and torch.equal(two[16:], default)
+    assert float((sub[11:] - default).norm() / default.norm()) < 1.3e-2
+    rel = float((stale - default).norm() / default.norm())
+    print(f"stale image format -> generic kernels: [CLS] features rel-L2 {rel:.2e}")
     assert 0 < rel < 1.3e-2
-    assert torch.equal(two[:16], m16) and torch.equal(two[16:], m16)
-    assert float((sub[11:] - m16).norm() / m16.norm()) < 1.3e-2  # (27 patches run row-major: another path, the bf16 bar)
 
 
 def test_vit256_patch_embedding_from_fp32_pixels(vit256, monkeypatch):

@@ -134,10 +134,47 @@ def test_clam_mb_eval_forward_vs_reference_golden():
     assert np.array_equal(y_hat.cpu().numpy(), g["Y_hat"])
 
 
+def test_clam_mb_inference_runs_the_streaming_kernels_100k_bf16():
+    """CLAM_MB in eval mode (models/model_clam.py:226-264) on the kernels CLAM_SB's inference uses: bf16, 100 000 x 192, K = 3 branches
+    -- one pass over the bag per branch on the MFMA streaming kernel (round 4: the fp32 VALU training kernels, 0.47 ms at 60 000 rows).
+    Against the module's own PyTorch-op forward in fp32 at CLAM_SB's bf16 bars (A_raw 4e-2, M rel-L2 2e-3), timed with the library's
+    per-kernel HIP events: three launches of 25 us, <= 90 us together (measured 76; the bag is read once per branch -- a kernel that
+    pools all K branches in one pass needs K x 64 more accumulator registers per wave than the streaming kernel has left)."""
+    m = make((192, 128, 64), 193, 3, True, 8, True).eval()
+    h = synth.hash_uniform_torch((100_000, 192), 27, device=DEV)
+    with torch.no_grad():
+        ref = m._torch_forward(h, None, False, True, False)
+        m.set_compute_dtype("bf16")
+        before = N.calls
+        lg, yp, yh, a_raw, res = m(h, return_features=True)
+        assert N.calls >= before + 3 and lg.grad_fn is None
+        att = m(h, attention_only=True)
+        hb = h.bfloat16()
+        for _ in range(3):
+            m(hb)
+        torch.cuda.synchronize()
+        N.profile_enable(True)
+        for _ in range(10):
+            m(hb)
+        torch.cuda.synchronize()
+        prof = N.profile_read()
+        N.profile_enable(False)
+    lr, ypr, yhr, ar, rr = ref
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    print(f"CLAM_MB bf16 100000x192, 3 branches vs fp32 PyTorch ops: A_raw max abs {md(a_raw, ar.cpu().numpy()):.2e}, M rel-L2 {rel(res['features'], rr['features']):.2e}, "
+          f"logits max abs {md(lg, lr.cpu().numpy()):.2e}; kernels {prof}")
+    assert a_raw.shape == (3, 100_000) and torch.equal(att, a_raw)
+    assert md(a_raw, ar.cpu().numpy()) < 4e-2 and rel(res["features"], rr["features"]) < 2e-3 and md(lg, lr.cpu().numpy()) < 2e-3
+    assert int(yh) == int(yhr) and abs(float(yp.sum()) - 1.0) < 1e-6
+    ms, cnt = prof["abmil_fused"]
+    assert cnt == 30 and ms / 10 * 1e3 <= 90.0, prof
+
+
 def test_clam_mb_long_bag_pools_over_many_workgroups():
-    """CLAM_MB's forward is the training kernels' forward; a slide-sized bag (N > 4096) spreads the softmax statistics and the
-    pooling over workgroups (fp32 atomics, like the backward of long bags).  Against the module's own PyTorch-op forward on the
-    same device, with the instance branch's top-k, and timed: one workgroup took ~1 ms per branch at 100 000 rows."""
+    """A slide-sized bag through CLAM_MB in fp32 with the instance branch's top-k (eval mode: the inference kernels, branch by
+    branch, ids by hipt_topk_rows, the selected h1 rows recomputed), against the module's own PyTorch-op forward on the same device, and
+    timed.  (Round 4 ran this on the training kernels' forward, whose pooling of long bags spreads over workgroups with fp32 atomics:
+    test_train_step_vs_oracle_other_shapes still covers that path at 5 000 rows.)"""
     import time
     m = make((192, 128, 64), 193, 3, True, 8, True).eval()
     h = synth.hash_uniform_torch((60000, 192), 26, device=DEV)

@@ -21,7 +21,7 @@ int hipt_mlp_pipe_launch(const MlpParams&, hipStream_t) { return -1; }
 #define LAUNCH(DBG, p) hipt_mlp_co_launch(p, 0)
 #define hipt_mlp_pack_launch hipt_mlp32_pack_launch
 #elif defined(PROBE_32)  // the 32x32x16 form (mlp32.hip); -DPROBE_32
-#include "../hipt_abmil_atec23_amd/csrc/mlp32.hip"
+#include "experiments/mlp32_r4.hip"
 #define LAUNCH(DBG, p) hipt_mlp32_launch_dbg<DBG>(p, 0)
 #define hipt_mlp_pack_launch hipt_mlp32_pack_launch
 #elif defined(PROBE_16)  // the 16x16x32 form of mlp32.hip (csrc/mlp16.hip); -DPROBE_16
