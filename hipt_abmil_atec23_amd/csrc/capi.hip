@@ -131,23 +131,27 @@ int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* 
     return hipt_gemm_launch(p, dtype, ALOAD_PLAIN, flags, st);
 }
 
-// Linears over ONE row per sequence (the [CLS] rows: M = nseq): always in slices the small-M GEMM takes (gemm.hip: a wave per 16 x 32
-// output tile, an element's summation order depends on its column only), however many sequences the call holds -- so that a
-// sequence's bits do not depend on its company (feature_store.extract_slide gathers loader batches on that promise), and 2 048 rows
-// are two launches as the gather + tiled GEMM they replace were.  a_row_step > 0: A is a bf16 activation image, GEMM row r its row
-// r * a_row_step (slices start on whole 16-row fragments, which occupy the bytes of their rows).
-constexpr int ROWS_SLICE = 1024;
+// Linears over ONE row per sequence (the [CLS] rows: M = nseq).  Up to 1 088 rows the small-M GEMM (gemm.hip: a wave per 16 x 32 output
+// tile, reading the rows out of the activation image itself when a_row_step > 0), above that a gather launch (image rows only) + the
+// tiled GEMM -- and BOTH walk k in the same ascending 32-element steps (GemmParams::asc), so that a sequence's bits do not depend
+// on how many sequences share the call (feature_store.extract_slide gathers loader batches on that promise).
+// a_row_step > 0: A is a bf16 activation image, GEMM row r its row r * a_row_step; `gather` = [M, K] scratch for the gathered rows.
 int rows_linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc, int M, int N, int K, int dtype,
-                hipStream_t st, int a_row_step = 0) {
-    const size_t e = esz(dtype);
-    for (int r0 = 0; r0 < M; r0 += ROWS_SLICE) {
-        const int m = M - r0 < ROWS_SLICE ? M - r0 : ROWS_SLICE;
-        const size_t arow = (size_t)r0 * (a_row_step > 0 ? a_row_step : 1);
-        int rc = linear((const char*)A + arow * lda * e, lda, W, ldw, bias, nullptr, (char*)out + (size_t)r0 * ldc * e, ldc, m, N, K, dtype, 0, st, 0, nullptr,
-                        nullptr, 0.f, a_row_step);
-        if (rc) return rc;
+                hipStream_t st, int a_row_step = 0, void* gather = nullptr) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.M = M; p.N = N; p.K = K; p.bias = bias; p.out = out; p.ldc = ldc;
+    p.asc = 1;
+    if (a_row_step > 0) {
+        if (!hipt_generic_only() && hipt_gemm_arows_supported(M, K, dtype, ALOAD_PLAIN, 0)) {
+            p.a_row_step = a_row_step;
+        } else {
+            int rc = hipt_gather_cls_bf16_launch(A, gather, M, a_row_step, K, st, 1);
+            if (rc) return rc;
+            p.A = gather;
+        }
     }
-    return HIPT_OK;
+    return hipt_gemm_launch(p, dtype, ALOAD_PLAIN, 0, st);
 }
 
 // emit_last: the MLP of block b1-1 also writes LayerNorm-1 of block b1 on its output rows (bf16, s.att), for a caller
@@ -212,12 +216,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
                 char* qcls = qa + al256((size_t)nseq * D * 2);                   // [nseq, 3 D] bf16 + 1 KiB the kernel's row DMA may read past the end
                 // (nseq rows are a handful of the streaming kernel's 192-row tiles -- 11 CUs for 2 048 patches; the generic GEMM tiles N as well.
                 //  Up to 1 088 sequences the small-M GEMM reads the [CLS] rows out of the image itself: one launch, not two)
-                if (!hipt_generic_only() && hipt_gemm_arows_supported(nseq < ROWS_SLICE ? nseq : ROWS_SLICE, D, dt, ALOAD_PLAIN, 0)) {
-                    PROF(PC_CLSROWS, rows_linear(s.att, D, b.qkv_w, D, b.qkv_b, qcls, 3 * D, nseq, 3 * D, D, dt, st, w->ntok));
-                } else {
-                    PROF(PC_CLSROWS, hipt_gather_cls_bf16_launch(s.att, qa, nseq, w->ntok, D, st, 1));
-                    PROF(PC_CLSROWS, linear(qa, D, b.qkv_w, D, b.qkv_b, nullptr, qcls, 3 * D, nseq, 3 * D, D, dt, 0, st));
-                }
+                PROF(PC_CLSROWS, rows_linear(s.att, D, b.qkv_w, D, b.qkv_b, qcls, 3 * D, nseq, 3 * D, D, dt, st, w->ntok, qa));
                 PROF(PC_QKVATT, hipt_qkv_attn_launch(s.att, b.qkv_att_pk, b.qkv_b, qcls, s.qkv, nseq, scale, st));
                 att_out = s.qkv;
             } else if (have_xn) {  // LayerNorm-1 already applied by the previous block's MLP epilogue

@@ -222,7 +222,8 @@ template <int EPC> __device__ __forceinline__ constexpr int pair_off(int s) { re
 // k order: ASCENDING in steps of KC consecutive values, no pairing, no staggered start -- the k sets and the order of the tiled kernel's
 // MFMAs (and of embed32.hip's), so that the tokens are the same bits whichever of the three kernels a call's size selects; and nothing is
 // lost: the 16 rows of a wave are the 16 tokens of one token row, whose 64-byte pixel runs are consecutive in the image.
-template <typename T, int FLAGS, bool EVEN, bool AIMG = false, bool AI2C = false>
+// ASC (EVEN): the same ascending order for plain / image rows (GemmParams::asc): one-row-per-sequence GEMMs whose larger calls run on the tiled kernel.
+template <typename T, int FLAGS, bool EVEN, bool AIMG = false, bool AI2C = false, bool ASC = false>
 __global__ __launch_bounds__(64) void gemm_small_kernel(const GemmParams p) {
     const int lane = threadIdx.x;
     const int li = lane & 15, g = lane >> 4;
@@ -231,10 +232,11 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(const GemmParams p) {
     constexpr int EPC = Tr<T>::EPC, KC = 4 * EPC;
     int r = row0 + li;
     r = r < p.M ? r : p.M - 1;                      // (padding rows re-read the last valid row: never stored)
-    const T* ap = (const T*)p.A + (int64_t)r * p.lda + g * (EVEN ? 2 * EPC : EPC);
+    const T* ap = (const T*)p.A + (int64_t)r * p.lda + g * (EVEN && !ASC ? 2 * EPC : EPC);
     if constexpr (AIMG) {
         const int64_t R = (int64_t)r * p.a_row_step;
-        ap = (const T*)p.A + (R >> 4) * (16 * 384) + (int)(R & 15) * 8 + (g >> 1) * 512 + (g & 1) * 256;
+        // (ascending order: chunk m = 4 kk + g of step kk -> lane part (g >> 1) * 256 + (g & 1) * 128, step part kk * 512)
+        ap = (const T*)p.A + (R >> 4) * (16 * 384) + (int)(R & 15) * 8 + (ASC ? (g >> 1) * 256 + (g & 1) * 128 : (g >> 1) * 512 + (g & 1) * 256);
     }
     const int i2c_rs = (int)p.im.row_stride, i2c_cs = (int)p.im.chan_stride;
     if constexpr (AI2C) {  // pixel (0, 0) of token r's 16 x 16 window, channel 0 (ALoader::init above)
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(const GemmParams p) {
     for (int j = 0; j < 2; ++j) {
         int n = n0 + j * 16 + li;
         n = n < p.N ? n : p.N - 1;
-        wp[j] = (const T*)p.W + (int64_t)n * p.ldw + g * (EVEN && !AI2C ? 2 * EPC : EPC);
+        wp[j] = (const T*)p.W + (int64_t)n * p.ldw + g * (EVEN && !AI2C && !ASC ? 2 * EPC : EPC);
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const int nk = p.K / KC;
@@ -262,17 +264,18 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(const GemmParams p) {
         // COLUMN tile (and wraps): with a row pitch of 3072 B (K = 1536 in bf16) the 16 rows of a request fall on 4 of the 16 L2
         // channels at any one k -- staggered starts spread the waves of a row tile over all of them.  The summation order of an
         // output element depends on its column only, not on which rows share the call.
-        const int rot = AI2C ? 0 : ((n0 >> 5) * 4) % nk;
+        const int rot = AI2C || ASC ? 0 : ((n0 >> 5) * 4) % nk;
         auto kstep = [&](int j) {
             int kk = rot + j;
             return kk >= nk ? kk - nk : kk;
         };
-        auto woff = [&](int kk) { return AI2C ? kk * KC : pair_off<EPC>(kk); };
+        auto woff = [&](int kk) { return AI2C || ASC ? kk * KC : pair_off<EPC>(kk); };
         auto aoff = [&](int kk) {
             if constexpr (AI2C) {
                 const int k = kk * KC + g * EPC;  // (the lane part is not in `ap` here)
                 return (k >> 8) * i2c_cs + ((k >> 4) & 15) * i2c_rs + (k & 15);
             }
+            if constexpr (ASC) return AIMG ? kk * 512 : kk * KC;
             return AIMG ? (kk >> 1) * 1024 + (kk & 1) * 128 : pair_off<EPC>(kk);
         };
 #pragma unroll
@@ -457,13 +460,17 @@ int launch(const GemmParams& p, hipStream_t st) {
         }
         if (p.a_row_step > 0) {  // (checked by hipt_gemm_launch: bf16, small M, K = 384, plain epilogue)
             if constexpr (FLAGS == 0 && sizeof(T) == 2) {
-                hipLaunchKernelGGL((gemm_small_kernel<T, 0, true, true>), sgrid, dim3(64), 0, st, p);
+                if (p.asc) hipLaunchKernelGGL((gemm_small_kernel<T, 0, true, true, false, true>), sgrid, dim3(64), 0, st, p);
+                else hipLaunchKernelGGL((gemm_small_kernel<T, 0, true, true>), sgrid, dim3(64), 0, st, p);
                 HIPT_CHECK_LAUNCH();
                 return HIPT_OK;
             }
         }
         if (p.M <= SMALL_M && p.K % (4 * Tr<T>::EPC) == 0) {
-            if (p.K % (SMALL_RING * 4 * Tr<T>::EPC) == 0)
+            if (p.asc && p.K % (SMALL_RING * 4 * Tr<T>::EPC) == 0) {
+                if constexpr (FLAGS == 0) hipLaunchKernelGGL((gemm_small_kernel<T, 0, true, false, false, true>), sgrid, dim3(64), 0, st, p);
+                else hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS, false>), sgrid, dim3(64), 0, st, p);  // (the guarded ring walks k in ascending order too)
+            } else if (p.K % (SMALL_RING * 4 * Tr<T>::EPC) == 0)
                 hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS, true>), sgrid, dim3(64), 0, st, p);
             else
                 hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS, false>), sgrid, dim3(64), 0, st, p);

@@ -32,6 +32,9 @@ struct GemmParams {
     // rows gathered from an activation image (small calls only, hipt_gemm_arows_supported): A is a bf16 image [.., 384] and GEMM row r
     // is image row r * a_row_step (the [CLS] rows of the sequences: a_row_step = tokens per sequence)
     int a_row_step;
+    // small-M kernel only: k in ASCENDING 32-byte steps (no pairing, no staggered start) -- the k sets and the order of the tiled kernel's
+    // MFMAs, so that an output element is the same bits whichever of the two kernels a call's row count selects (capi.hip: rows_linear)
+    int asc;
 };
 bool hipt_gemm_arows_supported(int M, int K, int dtype, int aload, int flags);
 
