@@ -106,7 +106,6 @@ struct QkvAttnParams {
                            // its slots: slot j takes units j, j + nslots, .. -- the 32 units in flight on an XCD are 5-6 patches, whose
                            // rows the six heads read through ONE L2 instead of from the fabric six times
     unsigned long long* stamps;  // diagnostic builds: per-workgroup cycle sums of the phases (8 per workgroup), or null
-    int prio;                    // 1: waves 4-7 (the second wave of every SIMD, the loser of the age-based issue arbitration) run at s_setprio 1
 };
 
 // phase stamps (make DEBUG_STAMPS=1 only): wave 0 of every workgroup adds the cycles between consecutive marks to a sum per phase
@@ -254,8 +253,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         *dst = (bf16_t)(o / L);
     };
 
-    // static priority for the younger half (MI355X_MICROARCH.md, "Two waves per SIMD", item 4): one s_setprio, no per-phase flips
-    if (p.prio && w >= 4) __builtin_amdgcn_s_setprio(1);
+    // (static priority for waves 4-7 -- MI355X_MICROARCH.md, "Two waves per SIMD", item 4 -- measured in round 5: 864 / 866 us per
+    //  attention unit without, 872 / 854 with: noise; not kept)
     QSTAMP_DECL;
     int pq = 0;          // parity of the patch counter: which [CLS] partial buffer / [CLS] row buffer
     int prev_b = -1, prev_hs = 0;  // work unit whose partials wait for their merge
@@ -738,7 +737,6 @@ static int qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv
     p.sl2e = scale * 1.4426950408889634f;
     p.out_bytes = (unsigned)((int64_t)nseq * (cls_only ? 1 : NTOK) * D * 2);
     p.stamps = nullptr;
-    p.prio = hipt_env_on("HIPT_QKVATT_PRIO") ? 1 : 0;
     // every CU gets a workgroup; the (patch, head) units of an eighth of the patches go round the workgroups of one XCD (QkvAttnParams)
     const int ncu = once.ncu[dev];
     p.px = (nseq + 7) / 8;

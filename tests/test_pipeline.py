@@ -314,6 +314,7 @@ def test_bench_one_rank_through_the_launcher_reports_rccl_ranks():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
+    assert r.stdout.strip() == lines[0], "stdout must hold the JSON line and nothing else (RCCL prints a version banner to fd 1): " + r.stdout[:300]
     assert d["rccl_ranks"] == 1 and d["collective_backend"] == "nccl" and d["n_gpus"] == 1 and d["value"] > 0
     assert d["config5"]["gathered_logits_shape"] == [4, 2]
     assert d["selfcheck"] in ("ok", "skipped"), d.get("selfcheck_detail")
