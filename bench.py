@@ -137,12 +137,16 @@ SUSTAINED_HBM_GBS = 6200.0
 MFMA_SHAPE_OF = {"mlp_fused": "16x16x32", "qkv_attention_fused": "32x32x16", "qkv_gemm": "16x16x32", "proj_gemm": "16x16x32", "attention": "16x16x32"}
 
 
+PROJ_FOLDED = [False]  # set by main(): the library runs the output projection inside the fused MLP kernel (image format 3, no HIPT_NO_PROJ_FOLD)
+
+
 def kernel_flops(cat, rows, D=384, H=1536, heads=6, ntok=257):
-    """Algorithmic FLOPs of one launch of a kernel category over `rows` token rows."""
+    """Algorithmic FLOPs of one launch of a kernel category over `rows` token rows.  With the proj fold the fused MLP's
+    launches also do the attention block's output projection (75 792 384 FLOP per patch and block): counted where it runs."""
     dh = D // heads
     att = 4 * (rows // ntok) * heads * ntok * ntok * dh
     return {"qkv_gemm": 2 * rows * 3 * D * D, "proj_gemm": 2 * rows * D * D,
-            "fc1_gemm": 2 * rows * D * H, "fc2_gemm": 2 * rows * D * H, "mlp_fused": 4 * rows * D * H,
+            "fc1_gemm": 2 * rows * D * H, "fc2_gemm": 2 * rows * D * H, "mlp_fused": 4 * rows * D * H + (2 * rows * D * D if PROJ_FOLDED[0] else 0),
             "attention": att, "qkv_attention_fused": 2 * rows * 3 * D * D + att}.get(cat)
 
 
@@ -527,8 +531,15 @@ def main():
     out["kernels"] = kernels
     # every launch of these categories is a full-size one (the [CLS]-row launches of the pruned last block are booked
     # under 'last_block_cls'): rows per launch = one chunk of patches x 257, or all of the step's patches when fewer
+    try:
+        pk256 = model.model256._packed_for(model.model256._pos_for(256, 256, 256))
+        PROJ_FOLDED[0] = N.lib().hipt_vit_mlp_pack_format(pk256.ref) == 3 and os.environ.get("HIPT_NO_PROJ_FOLD", "0") in ("", "0")
+    except Exception:
+        PROJ_FOLDED[0] = False
     rows_launch = min(chunk, 256 * R) * 257
     mf = {c: v for c, v in kernels.items() if kernel_flops(c, rows_launch)}
+    if PROJ_FOLDED[0]:
+        mf.pop("proj_gemm", None)  # (what is left in that category are the second-level ViT's small launches: no full-size proj launch exists)
     flops_of = lambda c: kernel_flops(c, rows_launch)
     if mf and (256 * R) % min(chunk, 256 * R) == 0:
         frac = {}
@@ -540,9 +551,30 @@ def main():
                            "frac": frac[dom]["frac"], "mfma_shape": MFMA_SHAPE_OF.get(dom), "peak_sustained": SUSTAINED_TFLOPS.get(MFMA_SHAPE_OF.get(dom)),
                            "frac_of_sustained": (frac[dom]["achieved"] / SUSTAINED_TFLOPS[MFMA_SHAPE_OF[dom]]) if args.dtype == "bf16" and dom in MFMA_SHAPE_OF else None,
                            "traffic": pmc_traffic(dom), "traffic_source": pmc_traffic(dom, True)[1], "flops_per_launch": flops_of(dom),
-                           "rows_per_launch": rows_launch, "launches_per_step": mf[dom]["launches_per_step"], "avg_launch_us": mf[dom]["avg_us"]}
-        out["roofline_all"] = {c: round(f["frac"], 4) for c, f in frac.items()}
-        if all(c in frac for c in ("qkv_attention_fused", "proj_gemm")):
+                           "rows_per_launch": rows_launch, "launches_per_step": mf[dom]["launches_per_step"], "avg_launch_us": mf[dom]["avg_us"],
+                           "proj_folded_into_fused_mlp": PROJ_FOLDED[0]}
+        # (only the categories whose every launch is a full-size one: the others also hold the second-level ViT's small launches, whose
+        #  average time says nothing about a 2 048-patch launch)
+        out["roofline_all"] = {c: round(f["frac"], 4) for c, f in frac.items() if c in ("mlp_fused", "qkv_attention_fused")}
+        if PROJ_FOLDED[0] and "qkv_attention_fused" in frac and "mlp_fused" in frac:
+            # north_star's "ViT-256 attention" unit with the output projection folded into the fused MLP kernel: the fused QKV + attention kernel,
+            # the side GEMM over the [CLS] rows, and proj's share of the fused MLP launch -- its share of that launch's FLOPs, i.e. proj is
+            # priced at the pace of the kernel it runs in (6 of its 54 ring phases)
+            side = kernels.get("qkv_cls_rows", {}).get("ms_per_step", 0.0) / kernels["qkv_attention_fused"]["launches_per_step"] * 1e3
+            fl_proj = 2 * rows_launch * 384 * 384
+            share = fl_proj / kernel_flops("mlp_fused", rows_launch)
+            proj_us = frac["mlp_fused"]["avg_launch_us"] * share
+            us = frac["qkv_attention_fused"]["avg_launch_us"] + side + proj_us
+            fl = kernel_flops("qkv_attention_fused", rows_launch) + fl_proj
+            out["roofline_attention_unit"] = {"kernels": ["qkv_attention_fused", "qkv_cls_rows", "mlp_fused (proj share)"], "bound": "mfma", "us_per_launch_set": us,
+                                              "cls_rows_us_per_block": side, "proj_share_of_fused_mlp": share, "proj_us_inside_fused_mlp": proj_us,
+                                              "achieved": fl / (us * 1e-6) / 1e12, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                                              "frac": fl / (us * 1e-6) / 1e12 / PEAK_TFLOPS[args.dtype], "target": 0.60,
+                                              "mfma_shape": "32x32x16", "peak_sustained": SUSTAINED_TFLOPS["32x32x16"],
+                                              "frac_of_sustained": fl / (us * 1e-6) / 1e12 / SUSTAINED_TFLOPS["32x32x16"],
+                                              "traffic": pmc_traffic("qkv_attention_fused"),
+                                              "traffic_source": pmc_traffic("qkv_attention_fused", True)[1]}
+        elif all(c in frac for c in ("qkv_attention_fused", "proj_gemm")):
             # north_star's "ViT-256 attention" unit (LN1 + QKV + QK^T + softmax + PV + proj = 404 620 800 FLOP per patch and block) as the
             # LayerNorm-chained blocks run it: the fused QKV + attention kernel, the side GEMM over the [CLS] rows (two small launches,
             # booked as 'qkv_cls_rows': their time per block is added), the proj GEMM

@@ -180,7 +180,7 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     // s.att as bf16 operands; block i+1's QKV GEMM then skips the fp32 row load + LayerNorm
     // (only the streaming kernels have that epilogue / prologue: every block of the range needs its packed weight images)
     bool chain = seq && !hipt_generic_only() && hipt_mlp16_supported(dt, D, w->hidden) && hipt_seqgemm_pipe_supported(dt, D, 3 * D, false, 0);
-    for (int i = b0; i < b1 && chain; ++i) chain = w->blocks[i].qkv_pk && w->blocks[i].proj_pk && w->blocks[i].mlp_pk && w->blocks[i].mlp_pk_fmt == 2;
+    for (int i = b0; i < b1 && chain; ++i) chain = w->blocks[i].qkv_pk && w->blocks[i].proj_pk && w->blocks[i].mlp_pk && (w->blocks[i].mlp_pk_fmt == 2 || w->blocks[i].mlp_pk_fmt == 3);
     bool have_xn = false;
     // activation images: chained streaming blocks, whole 16-row fragments, no probability output
     const bool img = img_ok && chain && probs == nullptr && M % 16 == 0 && !hipt_env_on("HIPT_NO_IMG") && hipt_attention64_supported(dt, dh, w->ntok, false);
@@ -231,14 +231,19 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             // (with activation images the attention output is one too: proj then reads its operands 1 KiB at a time)
             if (!fuse) PROF(cATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st, img ? 1 : 0, hm ? 1 : 0));
             if (last_probs) break;
-            // (proj folded into the fused MLP was measured break-even -- DESIGN.md -- and lives on as an experiment build only)
-            q.A = att_out; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
-            q.counter = (int*)s.hid + 32;
-            q.img = img ? 3 : 0;  // A = the attention output image, out = y1 image
-            PROF(cPROJ, hipt_seqgemm_launch(q, false, 0, st));
+            // image format 3 (round 5): the output projection runs at the head of the fused MLP's tiles (mlp16.hip, FOLD) -- no proj launch, no y1
+            const bool fold = chain && b.mlp_pk_fmt == 3 && !hipt_env_on("HIPT_NO_PROJ_FOLD");
+            if (!fold) {
+                q.A = att_out; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
+                q.counter = (int*)s.hid + 32;
+                q.img = img ? 3 : 0;  // A = the attention output image, out = y1 image
+                PROF(cPROJ, hipt_seqgemm_launch(q, false, 0, st));
+            }
             MlpParams m;
             memset(&m, 0, sizeof(m));
-            m.x = x; m.y1 = s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
+            m.x = x; m.y1 = fold ? att_out : s.xn; m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
+            m.fold = fold ? 1 : 0;
+            m.bproj = b.proj_b;
             m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.wpk_fmt = b.mlp_pk_fmt; m.M = M; m.D = D; m.hidden = w->hidden;
             m.counter = (int*)s.hid;
             m.counter_zeroed = qz ? 1 : 0;
@@ -670,7 +675,10 @@ int hipt_vit_attention_unit(const hipt_vit_weights* w, int block, const void* xn
 // 32x32x16 form of rounds 2-4, tools/experiments/mlp32_r4.hip: a tie on the MLP launches themselves, 3 % behind on the kernels that run
 // between them -- DESIGN.md -- and retired in round 5; an image packed as format 1 is refused by the chain test in run_blocks and its
 // model falls back to the generic kernels.)
-int hipt_vit_mlp_pack_format(const hipt_vit_weights* w) { return w && hipt_mlp16_supported(w->dtype, w->dim, w->hidden) ? 2 : 0; }
+// 3 (round 5, what this version packs) = format 2 behind six units of the proj matrix: the attention block's output projection then runs at the
+// head of the fused MLP's tiles (mlp16.hip, FOLD) and the chained blocks have no proj launch.  HIPT_NO_PROJ_FOLD=1 at LAUNCH time runs proj as its
+// own kernel again from the same image (the MLP's own units lie behind the proj units); an image packed as format 2 by an older binding still runs.
+int hipt_vit_mlp_pack_format(const hipt_vit_weights* w) { return w && hipt_mlp16_supported(w->dtype, w->dim, w->hidden) ? 3 : 0; }
 
 size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {
     if (!w || w->dtype != HIPT_BF16) return 0;
@@ -678,7 +686,7 @@ size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what) {
     switch (what) {
         case HIPT_PACK_QKV: return hipt_seqgemm_pipe_supported(w->dtype, D, 3 * D, false, 0) ? (size_t)3 * D * D * 2 : 0;
         case HIPT_PACK_PROJ: return hipt_seqgemm_pipe_supported(w->dtype, D, D, false, 0) ? (size_t)D * D * 2 : 0;
-        case HIPT_PACK_MLP: return hipt_vit_mlp_pack_format(w) != 0 ? (size_t)2 * D * w->hidden * 2 : 0;
+        case HIPT_PACK_MLP: return hipt_vit_mlp_pack_format(w) != 0 ? hipt_mlp16_packed_bytes(D, w->hidden, hipt_vit_mlp_pack_format(w) == 3) : 0;
         case HIPT_PACK_QKV_ATT: return hipt_qkv_attn_supported(w->dtype, D, w->heads, w->ntok) ? hipt_qkv_attn_packed_bytes() : 0;
         default: return 0;
     }
@@ -702,7 +710,8 @@ int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* 
         case HIPT_PACK_QKV_ATT: return hipt_qkv_attn_pack_launch(b.qkv_w, out, st);
         default:
             // the format the caller recorded beside the pointer (hipt_vit_mlp_pack_format): pack and launch read the same field
-            if (b.mlp_pk_fmt == 2 && hipt_mlp16_supported(w->dtype, D, w->hidden)) return hipt_mlp16_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st);
+            if ((b.mlp_pk_fmt == 2 || b.mlp_pk_fmt == 3) && hipt_mlp16_supported(w->dtype, D, w->hidden))
+                return hipt_mlp16_pack_launch(b.fc1_w, b.fc2_w, D, w->hidden, out, st, b.mlp_pk_fmt == 3 ? b.proj_w : nullptr);
             hipt_set_error("hipt_vit_pack_weights: blocks[%d].mlp_pk_fmt = %d is not a format this model has", block, b.mlp_pk_fmt);
             return HIPT_E_BADARG;
     }

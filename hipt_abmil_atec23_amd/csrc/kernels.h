@@ -102,9 +102,9 @@ int hipt_seqgemm_pack_launch(const void* W, int N, int K, void* packed, hipStrea
 // Fused MLP sub-block (mlp.hip): x <- x + y1 + fc2(GELU(fc1(LN2(x + y1))))
 struct MlpParams {
     float* x;            // fp32 [M, D] residual stream, updated in place
-    const void* y1;      // bf16 [M, D] attention-branch output still to be added (or null)
-    const float* bproj;  // (unused: the proj-folding experiment of round 2 lives in tools/experiments/mlp32_r3.hip)
-    int fold;            // (must be 0)
+    const void* y1;      // bf16 [M, D] attention-branch output still to be added (or null); fold: the ATTENTION OUTPUT, before proj
+    const float* bproj;  // fold: the proj bias [D]
+    int fold;            // 1 (mlp16.hip, image format 3 only): the output projection runs at the head of the tile, no proj launch before this kernel
     const float* ln_w;
     const float* ln_b;
     float ln_eps;
@@ -114,7 +114,7 @@ struct MlpParams {
     const float* b2;
     int M, D, hidden;
     const void* wpk;     // optional (streaming kernel only): both weights pre-packed in ring order (hipt_mlp16_pack_launch)
-    int wpk_fmt;         // format of wpk: 2 = mlp16.hip's fragment image (1 was the retired 32x32x16 form's)
+    int wpk_fmt;         // format of wpk: 2 = mlp16.hip's fragment image, 3 = the same behind six proj units (1 was the retired 32x32x16 form's)
     int img;             // (pipelined kernel only) activation images: bit 0 = y1, xn_out and the updated x, bit 1 = x on entry
     int* counter;        // device int the launcher zeroes on the stream: the kernel's tile queue
     int counter_zeroed;  // 1: the caller guarantees *counter == 0 at launch (mlp16.hip skips its memset); these kernels leave it 0 again
@@ -136,7 +136,8 @@ int hipt_mlp_launch(const MlpParams& p, hipStream_t st);  // dispatches to the p
 // (Its 32x32x16 twin of rounds 2-4 -- format 1 -- lives in tools/experiments/mlp32_r4.hip: DESIGN.md.)
 bool hipt_mlp16_supported(int dtype, int D, int hidden);
 int hipt_mlp16_launch(const MlpParams& p, hipStream_t st);
-int hipt_mlp16_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st);
+size_t hipt_mlp16_packed_bytes(int D, int hidden, bool with_proj);
+int hipt_mlp16_pack_launch(const void* w1, const void* w2, int D, int hidden, void* packed, hipStream_t st, const void* wproj = nullptr);
 
 int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, const float* b, void* out, int out_dtype,
                           int64_t out_stride, int rows, int D, float eps, hipStream_t st);

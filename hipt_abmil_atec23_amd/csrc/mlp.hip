@@ -482,7 +482,7 @@ int hipt_mlp_launch(const MlpParams& p, hipStream_t st) {
                        ((uintptr_t)p.y1 % 16) == 0,
                    "mlp: 16-byte alignment required");
     // the streaming kernel (mlp16.hip) runs from its packed weight image: callers without one get the generic kernel below
-    if (!hipt_generic_only() && p.wpk && p.wpk_fmt == 2 && hipt_mlp16_supported(HIPT_BF16, p.D, p.hidden)) return hipt_mlp16_launch(p, st);
+    if (!hipt_generic_only() && p.wpk && (p.wpk_fmt == 2 || p.wpk_fmt == 3) && hipt_mlp16_supported(HIPT_BF16, p.D, p.hidden)) return hipt_mlp16_launch(p, st);
     HIPT_CHECK_ARG(p.img == 0 && !p.xn_out && !p.fold, "mlp: activation images / the chained LayerNorm exist only in the streaming kernel (img=%d)", p.img);
     if (p.D == 384) return launch<6>(p, st);
     if (p.D == 192) return launch<3>(p, st);

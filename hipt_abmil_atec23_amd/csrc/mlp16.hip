@@ -51,7 +51,7 @@ __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b
 #define PSTAMP_CLK(k) (void)stamp_clk
 #endif
 
-enum { KA = 0, KB = 1 };  // phase kind: fc1 half / fc2 half
+enum { KA = 0, KB = 1, KP = 2 };  // phase kind: fc1 half / fc2 half / proj unit (FOLD: H = unit 0..5, operand = the attention rows in X)
 
 // Ring unit `pos` of a tile pass: positions A0(0) A1(0) B0(0) | A0(c) B1(c-1) A1(c) B0(c) ... | B1(n-1)
 __device__ __forceinline__ void unit_of(int pos, int nchunk, bool& is_a, int& c, int& h) {
@@ -78,11 +78,20 @@ __device__ __forceinline__ void unit_of(int pos, int nchunk, bool& is_a, int& c,
 //       W1[Hb + 16 U + i][32 s + 16 (j >> 2) + 4 g + (j & 3)]
 //   fc2 unit: fragment 4 gg + f (group gg 0..11; f = 2 (O' & 1) + t': output tile O' = 2 gg + (f >> 1), k-step t' 0/1): element j =
 //       W2[16 O' + i][Hb + 32 t' + 16 (j >> 2) + 4 g + (j & 3)]
-__global__ void mlp16_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2, int hidden, u32x4* __restrict__ out) {
-    const int nchunk = hidden / 128, upt = 4 * nchunk;
+//   proj units (format 3 only: six units IN FRONT of the pass, wp = the proj matrix [D, D]): unit pu, fragment 4 gg + f as an fc2 unit (output tile
+//       O' = 2 gg + (f >> 1), k-step ks = 2 pu + (f & 1)): element j = Wproj[16 O' + i][32 ks + 8 g + j] -- 8 CONSECUTIVE columns per lane group, the
+//       chunk order in which the attention output (row-major or image) is loaded as the other operand
+__global__ void mlp16_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2, const bf16_t* __restrict__ wp, int hidden,
+                                  u32x4* __restrict__ out) {
+    const int nchunk = hidden / 128, upt = 4 * nchunk, npu = wp ? 6 : 0;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte lane chunk
-    if (i >= (int64_t)upt * (UNIT / 16)) return;
-    const int pos = (int)(i / (UNIT / 16)), o = (int)(i % (UNIT / 16)), frag = o >> 6, lane = o & 63, r = lane & 15, g = lane >> 4;
+    if (i >= (int64_t)(upt + npu) * (UNIT / 16)) return;
+    const int pos = (int)(i / (UNIT / 16)) - npu, o = (int)(i % (UNIT / 16)), frag = o >> 6, lane = o & 63, r = lane & 15, g = lane >> 4;
+    if (pos < 0) {
+        const int pu = pos + npu, gg = frag >> 2, f = frag & 3, O = 2 * gg + (f >> 1), ks = 2 * pu + (f & 1);
+        out[i] = *(const u32x4*)(wp + (int64_t)(16 * O + r) * D + 32 * ks + 8 * g);
+        return;
+    }
     bool is_a;
     int c, hh;
     unit_of(pos, nchunk, is_a, c, hh);
@@ -103,7 +112,11 @@ __global__ void mlp16_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* _
 // images; XIN: x is read as an image.  Row-major otherwise.  Weights always come from the packed image p.wpk (format 1).
 // DBG (tools/mlp_probe.hip only): 1 = no weight DMA / ring syncs, 2 = GELU replaced by a plain pack, 4 = no MFMAs, 8 = no LDS
 // fragment reads.
-template <bool IMG = false, bool XIN = false, int DBG = 0>
+// FOLD (round 5; image format 3): the attention block's output projection runs at the head of the tile -- p.y1 is then the ATTENTION OUTPUT (before
+// proj; row-major or image like y1), six more ring units in front of the pass hold the proj matrix, the fc2 accumulators start from x + b_proj, take
+// att Wproj^T through six KB-shaped phases (the attention rows sit in X's registers: same shape), and v = x + proj(att) + b is what LayerNorm-2 reads
+// back from them: the proj launch, its 0.8 GB of HBM traffic per 2 048 patches and the bf16 rounding of y1 are gone.
+template <bool IMG = false, bool XIN = false, int DBG = 0, bool FOLD = false>
 __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
     // RING2 (round 4): TWO weight units in flight.  Rounds 1-3 requested unit c + 1 in groups 0..4 of phase c and waited for it at the
     // end of the same phase: the last pieces had 7 groups (~0.8 us) to come from L2 -- under the load of 256 CUs streaming the image
@@ -125,17 +138,18 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
     int* tile_s = (int*)(b1s + p.hidden);  // [2] tile handed to this workgroup, double-buffered by parity
     float* gam1 = (float*)(tile_s + 4);    // next block's LayerNorm-1 (gamma | beta), if p.xn_out
     float* pfj = gam1 + 2 * D;             // [64] where the L2-prefetch loads below drop their dwords (never read)
+    float* bps = pfj + 64;                 // [D] proj bias (FOLD)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunk = p.hidden / 128;
-    const int upt = 4 * nchunk;                   // ring units (phases) per tile pass
+    const int upt = 4 * nchunk + (FOLD ? 6 : 0);  // ring units (phases) per tile pass
 
     // ---- weight DMA: unit pos of the image = 48 pieces of 1 KiB, byte for byte what its ring slot holds; wave w issues pieces
     // 12 w .. 12 w + 11.  An LDS-DMA instruction takes its LDS base from M0, and it is WRITING M0 that makes a piece expensive
     // (tools/issue_mix_probe.hip: +36 cycles per piece with a new M0, +2 with the same M0 and the piece selected by the instruction's
     // immediate offset, which is added to the LDS and to the global address alike): four consecutive pieces share one M0.
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, 2 * p.hidden * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, 2 * p.hidden * D * 2 + (FOLD ? D * D * 2 : 0), 0x00020000);
     const uint32_t ilane = (uint32_t)(12 * wave * 1024 + lane * 16);
     int ioff = 0, islot = 0, ipos = 0;
     auto set_issue = [&](int pos, int slot) {
@@ -175,6 +189,7 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
         gam[i] = p.ln_w[i];
         bet[i] = p.ln_b[i];
         b2s[i] = p.b2[i];
+        if constexpr (FOLD) bps[i] = p.bproj[i];
         if (p.xn_out) {
             gam1[i] = p.ln_next_w[i];
             gam1[D + i] = p.ln_next_b[i];
@@ -358,7 +373,10 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
 #pragma unroll
                     for (int f = 0; f < 4; ++f)
 #pragma unroll
-                        for (int mm = 0; mm < 2; ++mm) mma16<DBG>(acc2[2 * gg + (f >> 1)][mm], wA[set][f], hf[hh][f & 1][mm]);
+                        for (int mm = 0; mm < 2; ++mm) {
+                            if constexpr (kind == KP) mma16<DBG>(acc2[2 * gg + (f >> 1)][mm], wA[set][f], X[mm][2 * hh + (f & 1)]);
+                            else mma16<DBG>(acc2[2 * gg + (f >> 1)][mm], wA[set][f], hf[hh & 1][f & 1][mm]);
+                        }
                 }
                 if constexpr (RING2) {
                     if constexpr (gg <= 5) {
@@ -402,6 +420,7 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
         typedef std::integral_constant<int, -1> IM1;
         typedef std::integral_constant<int, KA> TA;
         typedef std::integral_constant<int, KB> TB;
+        typedef std::integral_constant<int, KP> TP;
         typedef std::integral_constant<int, 64> I64;
         typedef std::integral_constant<int, 128> I128;
 
@@ -456,11 +475,26 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
 #pragma clang fp contract(off)
             uint32_t xo[2], yo[2];
             uint32_t g2base;  // LN-2 gamma in accumulator column order: gam[16 T + 4 g ..] at + 64 T bytes (beta: + D * 4)
+            uint32_t bpbase = 0;  // (FOLD) proj bias, the same way
             {
                 int g_;
                 lane_off(nrows, true, XIN, xo, g_);
                 lane_off(nrows, false, IMG, yo, g_);
                 g2base = (uint32_t)(uintptr_t)(LDS_AS char*)gam + 16 * g_;
+                if constexpr (FOLD) {
+                    // the attention rows as the proj product's B operand: lane (g, i) = row i, chunk 4 ks + g (8 columns = 16 bytes) of k-step ks.
+                    // Image: fragment base + chunk * 256 + 16 i (1 KiB per wave instruction); row-major: row * 768 + 16 chunk.
+                    int ln;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+                    const int i_ = ln & 15;
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) {
+                        const int r = wave * 32 + mm * 16 + i_;
+                        const uint32_t e = IMG ? (uint32_t)((wave * 32 + mm * 16) * D * 2 + g_ * 256 + i_ * 16) : (uint32_t)(r * D * 2 + g_ * 16);
+                        yo[mm] = r < nrows ? e : OOB;
+                    }
+                    bpbase = (uint32_t)(uintptr_t)(LDS_AS char*)bps + 16 * g_;
+                }
             }
             const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)row0 * D), 0, nrows * D * 4, 0x00020000);
             // (no y1: an empty range -- every piece reads as zero)
@@ -472,13 +506,50 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
             for (int T = 0; T < NT16; ++T)
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm) xv[mm][T] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo[mm], PIECE_X(XIN, T) * 4, 0));
+            if constexpr (FOLD) {
 #pragma unroll
-            for (int T = 0; T < NT16; ++T)
+                for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-                for (int mm = 0; mm < 2; ++mm) yv[mm][T] = __builtin_amdgcn_raw_buffer_load_b64(ry, yo[mm], PIECE_Y(IMG, T) * 2, 0);
+                    for (int mm = 0; mm < 2; ++mm) X[mm][ks] = __builtin_amdgcn_raw_buffer_load_b128(ry, yo[mm], ks * (IMG ? 1024 : 64), 0);
+            } else {
+#pragma unroll
+                for (int T = 0; T < NT16; ++T)
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) yv[mm][T] = __builtin_amdgcn_raw_buffer_load_b64(ry, yo[mm], PIECE_Y(IMG, T) * 2, 0);
+            }
             if (tid == 0) {
                 asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
                 if (nt_req == last_fetch) *p.counter = 0;
+            }
+            if constexpr (FOLD) {
+                // the fc2 accumulators start from x + b_proj, take att Wproj^T through six proj phases, and come out as v = x + proj(att) + b
+                sfor<0, NT16 / 4>([&](auto Q_) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+                    constexpr int T0 = 4 * decltype(Q_)::value;
+                    f32x4 bb[4];
+                    const uint32_t ba = bpbase;
+                    f32x4 &r0_ = bb[0], &r1_ = bb[1], &r2_ = bb[2], &r3_ = bb[3];
+                    DSR128X4_WAIT(r0_, r1_, r2_, r3_, ba, T0 * 64, T0 * 64 + 64, T0 * 64 + 128, T0 * 64 + 192);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int mm = 0; mm < 2; ++mm) {
+                            const f32x4 c = xv[mm][T0 + t];
+                            const f32x2 a = f32x2{c[0], c[1]} + f32x2{bb[t][0], bb[t][1]};
+                            const f32x2 b = f32x2{c[2], c[3]} + f32x2{bb[t][2], bb[t][3]};
+                            f32x4 sd = {a[0], a[1], b[0], b[1]};
+                            asm volatile("" : "+a"(sd));
+                            acc2[T0 + t][mm] = sd;
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                rd_frag(I0{}, I0{}, fbase + (cons % 3) * UNIT);
+                phase(TP{}, std::integral_constant<int, 0>{}, IM1{}, I0{}, I0{}, 0);
+                phase(TP{}, std::integral_constant<int, 1>{}, IM1{}, I0{}, I0{}, 0);
+                phase(TP{}, std::integral_constant<int, 2>{}, IM1{}, I0{}, I0{}, 0);
+                phase(TP{}, std::integral_constant<int, 3>{}, IM1{}, I0{}, I0{}, 0);
+                phase(TP{}, std::integral_constant<int, 4>{}, IM1{}, I0{}, I0{}, 0);
+                phase(TP{}, std::integral_constant<int, 5>{}, IM1{}, I0{}, IM1{}, 0);
             }
             // (packed fp32 arithmetic: no MFMA runs beside the row phases, and it halves their vector instructions)
             float mean[2], rstd[2];
@@ -488,10 +559,18 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
                 f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
                 for (int T = 0; T < NT16; ++T) {
-                    const bf16x4 y = __builtin_bit_cast(bf16x4, yv[mm][T]);
-                    f32x2 a = {xv[mm][T][0], xv[mm][T][1]}, b = {xv[mm][T][2], xv[mm][T][3]};
-                    a = a + f32x2{(float)y[0], (float)y[1]};
-                    b = b + f32x2{(float)y[2], (float)y[3]};
+                    f32x2 a, b;
+                    if constexpr (FOLD) {
+                        const f32x4 c = acc2[T][mm];  // v = x + proj(att) + b_proj, read back from the accumulator file
+                        a = f32x2{c[0], c[1]};
+                        b = f32x2{c[2], c[3]};
+                    } else {
+                        const bf16x4 y = __builtin_bit_cast(bf16x4, yv[mm][T]);
+                        a = f32x2{xv[mm][T][0], xv[mm][T][1]};
+                        b = f32x2{xv[mm][T][2], xv[mm][T][3]};
+                        a = a + f32x2{(float)y[0], (float)y[1]};
+                        b = b + f32x2{(float)y[2], (float)y[3]};
+                    }
                     rs2 = rs2 + a;
                     rs2 = rs2 + b;
                     xv[mm][T] = f32x4{a[0], a[1], b[0], b[1]};
@@ -524,9 +603,11 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
                         const f32x2 yb = __builtin_elementwise_fma((f32x2{v[2], v[3]} - mean2) * rstd2, f32x2{gq[2], gq[3]}, f32x2{bq_[2], bq_[3]});
                         w[2 * t] = pack_bf16x2(ya[0], ya[1]);
                         w[2 * t + 1] = pack_bf16x2(yb[0], yb[1]);
-                        f32x4 sd = v;
-                        asm volatile("" : "+a"(sd));  // the seed goes to the accumulator file at once
-                        acc2[2 * ks + t][mm] = sd;
+                        if constexpr (!FOLD) {  // (FOLD: the accumulators already hold v)
+                            f32x4 sd = v;
+                            asm volatile("" : "+a"(sd));  // the seed goes to the accumulator file at once
+                            acc2[2 * ks + t][mm] = sd;
+                        }
                     }
                     X[mm][ks] = u32x4{w[0], w[1], w[2], w[3]};  // k-slots j < 4: tile 2 s, j >= 4: tile 2 s + 1
                 }
@@ -697,34 +778,45 @@ bool hipt_mlp16_supported(int dtype, int D_, int hidden) {
     return dtype == HIPT_BF16 && D_ == 384 && hidden % 128 == 0 && hidden >= 256 && hidden <= 1536;
 }
 
-int hipt_mlp16_pack_launch(const void* w1, const void* w2, int D_, int hidden, void* packed, hipStream_t st) {
+size_t hipt_mlp16_packed_bytes(int D_, int hidden, bool with_proj) { return (size_t)2 * D_ * hidden * 2 + (with_proj ? (size_t)D_ * D_ * 2 : 0); }
+
+// wproj != null: format 3 (six proj units in front of the pass), else format 2
+int hipt_mlp16_pack_launch(const void* w1, const void* w2, int D_, int hidden, void* packed, hipStream_t st, const void* wproj) {
     if (!(D_ == 384 && hidden % 128 == 0 && hidden >= 256 && hidden <= 1536)) {
         hipt_set_error("mlp16 pack: unsupported D=%d hidden=%d", D_, hidden);
         return HIPT_E_UNSUPPORTED;
     }
-    const int64_t chunks = (int64_t)(hidden / 128) * 4 * (UNIT / 16);
-    hipLaunchKernelGGL(mlp16_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const bf16_t*)w1, (const bf16_t*)w2, hidden, (u32x4*)packed);
+    const int64_t chunks = (int64_t)((hidden / 128) * 4 + (wproj ? 6 : 0)) * (UNIT / 16);
+    hipLaunchKernelGGL(mlp16_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const bf16_t*)w1, (const bf16_t*)w2, (const bf16_t*)wproj, hidden,
+                       (u32x4*)packed);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }
 
-constexpr int MLP16_FMT = 2;  // (include/hipt_abmil.h: hipt_block_weights.mlp_pk_fmt)
+constexpr int MLP16_FMT = 2, MLP16_FMT_FOLD = 3;  // (include/hipt_abmil.h: hipt_block_weights.mlp_pk_fmt; 3 = with the proj units in front)
 template <int DBG>
 int hipt_mlp16_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     MlpParams p = p_in;
-    const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4 + 256;
-    if (!p.wpk || p.wpk_fmt != MLP16_FMT || (p.img & 2 && !(p.img & 1)) || (p.img && p.M % 16 != 0) || p.fold) {
-        hipt_set_error("mlp16: needs its packed weights; activation images need M %% 16 == 0 and img in {0, 1, 3}; no proj folding (img=%d, M=%d, fold=%d)", p.img,
-                       p.M, p.fold);
+    const bool fold = p.fold != 0;
+    const int lds = 3 * UNIT + (3 * D + p.hidden) * 4 + 16 + 2 * D * 4 + 256 + (fold ? D * 4 : 0);
+    if (!p.wpk || !(p.wpk_fmt == MLP16_FMT || p.wpk_fmt == MLP16_FMT_FOLD) || (p.img & 2 && !(p.img & 1)) || (p.img && p.M % 16 != 0) ||
+        (fold && (p.wpk_fmt != MLP16_FMT_FOLD || !p.y1 || !p.bproj))) {
+        hipt_set_error("mlp16: needs its packed weights; activation images need M %% 16 == 0 and img in {0, 1, 3}; proj folding needs image format 3, the attention "
+                       "output in y1 and the proj bias (img=%d, M=%d, fold=%d, fmt=%d)", p.img, p.M, p.fold, p.wpk_fmt);
         return HIPT_E_BADARG;
     }
-    auto k = p.img == 3 ? mlp16_kernel<true, true, DBG> : p.img == 1 ? mlp16_kernel<true, false, DBG> : mlp16_kernel<false, false, DBG>;
+    if (!fold && p.wpk_fmt == MLP16_FMT_FOLD) p.wpk = (const char*)p.wpk + 6 * UNIT;  // (the MLP's own units lie behind the six proj units)
+    auto k = fold ? (p.img == 3 ? mlp16_kernel<true, true, DBG, true> : p.img == 1 ? mlp16_kernel<true, false, DBG, true> : mlp16_kernel<false, false, DBG, true>)
+                  : (p.img == 3 ? mlp16_kernel<true, true, DBG> : p.img == 1 ? mlp16_kernel<true, false, DBG> : mlp16_kernel<false, false, DBG>);
     static DevOnce once;
     HIPT_CUR_DEVICE(dev);
     if (!once.done[dev]) {
         if (hipFuncSetAttribute((const void*)mlp16_kernel<true, true, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)mlp16_kernel<true, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)mlp16_kernel<false, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            hipFuncSetAttribute((const void*)mlp16_kernel<false, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mlp16_kernel<true, true, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mlp16_kernel<true, false, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mlp16_kernel<false, false, DBG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(mlp16) failed");
             return HIPT_E_LAUNCH;
         }

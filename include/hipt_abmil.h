@@ -73,8 +73,9 @@ typedef struct hipt_block_weights {
      * one run of consecutive bytes instead of eight 128-byte row segments (2.4x the L2->LDS rate on MI355X).  They
      * are a cache of qkv_w / proj_w / fc1_w+fc2_w: re-pack after the weights change. */
     const void*  qkv_pk;  const void* proj_pk;  const void* mlp_pk;
-    /* The image format of mlp_pk: the value hipt_vit_mlp_pack_format returned when it was packed (2 = the streaming kernel's
-     * fragment image on 16x16x32 MFMAs, the only format of this version; 0 = no packed form for this shape). */
+    /* The image format of mlp_pk: the value hipt_vit_mlp_pack_format returned when it was packed (3 = the streaming kernel's
+     * fragment image on 16x16x32 MFMAs behind six units of proj_w: what this version packs; 2 = the same without the proj
+     * units, still run; 0 = no packed form for this shape). */
     int32_t      mlp_pk_fmt;  int32_t reserved;
     /* Optional: qkv_w once more, head by head in the operand order of the fused QKV + attention kernel (HIPT_PACK_QKV_ATT;
      * ViT-256 shape only: D = 384, 6 heads of 64, 257 tokens).  NULL: LayerNorm-chained blocks run the QKV GEMM and the
@@ -165,9 +166,12 @@ size_t hipt_vit_workspace_bytes(const hipt_vit_weights* w, int nseq);
  * Done once per set of weights by the module that owns them (vision_transformer.py:_PackedVit here). */
 size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what);
 /* The fused-MLP image format hipt_vit_pack_weights(.., HIPT_PACK_MLP, ..) writes for this model, to be stored in
- * hipt_block_weights.mlp_pk_fmt beside the pointer: 2 = the streaming kernel's fragment image on 16x16x32 MFMAs, 0 = this
- * dtype / shape has no packed form (the generic kernel reads the row-major matrices).  (1 was the 32x32x16 form of ABI versions
- * before round 5: an image in that format is no longer run -- its model takes the generic kernels.) */
+ * hipt_block_weights.mlp_pk_fmt beside the pointer: 3 = the streaming kernel's fragment image on 16x16x32 MFMAs with six
+ * units of the block's proj matrix in front (the attention block's output projection then runs at the head of the fused MLP's
+ * tiles: LayerNorm-chained blocks have no proj launch and no y1 tensor; hipt_vit_packed_bytes(HIPT_PACK_MLP) includes them),
+ * 0 = this dtype / shape has no packed form (the generic kernel reads the row-major matrices).  An image packed as format 2
+ * (the same without the proj units) by an older binding still runs, with proj as its own kernel.  (1 was the 32x32x16 form
+ * of ABI versions before round 5: an image in that format is no longer run -- its model takes the generic kernels.) */
 int hipt_vit_mlp_pack_format(const hipt_vit_weights* w);
 int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* out, void* stream);
 /* Scratch of the whole-forward calls below (residual stream + block scratch + bf16 input copy). */

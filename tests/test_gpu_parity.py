@@ -357,7 +357,7 @@ def test_vit256_streaming_kernels_vs_generic_kernels(vit256, monkeypatch):
     try:
         pk = vit256._tokens(x)[0]
         assert all(pk.blocks[i].mlp_pk and pk.blocks[i].qkv_pk and pk.blocks[i].proj_pk and pk.blocks[i].qkv_att_pk for i in range(pk.w.depth))
-        assert all(pk.blocks[i].mlp_pk_fmt == 2 for i in range(pk.w.depth))  # (the 16x16x32 form is the default)
+        assert all(pk.blocks[i].mlp_pk_fmt == 3 for i in range(pk.w.depth))  # (16x16x32 MFMAs, the proj units in front)
         default = vit256(x), vit256.get_intermediate_layers(x, n=2)
         monkeypatch.setenv("HIPT_GENERIC", "1")
         generic = vit256(x), vit256.get_intermediate_layers(x, n=2)
@@ -375,18 +375,24 @@ def test_vit256_streaming_kernels_vs_generic_kernels(vit256, monkeypatch):
         N.call("hipt_vit_pack_weights", pk32.ref, 0, N.PACK_MLP, N.ptr(x), N.stream_ptr(x.device))
 
 
-def test_vit256_fused_mlp_image_format_travels_with_the_image(vit256):
-    """The fused MLP's weight image is format 2 (csrc/mlp16.hip, 16x16x32 MFMAs).  Bit-identical between batchings; an image that claims
-    another format (1: the 32x32x16 form retired in round 5) is not run through the streaming kernel -- the model takes the generic
-    kernels and stays within the bf16 bar."""
+def test_vit256_fused_mlp_image_format_travels_with_the_image(vit256, monkeypatch):
+    """The fused MLP's weight image is format 3 (csrc/mlp16.hip, 16x16x32 MFMAs, six units of the proj matrix in front: the output projection
+    runs at the head of the MLP's tiles).  Bit-identical between batchings; HIPT_NO_PROJ_FOLD=1 runs proj as its own kernel from the same image
+    (y1 rounded to bf16 on the way: the bf16 bar, not the bits); an image that claims another format (1: the 32x32x16 form retired in round 5) is
+    not run through the streaming kernel -- the model takes the generic kernels and stays within the bf16 bar."""
     x = synth.hash_uniform_torch((16, 3, 256, 256), 23, device=DEV)
     vit256.set_compute_dtype("bf16")
     try:
         default = vit256(x)
         pk = vit256._tokens(x)[0]
-        assert N.lib().hipt_vit_mlp_pack_format(pk.ref) == 2 and all(pk.blocks[i].mlp_pk_fmt == 2 and pk.blocks[i].mlp_pk for i in range(12))
+        assert N.lib().hipt_vit_mlp_pack_format(pk.ref) == 3 and all(pk.blocks[i].mlp_pk_fmt == 3 and pk.blocks[i].mlp_pk for i in range(12))
         two = vit256(torch.cat([x, x]))      # 32 patches = whole 16-row fragments, like the 16: the same kernels, other tile positions
         sub = vit256(torch.cat([x[5:], x]))  # 27 patches: 27 * 257 rows are no whole fragments: row-major path
+        monkeypatch.setenv("HIPT_NO_PROJ_FOLD", "1")
+        unfolded = vit256(x)
+        unfolded_full = vit256.get_intermediate_layers(x, n=1)[-1]
+        monkeypatch.delenv("HIPT_NO_PROJ_FOLD")
+        folded_full = vit256.get_intermediate_layers(x, n=1)[-1]
         for i in range(12):
             pk.blocks[i].mlp_pk_fmt = 1     # a stale image format
         stale = vit256(x)
@@ -396,8 +402,10 @@ def test_vit256_fused_mlp_image_format_travels_with_the_image(vit256):
     assert torch.equal(two[:16], default) and torch.equal(two[16:], default)
     assert float((sub[11:] - default).norm() / default.norm()) < 1.3e-2
     rel = float((stale - default).norm() / default.norm())
-    print(f"stale image format -> generic kernels: [CLS] features rel-L2 {rel:.2e}")
-    assert 0 < rel < 1.3e-2
+    rel_u = float((unfolded - default).norm() / default.norm())
+    rel_f = float((unfolded_full - folded_full).norm() / folded_full.norm())
+    print(f"stale image format -> generic kernels: [CLS] features rel-L2 {rel:.2e}; proj folded vs its own kernel: {rel_u:.2e} ([CLS]), {rel_f:.2e} (all tokens, row-major path)")
+    assert 0 < rel < 1.3e-2 and 0 < rel_u < 5e-3 and 0 < rel_f < 5e-3
 
 
 def test_vit256_patch_embedding_from_fp32_pixels(vit256, monkeypatch):
