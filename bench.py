@@ -151,7 +151,7 @@ def kernel_flops(cat, rows, D=384, H=1536, heads=6, ntok=257):
 
 
 # rocprofv3 kernel names of the categories, most specific first (keys of profiles/<tag>_traffic.json)
-TRAFFIC_KEYS = {"mlp_fused": ["void mlp16_kernel<true, true, 0>", "void mlp32_kernel<true, true, 0>", "void mlp32_kernel<true, true, 0, false>"],
+TRAFFIC_KEYS = {"mlp_fused": ["void mlp16_kernel<true, true, 0, true>", "void mlp16_kernel<true, true, 0>", "void mlp32_kernel<true, true, 0>", "void mlp32_kernel<true, true, 0, false>"],
                 "qkv_attention_fused": ["qkv_attn_kernel"],
                 "qkv_gemm": ["void seqgemm_pipe_kernel<false, 0, true, true, false, true>", "void seqgemm_pipe_kernel<true, 0, true, false, false, false>",
                              "void seqgemm_pipe_kernel<true, 0>"],
