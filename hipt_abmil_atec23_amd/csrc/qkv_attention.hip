@@ -713,7 +713,11 @@ static int qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv
 //  fence, hipcc re-uses them while the data is still on its way, and the landing data overwrites live addresses: a memory fault)
 // (bit 4 -- no attention phase -- is not instantiated any more either: with most of the Q tiles and the operand reload dead, hipcc (ROCm 7.2) re-uses
 //  the destinations of in-flight bias reads / operand loads and the audit refuses the object -- round 5; its figures are in DESIGN_HISTORY.md)
+#ifdef HIPT_QKVATT_STAMPS_BUILD  // (the phase stamps describe the complete kernel only: no ablation variants in that build)
+#define QKV_DBG_LIST(X)
+#else
 #define QKV_DBG_LIST(X) X(1) X(2) X(3) X(16) X(32) X(48) X(64)
+#endif
 #define QKV_SETATTR(n) ok = ok && hipFuncSetAttribute((const void*)qkv_attn_kernel<n>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
         QKV_DBG_LIST(QKV_SETATTR)
 #endif
