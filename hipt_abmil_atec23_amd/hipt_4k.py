@@ -35,9 +35,12 @@ class HIPT_4K(torch.nn.Module):
         # > 1: a batch of regions is cut into that many parts, each run on its own HIP stream with its own workspace.
         # Every kernel of the path occupies whole CUs (one persistent workgroup each), so the parts do not share CUs:
         # the second stream's kernels fill the CUs the first one's kernel frees in its last, partial round of tiles.
-        # Default 2: a batch of ONE region (the reference's call pattern) then runs as two half-size patch ranges on two streams
-        # (_run_patch_split: 162 -> 167 regions/s on MI355X), a batch of R >= 2 regions as two groups of regions.
+        # Default 2: a batch of R >= 2 regions runs as two groups of regions.
         self.streams = 2
+        # ... and a batch of ONE region (the reference's call pattern) as patch ranges over this many streams (_run_patch_split).  Default 1:
+        # with the proj fold of round 5 one stream is the robust choice -- tools/batch1_bench.py on two boxes of the pool: 1 stream 239 / 240
+        # regions/s, 2 streams 228-233 / 228-233, 3 streams 249 / 221, 4 streams 248-257 / 196-198 (rounds 2-4 split one region over 2).
+        self.patch_streams = 1
         self._side_streams = {}
         if compute_dtype is not None:
             self.set_compute_dtype(compute_dtype)
@@ -95,8 +98,11 @@ class HIPT_4K(torch.nn.Module):
             pk256 = m256._packed_for(m256._pos_for(256, 256, 256))
             # fewer regions than streams: the patches are spread over the streams (decided before anything is allocated or packed for
             # the whole-region path: that path's `out` and ViT-4K image are not used there)
-            if int(self.streams) > nreg and nseq >= 32 * int(self.streams):
-                return self._run_patch_split(region, u8, hwc, nreg, w_256, h_256, W, H, pk256, d256, want_cls256)
+            split = int(self.patch_streams) if nreg == 1 else int(self.streams)
+            while split > 1 and nseq < 32 * split:
+                split -= 1  # (small regions: fewer ranges)
+            if split > nreg and nseq >= 32 * split:
+                return self._run_patch_split(region, u8, hwc, nreg, w_256, h_256, W, H, pk256, d256, want_cls256, split)
             pk4k = m4k._packed_for(m4k._pos_for(per, w_256, h_256))
             out = torch.empty((nreg, pk4k.w.dim), dtype=torch.float32, device=d4k)
             cls256 = torch.empty((nseq, pk256.w.dim), dtype=torch.float32, device=d256) if want_cls256 else None
@@ -140,7 +146,7 @@ class HIPT_4K(torch.nn.Module):
         tokens = cls256.to(d4k, non_blocking=True).view(nreg, per, -1)
         return self.model4k.forward_tokens(tokens, w_256, h_256), cls256
 
-    def _run_patch_split(self, region, u8, hwc, nreg, w_256, h_256, W, H, pk256, dev, want_cls256):
+    def _run_patch_split(self, region, u8, hwc, nreg, w_256, h_256, W, H, pk256, dev, want_cls256, parts):
         """Fewer regions than streams (the reference's batch of ONE region, extract_features_fp.py:159-171): the PATCHES of the
         call are spread over the streams instead.  One region is 256 patches = 257 rows per CU: every kernel of a single
         stream ends in a ragged last round of tiles (2 x 128 rows + 1); two half-size streams fill each other's idle CUs.
@@ -160,7 +166,6 @@ class HIPT_4K(torch.nn.Module):
             img = Fn.workspace(dev, nb, ("img", cur.cuda_stream))
             N.call("hipt_image_to_compute", pk256.ref, N.ptr(region), kind, C.byref(lay), nseq, N.ptr(img), N.stream_ptr(dev))
         cls256 = torch.empty((nseq, pk256.w.dim), dtype=torch.float32, device=dev)
-        parts = int(self.streams)
         bounds = [(nseq * k // parts) // 16 * 16 for k in range(parts)] + [nseq]  # whole 16-sequence groups: whole MFMA row fragments
         key = (dev.index, parts)
         if key not in self._side_streams:

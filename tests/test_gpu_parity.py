@@ -619,19 +619,23 @@ def test_hipt4k_one_region_split_over_streams_by_patches(hipt):
     try:
         for dt in ("bf16", "fp32"):
             hipt.set_compute_dtype(dt)
-            hipt.streams = 1
+            hipt.patch_streams = 1
             one, one_u = hipt(x), hipt(xu)
             d1 = hipt.forward_asset_dict(x)
             before = N.calls
-            hipt.streams = 2
+            hipt.patch_streams = 2
             two, two_u = hipt(x), hipt(xu)
             d2 = hipt.forward_asset_dict(x)
             assert N.calls - before >= 3 * 3  # convert (bf16) / 2 ranges / ViT-4K per call
             assert torch.equal(one, two) and torch.equal(one_u, two_u), dt
             assert np.array_equal(d1["features_cls256"], d2["features_cls256"]) and np.array_equal(d1["features_cls4k"], d2["features_cls4k"])
-        hipt.streams = 3  # uneven ranges (16-sequence groups: 16 / 16 / 32)
-        assert torch.equal(hipt(x), one)
+        x3 = synth.hash_uniform_torch((1, 3, 2048, 3072), 36, device=DEV)  # 96 patches -> 32 / 32 / 32
+        hipt.patch_streams = 1
+        one3 = hipt(x3)
+        hipt.patch_streams = 3
+        assert torch.equal(hipt(x3), one3)
     finally:
+        hipt.patch_streams = 1
         hipt.streams = 1
         hipt.set_compute_dtype("fp32")
 
@@ -693,13 +697,13 @@ def test_hipt4k_one_region_from_a_view_off_the_16_byte_grid(hipt):
     off.copy_(aligned)
     assert aligned.data_ptr() % 16 == 0 and off.data_ptr() % 16 == 4
     hipt.set_compute_dtype("bf16")
-    old = hipt.streams
-    hipt.streams = 2
+    old = hipt.patch_streams
+    hipt.patch_streams = 2
     try:
         ref = hipt(aligned)
         got = hipt(off)
     finally:
-        hipt.streams = old
+        hipt.patch_streams = old
         hipt.set_compute_dtype("fp32")
     assert torch.equal(ref, got)
 
@@ -735,7 +739,7 @@ def test_extract_slide_4096_regions_gathered_ragged_tail_same_bits(hipt, tmp_pat
     hipt.set_compute_dtype("bf16")
     old_streams = hipt.streams
     try:
-        hipt.streams = 2  # (the class default: one region per call = two patch ranges on two streams)
+        hipt.streams = 2  # (the class default; one region per call runs on one stream)
         one = torch.load(extract_slide(hipt, batches, str(tmp_path), "co1", coalesce=1))
         # one stream: a gathered call is 2 048 patches in ONE pass (its [CLS]-row GEMMs are sliced into small-M launches: capi.hip
         # rows_linear); two streams: two groups of four regions

@@ -1,4 +1,5 @@
-"""One region per HIPT_4K.forward (the reference's batch size, extract_features_fp.py:159-171): time per call by stream count."""
+"""One region per HIPT_4K.forward (the reference's batch size, extract_features_fp.py:159-171): time per call by the number of streams its
+patches are spread over (HIPT_4K.patch_streams)."""
 import sys
 import time
 
@@ -29,6 +30,6 @@ def timed(n=20):
 
 for rep in range(2):
     for streams in [int(a) for a in sys.argv[1:] if a.isdigit()] or [2, 1]:
-        m.streams = streams
+        m.patch_streams = streams  # (one region: its patches over that many streams; the class default is 1)
         a = timed()
         print(f"streams {streams}: one region per call {a:.3f} ms ({1e3 / a:.1f} regions/s)", flush=True)
