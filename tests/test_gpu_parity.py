@@ -7,6 +7,7 @@ reference itself is 2.4e-2 max-abs off); SURVEY.md 8d recommends rel-L2 <= 2e-2 
 golden; the tests hold the build to twice what it measures (rel-L2 <= 1.3e-2, cosine >= 0.9999), stated and printed per test.
 """
 import os
+from functools import partial
 
 import numpy as np
 import pytest
@@ -406,6 +407,31 @@ def test_vit256_fused_mlp_image_format_travels_with_the_image(vit256, monkeypatc
     rel_f = float((unfolded_full - folded_full).norm() / folded_full.norm())
     print(f"stale image format -> generic kernels: [CLS] features rel-L2 {rel:.2e}; proj folded vs its own kernel: {rel_u:.2e} ([CLS]), {rel_f:.2e} (all tokens, row-major path)")
     assert 0 < rel < 1.3e-2 and 0 < rel_u < 5e-3 and 0 < rel_f < 5e-3
+
+
+def test_vit_other_hidden_width_proj_fold_vs_oracle(monkeypatch):
+    """The fused proj + MLP kernel at another hidden width (mlp_ratio 2: 768 hidden units = 6 chunks, 30 ring units per tile pass instead of 54)
+    and depth 3: bf16 against the fp32 numpy oracle at the bf16 bar, the folded and the unfolded form close to each other, and the image
+    the library reports (format 3, D * D * 2 bytes more than the two MLP matrices)."""
+    from hipt_abmil_atec23_amd.vision_transformer import VisionTransformer
+    cfg = dict(embed_dim=384, depth=3, num_heads=6, mlp_ratio=2)
+    m = VisionTransformer(patch_size=16, num_classes=0, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), **cfg)
+    specs = synth.vit_param_specs("vit256", **cfg)
+    m.load_state_dict(synth.make_state_dict(specs, 77))
+    m = m.eval().to(DEV).set_compute_dtype("bf16")
+    x = synth.hash_uniform_torch((16, 3, 256, 256), 78, device=DEV)
+    pk = m._tokens(x)[0]
+    assert N.lib().hipt_vit_mlp_pack_format(pk.ref) == 3
+    assert N.lib().hipt_vit_packed_bytes(pk.ref, N.PACK_MLP) == 2 * 384 * 768 * 2 + 384 * 384 * 2
+    folded = m(x)
+    monkeypatch.setenv("HIPT_NO_PROJ_FOLD", "1")
+    unfolded = m(x)
+    monkeypatch.delenv("HIPT_NO_PROJ_FOLD")
+    ref = O.vit256_forward(x.cpu().numpy(), synth.make_params_np(specs, 77), num_heads=6)
+    r_f, r_u = rel_l2(folded, ref), rel_l2(unfolded, ref)
+    r_fu = float((folded - unfolded).norm() / unfolded.norm())
+    print(f"ViT D=384 depth 3 hidden 768, bf16 vs fp32 oracle: folded {r_f:.2e}, proj as its own kernel {r_u:.2e}; folded vs unfolded {r_fu:.2e}")
+    assert r_f < 1.3e-2 and r_u < 1.3e-2 and 0 < r_fu < 1.3e-2  # (two bf16 paths, each ~8e-3 from the fp32 truth: measured 5.0e-3 apart)
 
 
 def test_vit256_patch_embedding_from_fp32_pixels(vit256, monkeypatch):
