@@ -659,7 +659,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                     u32x2 o;
                     o[0] = pack_bf16x2(O[t][4 * q] * inv, O[t][4 * q + 1] * inv);
                     o[1] = pack_bf16x2(O[t][4 * q + 2] * inv, O[t][4 * q + 3] * inv);
-                    __builtin_amdgcn_raw_buffer_store_b64(o, orsrc, orow + t * 1024 + q * 256, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, orsrc, orow + t * 1024 + q * 256, 0, 2);  // (nt: read once, by the fused MLP)
                 }
         }
         QSTAMP(6);
