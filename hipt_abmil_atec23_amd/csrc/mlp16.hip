@@ -25,7 +25,9 @@
 // Cache policy of the row traffic (the builtin's aux operand: 2 = nt).  A tile's rows are read once and written once per launch (2.4 GB per 2 048 patches)
 // while every tile re-reads the 2.4 MB weight image from L2: the rows are marked non-temporal so that they do not push the image out.  Round 5, same box,
 // two runs each: 1 430 / 1 428 us per launch without, 1 414 / 1 418 with (and the attention kernel behind it 685 / 681 -> 675 / 673: it finds its own
-// weight image in L2 more often); 325.4 / 325.8 -> 326.6 / 327.6 regions/s.
+// weight image in L2 more often); 325.4 / 325.8 -> 326.6 / 327.6 regions/s; HBM bytes per launch by PMC 2.78 -> 2.47 GB (2.43 algorithmic).  IMAGE
+// layouts only (whole 1 KiB per instruction): row-major pieces are 16 bytes of a 128-byte line that the lane's next pieces need again -- the block-1
+// form (row-major x from the patch embedding) got 12 % SLOWER with the hint on its x loads (1 470 -> 1 648 us).
 constexpr int AUX_ROWS = 2;
 
 namespace {
@@ -511,17 +513,17 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
 #pragma unroll
             for (int T = 0; T < NT16; ++T)
 #pragma unroll
-                for (int mm = 0; mm < 2; ++mm) xv[mm][T] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo[mm], PIECE_X(XIN, T) * 4, AUX_ROWS));
+                for (int mm = 0; mm < 2; ++mm) xv[mm][T] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo[mm], PIECE_X(XIN, T) * 4, XIN ? AUX_ROWS : 0));
             if constexpr (FOLD) {
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-                    for (int mm = 0; mm < 2; ++mm) X[mm][ks] = __builtin_amdgcn_raw_buffer_load_b128(ry, yo[mm], ks * (IMG ? 1024 : 64), AUX_ROWS);
+                    for (int mm = 0; mm < 2; ++mm) X[mm][ks] = __builtin_amdgcn_raw_buffer_load_b128(ry, yo[mm], ks * (IMG ? 1024 : 64), IMG ? AUX_ROWS : 0);
             } else {
 #pragma unroll
                 for (int T = 0; T < NT16; ++T)
 #pragma unroll
-                    for (int mm = 0; mm < 2; ++mm) yv[mm][T] = __builtin_amdgcn_raw_buffer_load_b64(ry, yo[mm], PIECE_Y(IMG, T) * 2, AUX_ROWS);
+                    for (int mm = 0; mm < 2; ++mm) yv[mm][T] = __builtin_amdgcn_raw_buffer_load_b64(ry, yo[mm], PIECE_Y(IMG, T) * 2, IMG ? AUX_ROWS : 0);
             }
             if (tid == 0) {
                 asm volatile("ds_write_b32 %0, %1" ::"v"(tsbase + 4 * ((seq + 1) & 1)), "v"(nt_req) : "memory");
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
                         rs2[mm] = rs2[mm] + a;
                         rs2[mm] = rs2[mm] + b;
                         const f32x4 v = {a[0], a[1], b[0], b[1]};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rx, xso[mm], PIECE_X(IMG, T0 + t) * 4, AUX_ROWS);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rx, xso[mm], PIECE_X(IMG, T0 + t) * 4, IMG ? AUX_ROWS : 0);
                         acc2[T0 + t][mm] = v;
                     }
                 __builtin_amdgcn_sched_barrier(0);
@@ -754,7 +756,7 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
                             u32x2 o2;
                             o2[0] = pack_bf16x2(ya[0], ya[1]);
                             o2[1] = pack_bf16x2(yb[0], yb[1]);
-                            __builtin_amdgcn_raw_buffer_store_b64(o2, rn, nso[mm], PIECE_Y(IMG, T0 + t) * 2, AUX_ROWS);
+                            __builtin_amdgcn_raw_buffer_store_b64(o2, rn, nso[mm], PIECE_Y(IMG, T0 + t) * 2, IMG ? AUX_ROWS : 0);
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 });
