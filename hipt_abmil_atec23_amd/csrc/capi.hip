@@ -161,8 +161,23 @@ int rows_linear(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
 // at most four 272-row sequences: what gemm.hip's small-M kernel takes (HIPT_GENERIC keeps its meaning: the generic kernels either way)
 static bool small_call(const hipt_vit_weights* w, int nseq) { return (int64_t)nseq * w->ntok <= 1088; }
 
+// do blocks [b0, b1) of a call of nseq sequences run LayerNorm-chained on the streaming kernels / exchange activation images?
+static bool blocks_chain(const hipt_vit_weights* w, int nseq, int b0, int b1) {
+    const int D = w->dim, dt = w->dtype;
+    bool chain = hipt_seqgemm_supported(dt, D) && hipt_mlp_supported(dt, D, w->hidden) && !small_call(w, nseq) && !hipt_generic_only() &&
+                 hipt_mlp16_supported(dt, D, w->hidden) && hipt_seqgemm_pipe_supported(dt, D, 3 * D, false, 0);
+    for (int i = b0; i < b1 && chain; ++i) chain = w->blocks[i].qkv_pk && w->blocks[i].proj_pk && w->blocks[i].mlp_pk && (w->blocks[i].mlp_pk_fmt == 2 || w->blocks[i].mlp_pk_fmt == 3);
+    return chain;
+}
+static bool blocks_images(const hipt_vit_weights* w, int nseq, int b0, int b1) {
+    return blocks_chain(w, nseq, b0, b1) && ((int64_t)nseq * w->ntok) % 16 == 0 && !hipt_env_on("HIPT_NO_IMG") &&
+           hipt_attention64_supported(w->dtype, w->dim / w->heads, w->ntok, false);
+}
+
+// xn_ready (round 5): the caller's embedding already left x as the fp32 activation image and LayerNorm-1 of block b0 as the bf16 image s.att
+// (embed32.hip, LNOUT): block b0 then runs like every later block.  Only with img_ok and blocks_images(..) true (checked).
 int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, float* probs, const BlockScratch& s,
-               hipStream_t st, bool emit_last = false, bool* have_xn_out = nullptr, bool img_ok = false, bool* x_img_out = nullptr) {
+               hipStream_t st, bool emit_last = false, bool* have_xn_out = nullptr, bool img_ok = false, bool* x_img_out = nullptr, bool xn_ready = false) {
     const int D = w->dim, M = nseq * w->ntok, dt = w->dtype, dh = D / w->heads;
     const float scale = attn_scale(w);
     int rc;
@@ -179,14 +194,14 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     // pipelined path: the MLP of block i applies LayerNorm-1 of block i+1 to the rows it finishes and leaves them in
     // s.att as bf16 operands; block i+1's QKV GEMM then skips the fp32 row load + LayerNorm
     // (only the streaming kernels have that epilogue / prologue: every block of the range needs its packed weight images)
-    bool chain = seq && !hipt_generic_only() && hipt_mlp16_supported(dt, D, w->hidden) && hipt_seqgemm_pipe_supported(dt, D, 3 * D, false, 0);
-    for (int i = b0; i < b1 && chain; ++i) chain = w->blocks[i].qkv_pk && w->blocks[i].proj_pk && w->blocks[i].mlp_pk && (w->blocks[i].mlp_pk_fmt == 2 || w->blocks[i].mlp_pk_fmt == 3);
-    bool have_xn = false;
+    const bool chain = blocks_chain(w, nseq, b0, b1);
     // activation images: chained streaming blocks, whole 16-row fragments, no probability output
-    const bool img = img_ok && chain && probs == nullptr && M % 16 == 0 && !hipt_env_on("HIPT_NO_IMG") && hipt_attention64_supported(dt, dh, w->ntok, false);
+    const bool img = img_ok && probs == nullptr && blocks_images(w, nseq, b0, b1);
+    HIPT_CHECK_ARG(!xn_ready || (img && b0 < b1), "run_blocks: image input without the image path");
+    bool have_xn = xn_ready;
     // with them, q | k | v leave the QKV GEMM head-major (the attention kernel's K / V staging reads consecutive bytes)
     const bool hm = img && (int64_t)M * 3 * D * 2 < ((int64_t)1 << 32) - 65536;
-    bool x_img = false;
+    bool x_img = xn_ready;
     // the tile queues of the streaming kernels (three ints in the unused hidden slot) reset themselves at the end of a launch:
     // zeroed once here instead of before each of the ~44 launches (5 us each on the stream: 3 % of a one-region forward)
     const bool qz = chain && hipMemsetAsync(s.hid, 0, 48 * sizeof(int), st) == hipSuccess;
@@ -411,8 +426,9 @@ static bool embed_fused_ok(const hipt_vit_weights* w, const void* images, const 
 }
 
 // the same from the fp32 image itself (embed32.hip): `wpk` = the packed Conv2d weight, `counter` = the kernel's tile queue
+// xn_img != null: x leaves as the fp32 activation image and LayerNorm-1 of the first block as the bf16 image xn_img (run_blocks: xn_ready)
 int embed256_f32(const hipt_vit_weights* w, const void* img, const hipt_image_layout* lay, int seq0, int nseq, float* x, const void* wpk,
-                 int* counter, hipStream_t st, int kind = 0) {
+                 int* counter, hipStream_t st, int kind = 0, void* xn_img = nullptr) {
     EmbedParams p;
     memset(&p, 0, sizeof(p));
     p.img = img;
@@ -429,6 +445,15 @@ int embed256_f32(const hipt_vit_weights* w, const void* img, const hipt_image_la
     p.ntok = w->ntok;
     p.counter = counter;
     int rc;
+    if (xn_img) {
+        p.xn_out = xn_img;
+        p.ln_w = w->blocks[0].ln1_w;
+        p.ln_b = w->blocks[0].ln1_b;
+        p.ln_eps = w->ln_eps;
+        PROF(PC_EMBED, hipt_embed32_launch(p, st));
+        PROF(PC_OTHER, hipt_cls_init_img_launch(x, xn_img, w->cls, w->pos, p.ln_w, p.ln_b, p.ln_eps, nseq, w->ntok, w->dim, st));
+        return HIPT_OK;
+    }
     PROF(PC_EMBED, hipt_embed32_launch(p, st));
     PROF(PC_OTHER, hipt_cls_init_launch(x, w->cls, w->pos, nseq, w->ntok, w->dim, st));
     return HIPT_OK;
@@ -751,15 +776,19 @@ static int vit256_range_impl(const hipt_vit_weights* w, const void* img, const h
     }
     for (int s0 = 0; s0 < nseq; s0 += chunk) {
         const int n = nseq - s0 < chunk ? nseq - s0 : chunk;
+        const bool prune = can_prune_last(w) && !small_call(w, n);
+        // the embedding hands the first block its operands as activation images when the blocks exchange images anyway (HIPT_NO_EMBED_LN: off)
+        const bool pre = embed_pk && prune && w->depth > 1 && blocks_images(w, n, 0, w->depth - 1) && !hipt_env_on("HIPT_NO_EMBED_LN");
         if (embed_pk) {
-            if ((rc = embed256_f32(w, img, lay, seq0 + s0, n, x, embed_pk, (int*)((char*)embed_pk + hipt_embed32_packed_bytes()), st, embed_kind))) return rc;
+            if ((rc = embed256_f32(w, img, lay, seq0 + s0, n, x, embed_pk, (int*)((char*)embed_pk + hipt_embed32_packed_bytes()), st, embed_kind, pre ? s.att : nullptr)))
+                return rc;
         } else if ((rc = embed256(w, img, lay, seq0 + s0, n, x, st))) {
             return rc;
         }
-        if (can_prune_last(w) && !small_call(w, n)) {
+        if (prune) {
             float* xc = (float*)((char*)s.hid + 4096);  // (the hidden-tensor slot is free on this path; its head holds tile queues)
             bool have_xn = false, x_img = false;  // (x is this function's own buffer: it may come back as an activation image)
-            if ((rc = run_blocks(w, x, n, 0, w->depth - 1, nullptr, s, st, true, &have_xn, true, &x_img))) return rc;
+            if ((rc = run_blocks(w, x, n, 0, w->depth - 1, nullptr, s, st, true, &have_xn, true, &x_img, pre))) return rc;
             if ((rc = run_last_block_cls(w, x, n, s, xc, have_xn, x_img, st))) return rc;
             PROF(PC_LN, hipt_layernorm_launch(xc, w->dim, w->norm_w, w->norm_b, out + (size_t)s0 * w->dim, HIPT_F32, w->dim, n, w->dim,
                                               w->ln_eps, st));

@@ -127,12 +127,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // host side -------------------------------------------------------------------------------
 void hipt_set_error(const char* fmt, ...);
 
-// The library reads FIVE environment switches, all for debugging / A-B runs (README.md):
+// The library reads SIX environment switches, all for debugging / A-B runs (README.md):
 //   HIPT_GENERIC=1        every operator takes its generic kernel (no streaming / packed-weight kernels)
 //   HIPT_NO_IMG=1         no activation images / head-major qkv between the streaming kernels
 //   HIPT_NO_PRUNE=1       the last ViT-256 block runs in full instead of for the [CLS] rows only
 //   HIPT_NO_FUSED_ATTN=1  LayerNorm-chained blocks run QKV GEMM + attention as two kernels instead of the fused one
 //   HIPT_NO_PROJ_FOLD=1   the attention block's output projection runs as its own kernel instead of at the head of the fused MLP's tiles
+//   HIPT_NO_EMBED_LN=1    the patch embedding writes row-major tokens only; the first block applies its own LayerNorm-1 (LN-in-GEMM + two-kernel attention)
 // read per call (cheap: host side, a handful of calls per forward), so a test may flip them inside one process.
 #include <stdlib.h>
 inline bool hipt_env_on(const char* name) {

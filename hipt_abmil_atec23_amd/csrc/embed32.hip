@@ -50,11 +50,15 @@ __global__ void embed32_pack_kernel(const bf16_t* __restrict__ w, u32x4* __restr
     out[i] = *(const u32x4*)(w + (int64_t)(32 * O + j) * (NCHN * KPC) + KPC * c + 16 * r + 8 * h);
 }
 
-template <int KIND>
+// LNOUT (round 5): the token rows leave as ACTIVATION IMAGES (kernels.h) -- x as the fp32 image and LayerNorm-1 of the first block applied to it
+// as the bf16 image p.xn_out -- so that the first block runs the kernels of all the others (fused QKV + attention, image-in fused MLP) instead
+// of LayerNorm-in-GEMM + a q | k | v tensor + the two-kernel attention.  A token's 384 values are the 192 of this lane and the 192 of lane ^ 32.
+template <int KIND, bool LNOUT>
 __global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bs = (float*)(smem + 3 * UNIT);  // bias [D]
-    int* tile_s = (int*)(bs + D);           // [2] tile handed to this workgroup, double-buffered by parity
+    float* gs = bs + D;                     // LNOUT: gamma [D] | beta [D] of the first block's LayerNorm-1
+    int* tile_s = (int*)(bs + (LNOUT ? 3 : 1) * D);  // [2] tile handed to this workgroup, double-buffered by parity
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,6 +79,11 @@ __global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
     };
 
     for (int i = tid; i < D; i += 256) bs[i] = p.bias[i];
+    if constexpr (LNOUT)
+        for (int i = tid; i < D; i += 256) {
+            gs[i] = p.ln_w[i];
+            gs[D + i] = p.ln_b[i];
+        }
     if (tid == 0) tile_s[0] = atomicAdd(p.counter, 1);
     __syncthreads();
     int tile = __builtin_amdgcn_readfirstlane(tile_s[0]);
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
         });
 
         // ---- epilogue: + bias + pos -> token rows of x.  acc[O][4 q + e] is output column 32 O + 8 q + 4 h + e of this lane's token ----
-        {
+        if constexpr (!LNOUT) {
             const int b = tile / tps, t = ((tile % tps) * 8 + 2 * wave + m) * p.ntx + li;
             float* xr = p.x + ((int64_t)b * p.ntok + 1 + t) * D + 4 * h;
             const float* pr = p.pos + (int64_t)(1 + t) * D + 4 * h;
@@ -292,6 +301,74 @@ __global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (acc[O][4 * q + e] + bb[q][e]) + pv[q][e];
                     *(f32x4*)(xr + 32 * O + 8 * q) = v;
+                }
+            });
+        } else {
+#pragma clang fp contract(off)
+            const int b = tile / tps, t = ((tile % tps) * 8 + 2 * wave + m) * p.ntx + li;
+            const float* pr = p.pos + (int64_t)(1 + t) * D + 4 * h;
+            // pass 1: the token values, in place; the row sum (this lane's 192 + the partner's)
+            float sum = 0.f;
+            sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
+                constexpr int O = decltype(O_)::value;
+                f32x4 pv[4], bb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pv[q] = *(const f32x4*)(pr + 32 * O + 8 * q);
+                const uint32_t ba = bbase;
+                f32x4 &r0_ = bb[0], &r1_ = bb[1], &r2_ = bb[2], &r3_ = bb[3];
+                DSR128X4_WAIT(r0_, r1_, r2_, r3_, ba, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = (acc[O][4 * q + e] + bb[q][e]) + pv[q][e];
+                        acc[O][4 * q + e] = v;
+                        sum += v;
+                    }
+            });
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum / (float)D;
+            float var = 0.f;
+            sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
+                constexpr int O = decltype(O_)::value;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float d = acc[O][k] - mean;
+                    var = __builtin_fmaf(d, d, var);
+                }
+            });
+            var += __shfl_xor(var, 32, 64);
+            const float rstd = 1.0f / sqrtf(var / (float)D + p.ln_eps);
+            // pass 2: x as the fp32 image, LayerNorm-1(x) as the bf16 image: row R, 16-byte chunk 4 O + q (g = q, c = O of kernels.h), half h
+            const int64_t R = (int64_t)b * p.ntok + 1 + t;
+            float* xi = p.x + (R >> 4) * 6144 + h * 256 + (int)(R & 15) * 4;                       // + O * 512 + q * 64
+            bf16_t* ni = (bf16_t*)p.xn_out + (R >> 4) * 6144 + (int)(R & 15) * 8 + 4 * h;           // + O * 512 + q * 128
+            const uint32_t ga = bbase + D * 4, be = bbase + 2 * D * 4;
+            sfor<0, NOT>([&](auto O_) __attribute__((always_inline)) {
+                constexpr int O = decltype(O_)::value;
+                f32x4 gg[4], bt[4];
+                {
+                    f32x4 &r0_ = gg[0], &r1_ = gg[1], &r2_ = gg[2], &r3_ = gg[3];
+                    DSR128X4_WAIT(r0_, r1_, r2_, r3_, ga, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
+                }
+                {
+                    f32x4 &r0_ = bt[0], &r1_ = bt[1], &r2_ = bt[2], &r3_ = bt[3];
+                    DSR128X4_WAIT(r0_, r1_, r2_, r3_, be, O * 128, O * 128 + 32, O * 128 + 64, O * 128 + 96);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+                    float y[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[O][4 * q + e];
+                        y[e] = __builtin_fmaf((v[e] - mean) * rstd, gg[q][e], bt[q][e]);
+                    }
+                    *(f32x4*)(xi + O * 512 + q * 64) = v;
+                    u32x2 o;
+                    o[0] = pack_bf16x2(y[0], y[1]);
+                    o[1] = pack_bf16x2(y[2], y[3]);
+                    *(u32x2*)(ni + O * 512 + q * 128) = o;
                 }
             });
         }
@@ -323,13 +400,18 @@ int hipt_embed32_launch(const EmbedParams& p_in, hipStream_t st) {
     HIPT_CHECK_ARG(p.ntx == 16 && p.nty % 8 == 0 && p.ntok == p.nty * p.ntx + 1, "embed32: token grid %dx%d / %d tokens", p.nty, p.ntx, p.ntok);
     HIPT_CHECK_ARG(((uintptr_t)p.img % 16) == 0 && p.im.row_stride % 4 == 0 && p.im.chan_stride % 4 == 0 && p.im.batch_stride % 4 == 0 && p.im.patch_w % 16 == 0,
                    "embed32: 16-byte aligned pixel rows required");
-    const int lds = 3 * UNIT + D * 4 + 16;
+    const bool lnout = p.xn_out != nullptr;
+    HIPT_CHECK_ARG(!lnout || (p.ln_w && p.ln_b && ((int64_t)p.nseq * p.ntok) % 16 == 0), "embed32: image output needs LayerNorm parameters and whole 16-row fragments");
+    const int lds = 3 * UNIT + (lnout ? 3 : 1) * D * 4 + 16;
     static DevOnce once;
     HIPT_CUR_DEVICE(dev);
     if (!once.done[dev]) {
-        if (hipFuncSetAttribute((const void*)embed32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)embed32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)embed32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)embed32_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)embed32_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)embed32_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)embed32_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)embed32_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)embed32_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             hipt_set_error("hipFuncSetAttribute(embed32) failed");
             return HIPT_E_LAUNCH;
         }
@@ -348,7 +430,9 @@ int hipt_embed32_launch(const EmbedParams& p_in, hipStream_t st) {
         hipt_set_error("embed32: hipMemsetAsync(counter) failed");
         return HIPT_E_LAUNCH;
     }
-    hipLaunchKernelGGL(p.kind == 2 ? embed32_kernel<2> : (p.kind == 1 ? embed32_kernel<1> : embed32_kernel<0>), dim3(grid), dim3(256), lds, st, p);
+    auto k = lnout ? (p.kind == 2 ? embed32_kernel<2, true> : (p.kind == 1 ? embed32_kernel<1, true> : embed32_kernel<0, true>))
+                   : (p.kind == 2 ? embed32_kernel<2, false> : (p.kind == 1 ? embed32_kernel<1, false> : embed32_kernel<0, false>));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }

@@ -56,6 +56,12 @@ struct EmbedParams {
     int ntok;
     int* counter;            // device int the launcher zeroes on the stream: the kernel's tile queue
     int ntiles;              // (set by the launcher)
+    // optional: xn_out != null -> x is written as the fp32 ACTIVATION IMAGE (below) and LayerNorm(x; ln_w, ln_b, ln_eps) -- the first block's
+    // LayerNorm-1 -- as the bf16 image xn_out (nseq * ntok % 16 == 0); the [CLS] rows of both: hipt_cls_init_img_launch
+    void* xn_out;
+    const float* ln_w;
+    const float* ln_b;
+    float ln_eps;
 };
 bool hipt_embed32_supported(int dtype, int D, int K, int nty, int ntx);
 size_t hipt_embed32_packed_bytes();
@@ -165,6 +171,9 @@ int hipt_gather_cls_launch(const float* src, float* dst, int nseq, int64_t seq_s
 int hipt_gather_cls_bf16_launch(const void* src, void* dst, int nseq, int ntok, int D, hipStream_t st, int img = 0);  // bf16 rows s * ntok of [.., 384]
 // x[s, 0, :] = cls + pos[0]  for s in [0, nseq)
 int hipt_cls_init_launch(float* x, const float* cls, const float* pos, int nseq, int ntok, int D, hipStream_t st);
+// the same into ACTIVATION IMAGES (D = 384): row s * ntok of the fp32 image x_img = cls + pos[0], and of the bf16 image xn_img its LayerNorm
+int hipt_cls_init_img_launch(float* x_img, void* xn_img, const float* cls, const float* pos, const float* ln_w, const float* ln_b, float ln_eps, int nseq,
+                             int ntok, int D, hipStream_t st);
 // out[i] = src[i] (+ (float)y[i] if y)  (fp32, bf16 branch, n % 8 == 0): lands the residual stream in the caller's buffer
 int hipt_add_bf16_launch(float* out, const float* src, const void* y, int64_t n, hipStream_t st);
 // uint8 image -> normalised compute-dtype image [n, 3, plane] (ToTensor + Normalize(0.5, 0.5)); hwc: src is [n, plane, 3]

@@ -74,6 +74,39 @@ __global__ void cls_init_kernel(float* x, const float* cls, const float* pos, in
     x[(int64_t)s * ntok * D + d] = cls[d] + pos[d];
 }
 
+// one wave per sequence: the [CLS] row (cls + pos[0]: the same 384 values for every sequence) into the fp32 activation image, its LayerNorm into
+// the bf16 one (kernels.h: fragment F = rows [16 F, 16 F + 16), row li, 16-byte chunk g + 4 c at c * 512 + (16 g + li) * 8 bf16 elements)
+__global__ __launch_bounds__(64) void cls_init_img_kernel(float* __restrict__ x, bf16_t* __restrict__ xn, const float* __restrict__ cls, const float* __restrict__ pos,
+                                                          const float* __restrict__ gw, const float* __restrict__ gb, float eps, int nseq, int ntok) {
+#pragma clang fp contract(off)
+    constexpr int D = 384;
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= nseq) return;
+    float v[6], sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        v[j] = cls[lane + 64 * j] + pos[lane + 64 * j];
+        sum += v[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / (float)D;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) var = __builtin_fmaf(v[j] - mean, v[j] - mean, var);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    const float rstd = 1.0f / sqrtf(var / (float)D + eps);
+    const int64_t R = (int64_t)s * ntok, F = R >> 4;
+    const int li = (int)(R & 15);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int d = lane + 64 * j, ch = d >> 3;
+        x[F * 6144 + (ch >> 2) * 512 + ((d >> 2) & 1) * 256 + (16 * (ch & 3) + li) * 4 + (d & 3)] = v[j];
+        xn[F * 6144 + (ch >> 2) * 512 + (16 * (ch & 3) + li) * 8 + (d & 7)] = (bf16_t)__builtin_fmaf((v[j] - mean) * rstd, gw[d], gb[d]);
+    }
+}
+
 __global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n8) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const f32x4 a = *(const f32x4*)(in + i * 8), c = *(const f32x4*)(in + i * 8 + 4);
@@ -406,6 +439,14 @@ int hipt_layernorm_launch(const float* x, int64_t x_stride, const float* w, cons
 int hipt_cls_init_launch(float* x, const float* cls, const float* pos, int nseq, int ntok, int D, hipStream_t st) {
     const int n = nseq * D;
     hipLaunchKernelGGL(cls_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, cls, pos, nseq, ntok, D);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}
+
+int hipt_cls_init_img_launch(float* x_img, void* xn_img, const float* cls, const float* pos, const float* ln_w, const float* ln_b, float ln_eps, int nseq,
+                             int ntok, int D, hipStream_t st) {
+    HIPT_CHECK_ARG(D == 384 && x_img && xn_img && ln_w && ln_b && nseq > 0 && ((int64_t)nseq * ntok) % 16 == 0, "cls_init_img: D = 384 and whole 16-row fragments");
+    hipLaunchKernelGGL(cls_init_img_kernel, dim3(nseq), dim3(64), 0, st, x_img, (bf16_t*)xn_img, cls, pos, ln_w, ln_b, ln_eps, nseq, ntok);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }

@@ -155,8 +155,15 @@ class HIPT_4K(torch.nn.Module):
         import ctypes as C
         per, nseq = w_256 * h_256, nreg * w_256 * h_256
         lay = N.ImageLayout(w_256, h_256, 256, 256, H, W * H, 3 * W * H)
-        kind = (2 if hwc else 1) if u8 else 0
         cur = torch.cuda.current_stream(dev)
+        if u8:
+            # raw RGB bytes: normalised once into fp32 (ToTensor + Normalize(0.5, 0.5), the bits torch computes), then the float path -- the
+            # pixel-reading embedding below.  (Not the bf16 copy: the ranges must take the kernels the whole-region call takes -- embed32.hip hands
+            # the first block its operands -- or a region's bits would depend on patch_streams.)
+            buf = Fn.workspace(dev, nreg * 3 * W * H * 4, ("u8f32", cur.cuda_stream))[:nreg * 3 * W * H * 4].view(torch.float32).view(nreg, 3, W, H)
+            N.call("hipt_u8_normalize", N.ptr(region), int(hwc), nreg, W * H, N.ptr(buf), N.HIPT_F32, N.stream_ptr(dev))
+            region, u8, hwc = buf, False, False
+        kind = 0
         # fp32 pixels and a patch embedding that reads them itself (csrc/embed32.hip): no copy in the compute dtype
         # (that kernel loads 16 bytes at a time: a region view that starts off a 16-byte boundary takes the converted copy instead)
         px = (not u8) and region.data_ptr() % 16 == 0 and N.lib().hipt_vit256_range_px_workspace_bytes(pk256.ref, C.byref(lay), 16, self.chunk) > 0

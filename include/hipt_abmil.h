@@ -239,7 +239,10 @@ int hipt_vit256_forward_range(const hipt_vit_weights* w, const void* images_cd, 
                               int seq0, int nseq, int chunk, float* out, void* workspace, size_t ws_bytes, void* stream);
 /* The same straight from fp32 pixels, for models / layouts whose patch embedding reads them itself (bf16 ViT-256 on 256 x 256
  * patches): no compute-dtype copy of the image.  hipt_vit256_range_px_workspace_bytes returns 0 where that is not available
- * (then: hipt_image_to_compute + hipt_vit256_forward_range). */
+ * (then: hipt_image_to_compute + hipt_vit256_forward_range).
+ * Bits: the pixel-reading embedding hands the first block LayerNorm-ed operands itself (bf16, whole 16-row fragments), which the embedding over a
+ * compute-dtype copy does not -- hipt_vit256_forward_range_px gives the bits of hipt_vit256_forward / hipt_hipt4k_forward on the same pixels,
+ * hipt_vit256_forward_range agrees with them to the bf16 bar only.  Split a call with the _px form (uint8 input: hipt_u8_normalize to fp32 first). */
 size_t hipt_vit256_range_px_workspace_bytes(const hipt_vit_weights* w, const hipt_image_layout* lay, int nseq, int chunk);
 int hipt_vit256_forward_range_px(const hipt_vit_weights* w, const float* images, const hipt_image_layout* lay, int seq0, int nseq,
                                  int chunk, float* out, void* workspace, size_t ws_bytes, void* stream);

@@ -506,11 +506,13 @@ def test_vit256_activation_images_change_nothing(vit256, monkeypatch):
     """forward() keeps the residual stream, the attention-branch output and the pre-normalised QKV operands of blocks
     2..11 as fragment-blocked "activation images" (csrc/kernels.h) when the batch has whole 16-row fragments: a pure
     re-ordering of bytes in private buffers -- identical bits to the row-major path (HIPT_NO_IMG=1) when both sides run the
-    same kernels (HIPT_NO_FUSED_ATTN=1: the fused QKV + attention kernel exists with images only), also for a batch whose
-    row count is not a multiple of 16 (which never uses them)."""
+    same kernels (HIPT_NO_FUSED_ATTN=1: the fused QKV + attention kernel exists with images only; HIPT_NO_EMBED_LN=1: the patch
+    embedding's own LayerNorm-1 -- another summation order than the LN-in-GEMM load -- exists with images only), also for a batch
+    whose row count is not a multiple of 16 (which never uses them)."""
     vit256.set_compute_dtype("bf16")
     try:
         monkeypatch.setenv("HIPT_NO_FUSED_ATTN", "1")
+        monkeypatch.setenv("HIPT_NO_EMBED_LN", "1")
         for nseq in (16, 48, 5):  # 16 * 257 and 48 * 257 rows: whole fragments; 5 * 257: not
             x = synth.hash_uniform_torch((nseq, 3, 256, 256), 23 + nseq, device=DEV)
             img = vit256(x)
@@ -521,7 +523,49 @@ def test_vit256_activation_images_change_nothing(vit256, monkeypatch):
     finally:
         monkeypatch.delenv("HIPT_NO_IMG", raising=False)
         monkeypatch.delenv("HIPT_NO_FUSED_ATTN", raising=False)
+        monkeypatch.delenv("HIPT_NO_EMBED_LN", raising=False)
         vit256.set_compute_dtype("fp32")
+
+
+def test_vit256_embedding_emits_first_block_operands(vit256, hipt, monkeypatch):
+    """With activation images the patch embedding (embed32.hip, LNOUT) writes x as the fp32 image and LayerNorm-1 of the FIRST block as the bf16
+    image, so that block 1 runs the fused QKV + attention kernel and the image-in fused MLP like blocks 2..11 (vision_transformer.py:235-246 then
+    Block.forward :146-152).  Against the fp32 oracle at the bf16 bar of the other 12-block tests, against the path without it (HIPT_NO_EMBED_LN=1:
+    LayerNorm in the QKV GEMM's load + the two-kernel attention) within that bar; a patch's features do not depend on its position in the call or
+    on the call's size (bitwise); uint8 regions (planar and interleaved, 16 patches: whole fragments) give the bits of the normalised float path."""
+    p = synth.make_params_np(synth.vit_param_specs("vit256"), 256)
+    vit256.set_compute_dtype("bf16")
+    try:
+        x = synth.hash_uniform_torch((48, 3, 256, 256), 91, device=DEV)
+        before = N.calls
+        out = vit256(x)
+        assert N.calls > before
+        monkeypatch.setenv("HIPT_NO_EMBED_LN", "1")
+        old = vit256(x)
+        monkeypatch.delenv("HIPT_NO_EMBED_LN")
+        ref = O.vit256_forward(x[:4].cpu().numpy(), p, num_heads=6)
+        r_new, r_old, r_no = rel_l2(out[:4], ref), rel_l2(old[:4], ref), float((out - old).norm() / old.norm())
+        print(f"ViT-256 bf16 vs fp32 oracle: embedding's LayerNorm {r_new:.2e}, LN-in-GEMM first block {r_old:.2e}; one vs the other {r_no:.2e}")
+        assert r_new < 2e-2 and r_old < 2e-2 and 0 < r_no < 2e-2  # (two bf16 paths through 12 blocks)
+        # position and call size: patches 16..31 alone, and the same patches at the head of a 32-patch call
+        assert torch.equal(vit256(x[16:32]), out[16:32])
+        assert torch.equal(vit256(torch.cat([x[16:32], x[:16]]))[:16], out[16:32])
+    finally:
+        monkeypatch.delenv("HIPT_NO_EMBED_LN", raising=False)
+        vit256.set_compute_dtype("fp32")
+    g = torch.Generator().manual_seed(7)
+    u8 = torch.randint(0, 256, (1, 1024, 1024, 3), dtype=torch.uint8, generator=g)  # one decoded tile of 16 patches
+    planar = u8.permute(0, 3, 1, 2).contiguous()
+    ref_in = planar.float().div(255).sub(0.5).div(0.5)
+    hipt.set_compute_dtype("bf16")
+    try:
+        want = hipt(ref_in.to(DEV))
+        assert torch.equal(hipt(planar.to(DEV)), want) and torch.equal(hipt(u8.to(DEV)), want)
+        monkeypatch.setenv("HIPT_NO_EMBED_LN", "1")
+        assert not torch.equal(hipt(ref_in.to(DEV)), want)  # (the switch reaches this path: one region of 16 patches uses the images)
+    finally:
+        monkeypatch.delenv("HIPT_NO_EMBED_LN", raising=False)
+        hipt.set_compute_dtype("fp32")
 
 
 def _to_image(x):
