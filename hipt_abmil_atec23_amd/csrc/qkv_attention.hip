@@ -256,6 +256,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     // (static priority for waves 4-7 -- MI355X_MICROARCH.md, "Two waves per SIMD", item 4 -- measured in round 5: 864 / 866 us per
     //  attention unit without, 872 / 854 with: noise; not kept)
     QSTAMP_DECL;
+    unsigned long long st_rt0 = 0;  // (stamps build: this workgroup's wall time, 100 MHz ticks, in slot 7)
+    if (QST_ON(p.stamps) && w == 0) st_rt0 = __builtin_amdgcn_s_memrealtime();
     int pq = 0;          // parity of the patch counter: which [CLS] partial buffer / [CLS] row buffer
     int prev_b = -1, prev_hs = 0;  // work unit whose partials wait for their merge
     if (!any) return;  // (uniform: a workgroup without work)
@@ -679,6 +681,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     __builtin_amdgcn_s_barrier();
     if (prev_b >= 0 && w == (last_wi & 7)) merge_cls(prev_b, prev_hs, pq ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (continuous stream: pieces of units nobody consumes)
+    if (QST_ON(p.stamps) && w == 0) st_sum[7] = __builtin_amdgcn_s_memrealtime() - st_rt0;
     if (QST_ON(p.stamps) && tid == 0)
         for (int k = 0; k < 8; ++k) p.stamps[(size_t)blockIdx.x * 8 + k] = st_sum[k];
 }
@@ -777,7 +780,19 @@ static int qkv_attn_launch(const void* xn_img, const void* wpk, const float* qkv
         double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const double heads = (double)((p.px * HEADS + p.nslots - 1) / p.nslots);
         for (int b = 0; b < grid; ++b)
-            for (int k = 0; k < 8; ++k) ph[k] += (double)h[b * 8 + k] / grid / heads;
+            for (int k = 0; k < 7; ++k) ph[k] += (double)h[b * 8 + k] / grid / heads;
+        {   // wall time of the workgroups (slot 7, 100 MHz): how even is the static split over the XCDs and their CUs?
+            double xm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lo = 1e30, hi = 0, mean = 0;
+            for (int b = 0; b < grid; ++b) {
+                const double us = (double)h[b * 8 + 7] * 0.01;
+                xm[b & 7] += us / (grid / 8);
+                mean += us / grid;
+                lo = us < lo ? us : lo;
+                hi = us > hi ? us : hi;
+            }
+            fprintf(stderr, "[qkv_attention nseq=%d grid=%d] workgroup wall time: mean %.1f us, min %.1f, max %.1f | per XCD mean %.1f %.1f %.1f %.1f %.1f %.1f %.1f %.1f\n", nseq, grid,
+                    mean, lo, hi, xm[0], xm[1], xm[2], xm[3], xm[4], xm[5], xm[6], xm[7]);
+        }
         fprintf(stderr, "[qkv_attention nseq=%d grid=%d] cycles per (patch, head) (wave 0): GEMM units %.0f | [CLS] k/v + barrier %.0f | [CLS] query %.0f | scores %.0f | "
                         "softmax %.0f | PV %.0f | operand loads + stores %.0f  (sum %.0f)\n",
                 nseq, grid, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5] + ph[6]);

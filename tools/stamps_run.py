@@ -10,6 +10,7 @@ m = HIPT_4K(None, None, dev, dev)
 m.model256.load_state_dict(synth.make_state_dict(synth.vit_param_specs("vit256"), 256))
 m.model4k.load_state_dict(synth.make_state_dict(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096))
 m = m.eval().to(dev).set_compute_dtype("bf16")
+m.streams = int(os.environ.get("STREAMS", m.streams))  # (STREAMS=1: all 8 regions = 2 048 patches in every launch)
 x = synth.hash_uniform_torch((8, 3, 4096, 4096), 3, device=dev)
 with torch.no_grad():
     m(x); torch.cuda.synchronize()
