@@ -137,6 +137,51 @@ SUSTAINED_HBM_GBS = 6200.0
 MFMA_SHAPE_OF = {"mlp_fused": "16x16x32", "qkv_attention_fused": "32x32x16", "qkv_gemm": "16x16x32", "proj_gemm": "16x16x32", "attention": "16x16x32"}
 
 
+SUSTAINED_SOURCE = ["constants typed from tools/mfma_shape_probe.hip runs of round 4 (DESIGN_HISTORY.md); profiles/r06_power.json holds round 6's measurement with W and MHz"]
+
+
+def measure_sustained(dev, sampler=None, seconds=1.5):
+    """The bf16 MFMA rate the chip SUSTAINS on THIS box in THIS run: bare 16x16x32 and 32x32x16 loops on random operands (tools/power_probe.hip, one
+    wave per SIMD, 256 workgroups), `seconds` each after a 0.5 s ramp, HIP-event timed; with the hwmon sampler the W and MHz they ran at.
+    Returns {shape: {...}} or None when the probe library is not built (build(): __graft_entry__.py)."""
+    import ctypes as C
+
+    import torch
+    so = os.path.join(ROOT, "tools", "probe_bin", "libpower_probe.so")
+    if not os.path.exists(so):
+        return None
+    pp = C.CDLL(so)
+    pp.pp_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    outb = torch.zeros(2 * 4 * ncu, dtype=torch.int64, device=dev)
+    iters = 200000  # 25.6 M matrix-pipe cycles per launch: ~12 ms
+    res = {}
+    for shape, name in ((16, "16x16x32"), (32, "32x32x16")):
+        launch = lambda: pp.pp_launch(shape, ncu, iters, outb.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.5:
+            launch()
+            torch.cuda.synchronize()
+        lo = sampler.mark() if sampler else 0
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(4):
+                launch()
+                n += 1
+            torch.cuda.current_stream(dev).synchronize()
+        b.record()
+        torch.cuda.synchronize()
+        tf = ncu * 4 * iters * 131072.0 * n / (a.elapsed_time(b) * 1e-3) / 1e12
+        h = outb.cpu().numpy().reshape(-1, 2).astype("float64")
+        res[name] = {"tflops": tf, "in_kernel_ghz": float((h[:, 0] / h[:, 1]).mean() * 0.1)}
+        if sampler:
+            sm = sampler.summary(lo, sampler.mark(), skip_s=0.3)
+            res[name].update({k: sm.get(k) for k in ("power_w_mean", "power_w_max", "sclk_mhz_mean")})
+    return res
+
+
 PROJ_FOLDED = [False]  # set by main(): the library runs the output projection inside the fused MLP kernel (image format 3, no HIPT_NO_PROJ_FOLD)
 
 
@@ -305,7 +350,7 @@ def main():
     from hipt_abmil_atec23_amd import synth
 
     dry = args.dry_run
-    rank, world, local = D.init_from_env(backend="gloo" if dry else None)
+    rank, world, local = D.init_from_env(backend="gloo" if dry else None, single_rank_group=True)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the job has WORLD_SIZE={world} rank(s): refusing to report a number for a "
                          f"different GPU count than asked for")
@@ -364,7 +409,18 @@ def main():
 
     for i in range(args.warmup):
         step(i, False)
+    # board power / shader clock over the timed steps: a thread of THIS process reading the card's hwmon node (tools/telemetry.py; sysfs only --
+    # no GPU call, no child process), rank 0 only
+    sampler = None
+    if not dry and rank == 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from telemetry import PowerSampler, pci_bus_id_of
+            sampler = PowerSampler(pci_bus_id_of(local), period_s=0.01).start()
+        except Exception:
+            sampler = None
     barrier()
+    p_lo = sampler.mark() if sampler else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = step(i, True)
@@ -372,6 +428,7 @@ def main():
         D.gather_slide_outputs([rank], [last[1]], [last[2]], world, device=dev)
     barrier()
     dt = time.perf_counter() - t0
+    power_timed = sampler.summary(p_lo, sampler.mark()) if sampler else None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if grp[0]:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -513,6 +570,21 @@ def main():
         out["rccl_ranks" if group_info["backend"] == "nccl" else "group_ranks"] = group_info["ranks"]
         out["collective_backend"] = group_info["backend"]
 
+    if power_timed is not None:
+        # what the board drew and the shader clock it held over the timed steps (hwmon power1_input / freq1_input, 10 ms samples)
+        out["power"] = dict(power_timed, note="socket power and sclk over the timed steps; power_cap_w = hwmon power1_cap (the board limit)")
+    # the ceilings `frac_of_sustained` is quoted against, measured by THIS run on THIS box (bare MFMA loops, 2 s each) -- or the typed constants
+    if not args.no_extras and world == 1:
+        try:
+            ms_ = measure_sustained(dev, sampler)
+            if ms_:
+                for shp, v in ms_.items():
+                    SUSTAINED_TFLOPS[shp] = v["tflops"]
+                SUSTAINED_SOURCE[0] = "measured by this run: bare bf16 MFMA loops on random operands, one wave per SIMD, 256 workgroups (tools/power_probe.hip)"
+                out["sustained_mfma"] = ms_
+        except Exception as e:
+            out["sustained_mfma"] = {"error": repr(e)[:200]}
+
     # ---- per-kernel roofline leg: same workload, HIP events around every launch, ONE stream ----
     prof = {}
     if args.profile_steps > 0:
@@ -550,6 +622,7 @@ def main():
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": frac[dom]["achieved"], "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                            "frac": frac[dom]["frac"], "mfma_shape": MFMA_SHAPE_OF.get(dom), "peak_sustained": SUSTAINED_TFLOPS.get(MFMA_SHAPE_OF.get(dom)),
                            "frac_of_sustained": (frac[dom]["achieved"] / SUSTAINED_TFLOPS[MFMA_SHAPE_OF[dom]]) if args.dtype == "bf16" and dom in MFMA_SHAPE_OF else None,
+                           "peak_sustained_source": SUSTAINED_SOURCE[0],
                            "traffic": pmc_traffic(dom), "traffic_source": pmc_traffic(dom, True)[1], "flops_per_launch": flops_of(dom),
                            "rows_per_launch": rows_launch, "launches_per_step": mf[dom]["launches_per_step"], "avg_launch_us": mf[dom]["avg_us"],
                            "proj_folded_into_fused_mlp": PROJ_FOLDED[0]}

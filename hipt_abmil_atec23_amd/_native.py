@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 
 HIPT_F32, HIPT_BF16 = 0, 1
 EPI_GELU, EPI_RESID, EPI_OUT_F32, EPI_RELU = 1, 2, 4, 16
-ABI_VERSION = 4
+ABI_VERSION = 5
 PACK_QKV, PACK_PROJ, PACK_MLP, PACK_QKV_ATT = 0, 1, 2, 3
 
 c_f32p = C.c_void_p  # device pointers travel as integers
@@ -88,6 +88,7 @@ SIGNATURES = {
     "hipt_vit_head": (_i, [_VW, _p, _i, _i, _p, _p]),
     "hipt_vit_cls_attention": (_i, [_VW, _p, _i, _p, _p, _sz, _p]),
     "hipt_vit_attention_unit": (_i, [_VW, _i, _p, _i, _p, _i, _p, _sz, _p]),
+    "hipt_vit_mlp_unit": (_i, [_VW, _i, _p, _p, _i, _p, _p, _sz, _p]),
     "hipt_vit256_forward": (_i, [_VW, _p, _IL, _i, _i, _p, _p, _sz, _p]),
     "hipt_vit4k_forward": (_i, [_VW, _p, _i, _p, _p, _sz, _p]),
     "hipt_image_compute_bytes": (_sz, [_VW, _IL, _i, _i]),

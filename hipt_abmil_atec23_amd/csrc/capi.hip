@@ -696,6 +696,37 @@ int hipt_vit_attention_unit(const hipt_vit_weights* w, int block, const void* xn
     return hipt_attention_launch(s.qkv, out_img, nullptr, nseq, w->ntok, w->heads, D / w->heads, attn_scale(w), w->dtype, st, 1, hm ? 1 : 0);
 }
 
+int hipt_vit_mlp_unit(const hipt_vit_weights* w, int block, float* x_img, const void* att_img, int nseq, void* xn_out_img, void* workspace,
+                      size_t ws_bytes, void* stream) {
+    int rc = check_vit(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(x_img && att_img && nseq > 0 && block >= 0 && block < w->depth, "vit_mlp_unit: bad argument");
+    const int D = w->dim, M = nseq * w->ntok;
+    const hipt_block_weights& b = w->blocks[block];
+    if (!hipt_mlp16_supported(w->dtype, D, w->hidden) || M % 16 != 0 || !b.mlp_pk || b.mlp_pk_fmt != 3) {
+        hipt_set_error("vit_mlp_unit: bf16, D = 384, hidden %% 128 == 0, nseq * ntok %% 16 == 0 and blocks[%d].mlp_pk in format 3 only", block);
+        return HIPT_E_UNSUPPORTED;
+    }
+    if (ws_bytes < 256 || ((uintptr_t)workspace & 255) || !workspace) {
+        hipt_set_error("vit_mlp_unit: workspace %zu B too small / unaligned (need 256)", ws_bytes);
+        return HIPT_E_WORKSPACE;
+    }
+    MlpParams m;
+    memset(&m, 0, sizeof(m));
+    m.x = x_img; m.y1 = att_img; m.fold = 1; m.bproj = b.proj_b;
+    m.ln_w = b.ln2_w; m.ln_b = b.ln2_b; m.ln_eps = w->ln_eps;
+    m.w1 = b.fc1_w; m.b1 = b.fc1_b; m.w2 = b.fc2_w; m.b2 = b.fc2_b; m.wpk = b.mlp_pk; m.wpk_fmt = b.mlp_pk_fmt; m.M = M; m.D = D; m.hidden = w->hidden;
+    m.counter = (int*)workspace;
+    m.img = 3;
+    if (xn_out_img) {
+        const hipt_block_weights& nb = w->blocks[block + 1 < w->depth ? block + 1 : block];
+        m.ln_next_w = nb.ln1_w; m.ln_next_b = nb.ln1_b; m.xn_out = xn_out_img;
+    }
+    hipStream_t st = S(stream);
+    PROF(PC_MLP, hipt_mlp_launch(m, st));
+    return HIPT_OK;
+}
+
 // Format of the fused MLP's weight image: 2 = csrc/mlp16.hip (16x16x32 MFMAs), 0 = this shape has no packed form.  (Format 1 was the
 // 32x32x16 form of rounds 2-4, tools/experiments/mlp32_r4.hip: a tie on the MLP launches themselves, 3 % behind on the kernels that run
 // between them -- DESIGN.md -- and retired in round 5; an image packed as format 1 is refused by the chain test in run_blocks and its

@@ -19,17 +19,20 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
-    """(rank, world, local_rank) from the torchrun environment; initialises the process group whenever a launcher set one up
-    (RANK + WORLD_SIZE + MASTER_PORT present) -- also for ONE rank: `python -m torch.distributed.run --nproc-per-node 1 bench.py`
-    then carries its gather over a real 1-rank RCCL communicator, which is how the collective path is exercised on a one-GPU box.
-    Without a launcher environment (plain `python bench.py`) there is no group and the gather is a local copy.
-    RCCL needs dmabuf IPC on this pool, hence HSA_ENABLE_IPC_MODE_LEGACY=0."""
+def init_from_env(backend: str | None = None, single_rank_group: bool | None = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; initialises the process group for WORLD_SIZE > 1.
+    ONE rank gets NO group by default (schedulers and wrappers export RANK / WORLD_SIZE / MASTER_PORT to single-process jobs too: a library
+    must not answer that with an RCCL communicator and a TCP rendezvous).  ``single_rank_group=True`` (or ``HIPT_SINGLE_RANK_GROUP=1``) opts in,
+    when a launcher set the environment up (RANK + WORLD_SIZE + MASTER_PORT present): `python -m torch.distributed.run --nproc-per-node 1
+    bench.py` then carries its gather over a real 1-rank RCCL communicator -- how the collective path is exercised on a one-GPU box.
+    Without a group the gather is a local copy.  RCCL needs dmabuf IPC on this pool, hence HSA_ENABLE_IPC_MODE_LEGACY=0."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if single_rank_group is None:
+        single_rank_group = os.environ.get("HIPT_SINGLE_RANK_GROUP", "0") not in ("", "0")
     launched = all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_PORT"))
-    if (world > 1 or launched) and not dist.is_initialized():
+    if (world > 1 or (launched and single_rank_group)) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
@@ -86,15 +89,20 @@ def gather_slide_outputs(slide_ids: Sequence[int], logits: Sequence[torch.Tensor
         dist.all_reduce(meta, op=dist.ReduceOp.MAX)
     S, n_max, C = (int(v) for v in meta.tolist())
     HDR = 4  # int64 id | int64 length, bit-cast into four fp32 slots
+    # The block is assembled with a constant number of device operations whatever the slide count (round 6: it used to be three scalar
+    # writes per slide): the header from ONE host tensor, the logits from one stack, the ragged A_raw rows from one pad.
     block = torch.zeros((S, HDR + C + n_max), dtype=torch.float32, device=device)
-    hdr = torch.full((S, 2), -1, dtype=torch.int64, device=device)  # id -1: empty slot
+    hdr_h = torch.full((S, 2), -1, dtype=torch.int64)  # id -1: empty slot
     for j, sid in enumerate(slide_ids):
-        n = int(a_raw[j].numel())
-        hdr[j, 0] = int(sid)
-        hdr[j, 1] = n
-        block[j, HDR:HDR + C] = logits[j].reshape(-1).float()
-        block[j, HDR + C:HDR + C + n] = a_raw[j].reshape(-1).float()
-    block[:, :HDR] = hdr.view(torch.float32)  # raw bits: the collective moves bytes, nothing interprets these words as floats
+        hdr_h[j, 0] = int(sid)
+        hdr_h[j, 1] = int(a_raw[j].numel())
+    block[:, :HDR] = hdr_h.to(device).view(torch.float32)  # raw bits: the collective moves bytes, nothing interprets these words as floats
+    if s_local:
+        if C:
+            block[:s_local, HDR:HDR + C] = torch.stack([l.reshape(-1).float() for l in logits])
+        if n_local_max:
+            pad = torch.nn.utils.rnn.pad_sequence([a.reshape(-1).float() for a in a_raw], batch_first=True)
+            block[:s_local, HDR + C:HDR + C + pad.shape[1]] = pad
     if grouped():
         out = torch.empty((ws * S, block.shape[1]), dtype=torch.float32, device=device)  # concatenated along dim 0
         dist.all_gather_into_tensor(out, block)
@@ -102,11 +110,12 @@ def gather_slide_outputs(slide_ids: Sequence[int], logits: Sequence[torch.Tensor
         out = block
     all_logits = torch.zeros((n_slides, C), dtype=torch.float32, device=device)
     all_a: List[torch.Tensor] = [torch.empty(0, device=device) for _ in range(n_slides)]
-    meta_i = out[:, :HDR].contiguous().view(torch.int64)
+    meta_i = out[:, :HDR].contiguous().view(torch.int64).cpu()  # ONE read-back: ids and lengths of every row
     ids, lens = meta_i[:, 0].tolist(), meta_i[:, 1].tolist()
-    for row, (sid, n) in enumerate(zip(ids, lens)):
-        if sid < 0:
-            continue
-        all_logits[sid] = out[row, HDR:HDR + C]
-        all_a[sid] = out[row, HDR + C:HDR + C + n].clone()
+    rows = [r for r, sid in enumerate(ids) if sid >= 0]
+    if rows:
+        sel = torch.tensor(rows, dtype=torch.int64, device=device)
+        all_logits[torch.tensor([ids[r] for r in rows], dtype=torch.int64, device=device)] = out[sel, HDR:HDR + C]
+    for r in rows:  # (views of the gathered buffer: no launch per slide)
+        all_a[ids[r]] = out[r, HDR + C:HDR + C + lens[r]]
     return all_logits, all_a

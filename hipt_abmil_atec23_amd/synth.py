@@ -159,3 +159,59 @@ def make_state_dict(specs, base_seed: int = 0, device="cpu"):
     """Materialise a spec dict as torch tensors (same bits as :func:`make_params_np`)."""
     return OrderedDict((k, hash_uniform_torch(shape, name_seed(k, base_seed), sc, off, device=device))
                        for k, (shape, sc, off) in specs.items())
+
+
+# ----------------------------------------------------------------------------------
+# The OUTLIER weight family (round 6): the benign family above has LN gamma ~ 1 and O(1) activations everywhere; trained DINO ViTs
+# do not -- a few residual channels carry magnitudes of 10^2 ("massive activations"), LayerNorm gains spread over two decades, some
+# heads are peaky.  The same specs, then deterministic edits (exactly representable constants, chosen by the hash):
+#   * every LayerNorm gain: ~2 % of the channels take a value from GAINS (0.05 ... 20);
+#   * four residual channels get a bias of +-(50 ... 100) in the patch embedding (ViT-256: patch_embed.proj.bias; ViT-4K: phi.0.bias)
+#     and four more in blocks.0.mlp.fc2.bias;
+#   * in every block the q and k rows of ONE head (block i: head i mod heads) are scaled by `qk_scale` each: logits of that head ~ +-40.
+# ----------------------------------------------------------------------------------
+GAINS = (0.05, 0.1, 0.25, 0.5, 2.0, 4.0, 8.0, 20.0)
+_BIG = (50.0, -62.5, 75.0, -100.0)
+
+
+def apply_vit_outliers_np(params, heads: int, qk_scale: float = 3.0, seed: int = 77):
+    """In-place edits of a ``make_params_np`` dict of a ViT (see above); returns it."""
+    D = params["norm.weight"].shape[0]
+    dh = D // heads
+    for k in list(params):
+        if k.endswith(("norm1.weight", "norm2.weight")) or k == "norm.weight":
+            h = hash_u32_np(D, name_seed(k, seed))
+            idx = np.nonzero(h % np.uint32(50) == 0)[0]
+            params[k][idx] = np.asarray(GAINS, np.float32)[(h[idx] >> np.uint32(8)) % np.uint32(len(GAINS))]
+    ek = "patch_embed.proj.bias" if "patch_embed.proj.bias" in params else "phi.0.bias"
+    for j, k in enumerate((ek, "blocks.0.mlp.fc2.bias")):
+        ch = np.unique(hash_u32_np(4, name_seed(k, seed + 1)) % np.uint32(D))
+        params[k][ch] = np.asarray(_BIG, np.float32)[:len(ch)] * np.float32(1.0 if j == 0 else -1.0)
+    i = 0
+    while f"blocks.{i}.attn.qkv.weight" in params:
+        w, b = params[f"blocks.{i}.attn.qkv.weight"], params[f"blocks.{i}.attn.qkv.bias"]
+        hd = i % heads
+        for part in (0, 1):  # q rows, k rows
+            sl = slice(part * D + hd * dh, part * D + (hd + 1) * dh)
+            w[sl] *= np.float32(qk_scale)
+            b[sl] *= np.float32(qk_scale)
+        i += 1
+    return params
+
+
+def make_vit_outlier_params_np(specs, base_seed: int, heads: int, qk_scale: float = 3.0):
+    return apply_vit_outliers_np(make_params_np(specs, base_seed), heads, qk_scale)
+
+
+def make_vit_outlier_state_dict(specs, base_seed: int, heads: int, qk_scale: float = 3.0, device="cpu"):
+    """torch tensors with the bits of :func:`make_vit_outlier_params_np` (made on the host, then moved)."""
+    import torch
+    return OrderedDict((k, torch.from_numpy(v).to(device)) for k, v in make_vit_outlier_params_np(specs, base_seed, heads, qk_scale).items())
+
+
+def scale_clam_attention_c_np(params, target_bound: float):
+    """attention_c.weight rescaled so that sum_j |wc_j| (the bound of |A_raw - bc|: tanh * sigmoid is inside (-1, 1)) equals
+    `target_bound` up to fp32 rounding -- CLAM's fixed-shift softmax kernel runs below 60, the general kernels above."""
+    k = [n for n in params if n.endswith("attention_c.weight")][0]
+    params[k] = params[k] * np.float32(target_bound / float(np.abs(params[k].astype(np.float64)).sum(axis=1).max()))
+    return params

@@ -31,7 +31,10 @@
 extern "C" {
 #endif
 
-#define HIPT_ABI_VERSION 4
+/* 5 (round 6): the HIPT_PACK_MLP image of format 3 is 2*D*hidden*2 + D*D*2 bytes (six proj units in front: ask
+ * hipt_vit_packed_bytes, never compute the size) and packing it reads blocks[i].proj_w, which must be set first;
+ * hipt_vit_mlp_unit added; formats 1 / HIPT_MLP32 are gone. */
+#define HIPT_ABI_VERSION 5
 
 enum { HIPT_F32 = 0, HIPT_BF16 = 1 };
 
@@ -206,6 +209,16 @@ int hipt_vit_blocks(const hipt_vit_weights* w, float* x, int nseq, int blk_begin
  * workspace >= hipt_vit_workspace_bytes(w, nseq); out_img must not alias xn_img. */
 int hipt_vit_attention_unit(const hipt_vit_weights* w, int block, const void* xn_img, int nseq, void* out_img, int fused,
                             void* workspace, size_t ws_bytes, void* stream);
+
+/* The other half of a LayerNorm-chained ViT-256 block as the streaming path runs it, for per-kernel benches and parity tests:
+ * x <- x + proj(att) + b_proj;  x <- x + fc2(GELU(fc1(LayerNorm-2(x))))  (Block.forward, vision_transformer.py:146-152 with Mlp.forward
+ * :98-104) in ONE launch of the fused proj + MLP kernel.  x_img: the fp32 residual stream [nseq * 257, 384] as an activation image,
+ * updated in place; att_img: the attention output (before proj) as a bf16 activation image (hipt_vit_attention_unit's out_img);
+ * xn_out_img: NULL, or where LayerNorm-1 of block + 1 (of `block` itself for the last one) of the updated rows goes as a bf16 image
+ * (may alias att_img: a workgroup loads all attention rows of its tile before it writes them).  Needs blocks[block].mlp_pk in format 3
+ * (bf16, D = 384, hidden % 128 == 0), nseq * 257 a multiple of 16; workspace >= 256 bytes (the kernel's tile queue). */
+int hipt_vit_mlp_unit(const hipt_vit_weights* w, int block, float* x_img, const void* att_img, int nseq, void* xn_out_img,
+                      void* workspace, size_t ws_bytes, void* stream);
 
 /* [CLS] row of the last block's attention map: probs_cls[nseq, heads, ntok] fp32 =
  * get_last_selfattention(x)[:, :, 0, :] (vision_transformer.py:255-262 as consumed by the heat-maps,

@@ -79,3 +79,32 @@ def test_gather_carries_ids_and_lengths_as_integers():
     all_logits, all_a = D.gather_slide_outputs([1, 0], [torch.tensor([1.0, 2.0]), torch.tensor([3.0, 4.0])], [a, torch.arange(3.0)], 2)
     assert all_a[1].numel() == n and float(all_a[1][-1]) == 7.0 and all_a[0].tolist() == [0.0, 1.0, 2.0]
     assert all_logits.tolist() == [[3.0, 4.0], [1.0, 2.0]]
+
+
+def _one_rank_worker(port, opt_in, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("HIPT_SINGLE_RANK_GROUP", None)
+    from hipt_abmil_atec23_amd import distributed as D
+    r, w, _ = D.init_from_env(backend="gloo", single_rank_group=True if opt_in == "arg" else None) if opt_in != "env" else (None, None, None)
+    if opt_in == "env":
+        os.environ["HIPT_SINGLE_RANK_GROUP"] = "1"
+        r, w, _ = D.init_from_env(backend="gloo")
+    q.put((r, w, D.grouped(), D.group_info()))
+    if D.grouped():
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("opt_in,grouped", [("no", False), ("arg", True), ("env", True)])
+def test_one_rank_group_is_opt_in(opt_in, grouped):
+    """a launcher-style environment with WORLD_SIZE=1 must NOT make a library user a process group (and a TCP rendezvous) unless
+    asked: init_from_env(single_rank_group=True) -- what bench.py passes -- or HIPT_SINGLE_RANK_GROUP=1."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), opt_in, q))
+    p.start()
+    r, w, g, info = q.get(timeout=90)
+    p.join(timeout=30)
+    assert p.exitcode == 0 and (r, w) == (0, 1) and g == grouped
+    assert info == ({"backend": "gloo", "ranks": 1} if grouped else {})

@@ -257,3 +257,49 @@ def test_host_mirror_cpu_training_path_gradients(name, size, base, shape, seed, 
     assert maxdiff(a_raw.detach().numpy(), g["A_raw"]) < 1e-5
     for key, p in m.named_parameters():
         assert maxdiff((p.grad if p.grad is not None else torch.zeros_like(p)).numpy(), g["grad." + key]) < 1e-5, key
+
+
+# ---- the OUTLIER weight family (round 6): LayerNorm gains 0.05 ... 20, residual channels of magnitude 100, logits up to +-120 ----
+def test_outlier_weights_numpy_equals_torch():
+    a = synth.make_vit_outlier_params_np(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096, 6)
+    b = synth.make_vit_outlier_state_dict(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096, 6)
+    assert all(np.array_equal(a[k], b[k].numpy()) for k in a)
+    assert np.abs(a["phi.0.bias"]).max() == 100.0 and a["blocks.2.norm1.weight"].max() <= 20.0
+
+
+def test_vit256_outlier_family():
+    g = golden("vit256_outlier")
+    p = synth.make_vit_outlier_params_np(synth.vit_param_specs("vit256"), 256, 6)
+    x = synth.hash_uniform_np((2, 3, 256, 256), 2)
+    tok = O.vit256_prepare_tokens(x, p)
+    scale = float(np.abs(g["blk11_rows"]).max())  # the residual stream carries |x| ~ 100: fp32 round-off scales with it
+    assert 90 < scale < 120 and g["logit_absmax_per_block"].max() > 100  # the fixture IS a stress case
+    assert maxdiff(tok[:, ROWS], g["tokens_rows"]) < TOL * scale
+    t = tok
+    for i in range(12):
+        t = O.block(t, p, i, 6)
+        if i in (0, 5, 11):
+            assert maxdiff(t[:, ROWS], g[f"blk{i}_rows"]) < TOL * scale, i
+    out = O.layer_norm(t, p["norm.weight"], p["norm.bias"])[:, 0]
+    assert maxdiff(out, g["out"]) < TOL * float(np.abs(g["out"]).max())
+    assert maxdiff(O.vit_last_selfattention(tok, p, 6)[:, :, 0], g["attn_cls"]) < TOL
+
+
+def test_hipt4k_outlier_family():
+    g = golden("hipt4k_outlier_1024")
+    p256 = synth.make_vit_outlier_params_np(synth.vit_param_specs("vit256"), 256, 6)
+    p4k = synth.make_vit_outlier_params_np(synth.vit_param_specs("vit4k", embed_dim=192, depth=6), 4096, 6)
+    x = synth.hash_uniform_np((1, 3, 1024, 768), 3)
+    out, f = O.hipt4k_forward(x, p256, p4k, return_cls256=True)
+    assert maxdiff(f, g["cls256"]) < TOL * float(np.abs(g["cls256"]).max())
+    assert maxdiff(out, g["out"]) < TOL * float(np.abs(g["out"]).max())
+
+
+@pytest.mark.parametrize("tag,bound", [("lo", 50.0), ("hi", 70.0)])
+def test_clam_outlier_bounds(tag, bound):
+    g = golden("clam_outlier_n2000")
+    p = synth.scale_clam_attention_c_np(synth.make_params_np(synth.clam_param_specs((384, 128, 64)), 384), bound)
+    assert abs(float(g[f"{tag}_bound"]) - bound) < 1e-3
+    r = O.clam_sb_forward(synth.hash_uniform_np((2000, 384), 1), p)
+    assert maxdiff(r["A_raw"], g[f"{tag}_A_raw"]) < TOL and maxdiff(r["M"], g[f"{tag}_M"]) < TOL
+    assert maxdiff(r["logits"], g[f"{tag}_logits"]) < TOL and np.array_equal(np.asarray(r["Y_hat"]).ravel(), g[f"{tag}_Y_hat"].ravel())

@@ -257,7 +257,7 @@ def _nccl_one_rank_worker(port, q):
     os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from hipt_abmil_atec23_amd import distributed as D
     from hipt_abmil_atec23_amd import pipeline as PL
-    r, w, local = D.init_from_env()
+    r, w, local = D.init_from_env(single_rank_group=True)
     info = D.group_info()
     calls = {"all_reduce": 0, "all_gather": 0}
     real_ar, real_ag = torch.distributed.all_reduce, torch.distributed.all_gather_into_tensor
