@@ -225,7 +225,15 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             // q | k | v never reach HBM.  The [CLS] rows (257 = 8 x 32 + 1) get their q | k | v from a side GEMM over nseq rows.
             const bool fuse = have_xn && img && b.qkv_att_pk && hipt_qkv_attn_supported(dt, D, w->heads, w->ntok) && !last_probs &&
                               !hipt_env_on("HIPT_NO_FUSED_ATTN");
-            const void* att_out = s.att;
+            // image format 3 (round 5): the output projection runs at the head of the fused MLP's tiles (mlp16.hip, FOLD) -- no proj launch, no y1
+            const bool fold = chain && b.mlp_pk_fmt == 3 && !hipt_env_on("HIPT_NO_PROJ_FOLD") && !last_probs;
+            // Where the attention output goes.  Fused kernel: the (unused) qkv slot.  Two kernels: s.att -- except under the fold, where the
+            // MLP kernel reads the attention rows as y1 AND writes the next block's LayerNorm-1 rows to s.att in the same launch: the y1 slot
+            // s.xn is free then (no proj launch writes it), so the two never share a buffer.  (The kernel itself would tolerate the alias -- a
+            // workgroup loads all attention rows of its tile before it stores any, tiles own disjoint rows: mlp16.hip, "in place" -- but
+            // nothing in a launch sequence should rest on that.)
+            void* att_two = fold ? s.xn : s.att;
+            const void* att_out = att_two;
             if (fuse) {
                 char* qa = (char*)s.hid + 4096 + al256((size_t)nseq * D * 4);   // (the hidden slot is free on this path; its head holds tile queues)
                 char* qcls = qa + al256((size_t)nseq * D * 2);                   // [nseq, 3 D] bf16 + 1 KiB the kernel's row DMA may read past the end
@@ -244,10 +252,8 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             }
             q.img = 0;
             // (with activation images the attention output is one too: proj then reads its operands 1 KiB at a time)
-            if (!fuse) PROF(cATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st, img ? 1 : 0, hm ? 1 : 0));
+            if (!fuse) PROF(cATTN, hipt_attention_launch(s.qkv, att_two, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st, img ? 1 : 0, hm ? 1 : 0));
             if (last_probs) break;
-            // image format 3 (round 5): the output projection runs at the head of the fused MLP's tiles (mlp16.hip, FOLD) -- no proj launch, no y1
-            const bool fold = chain && b.mlp_pk_fmt == 3 && !hipt_env_on("HIPT_NO_PROJ_FOLD");
             if (!fold) {
                 q.A = att_out; q.ln_w = q.ln_b = nullptr; q.W = b.proj_w; q.wpk = b.proj_pk; q.N = D; q.bias = b.proj_b; q.out = s.xn; q.ldc = D;
                 q.counter = (int*)s.hid + 32;

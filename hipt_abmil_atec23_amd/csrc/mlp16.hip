@@ -120,6 +120,11 @@ __global__ void mlp16_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* _
 // images; XIN: x is read as an image.  Row-major otherwise.  Weights always come from the packed image p.wpk (format 1).
 // DBG (tools/mlp_probe.hip only): 1 = no weight DMA / ring syncs, 2 = GELU replaced by a plain pack, 4 = no MFMAs, 8 = no LDS
 // fragment reads.
+// IN PLACE: p.xn_out may be the buffer p.y1 points to (hipt_vit_mlp_unit documents it for callers; run_blocks itself never aliases them since
+// round 6).  What makes that safe, and what any change to this kernel must keep: a workgroup loads ALL rows of its tile (x and y1 / the
+// attention rows) in the row phase, before the first store of its epilogue; tiles own disjoint rows; nothing is prefetched from another tile's
+// y1 rows (the L2 touches of DBG 64 only read).  A next-tile prefetch of y1 into registers, or an epilogue that stores before the row phase
+// has consumed its loads, would need distinct buffers.
 // FOLD (round 5; image format 3): the attention block's output projection runs at the head of the tile -- p.y1 is then the ATTENTION OUTPUT (before
 // proj; row-major or image like y1), six more ring units in front of the pass hold the proj matrix, the fc2 accumulators start from x + b_proj, take
 // att Wproj^T through six KB-shaped phases (the attention rows sit in X's registers: same shape), and v = x + proj(att) + b is what LayerNorm-2 reads

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of whole library builds through bench.py itself (the probe's back-to-back launches sit in a power transient that the
-# pipeline does not): tools/bench_ab.sh <rounds> <lib suffix> ... ("-" = the shipped library; NAME=VALUE = the shipped library under that environment switch, e.g. HIPT_MLP32=1), interleaved; prints regions/s and the
+# pipeline does not): tools/bench_ab.sh <rounds> <lib suffix> ... ("-" = the shipped library; NAME=VALUE = the shipped library under that environment switch, e.g. HIPT_NO_PROJ_FOLD=1), interleaved; prints regions/s and the
 # per-launch time of the fused MLP / fused attention kernels.
 R=$1; shift
 for r in $(seq 1 $R); do
