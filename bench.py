@@ -152,6 +152,7 @@ def measure_sustained(dev, sampler=None, seconds=1.5):
         return None
     pp = C.CDLL(so)
     pp.pp_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    pp.pp_flop_per_iter.restype, pp.pp_flop_per_iter.argtypes = C.c_double, [C.c_int]
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count
     outb = torch.zeros(2 * 4 * ncu, dtype=torch.int64, device=dev)
     iters = 200000  # 25.6 M matrix-pipe cycles per launch: ~12 ms
@@ -173,7 +174,7 @@ def measure_sustained(dev, sampler=None, seconds=1.5):
             torch.cuda.current_stream(dev).synchronize()
         b.record()
         torch.cuda.synchronize()
-        tf = ncu * 4 * iters * 131072.0 * n / (a.elapsed_time(b) * 1e-3) / 1e12
+        tf = ncu * 4 * iters * pp.pp_flop_per_iter(shape) * n / (a.elapsed_time(b) * 1e-3) / 1e12
         h = outb.cpu().numpy().reshape(-1, 2).astype("float64")
         res[name] = {"tflops": tf, "in_kernel_ghz": float((h[:, 0] / h[:, 1]).mean() * 0.1)}
         if sampler:
@@ -742,6 +743,35 @@ def main():
             model.streams = args.streams
             reg8 = ((region * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
             ex["uint8_input_regions_per_s"] = R / timed(lambda: model(reg8), 5)
+            # ---- the loop WITH its H2D hop (extract_features_fp.py:162-166): one-region loader batches in PINNED HOST memory through
+            # feature_store.extract_slide (8 per call, copy stream + double-buffered gather buffers + features read back one call late), beside the
+            # same loop over resident batches.  uint8 RGB tiles: 50 MB per region over the link; fp32: 201 MB (the link alone caps that at ~300 / s)
+            try:
+                import tempfile
+                from hipt_abmil_atec23_amd.feature_store import extract_slide
+                h2d = {}
+                for kind, src, reps in (("uint8", reg8[:8], 4), ("fp32", region[:8], 2)):
+                    res_loader = [(src[i:i + 1], torch.tensor([[4096 * i, 0]])) for i in range(8)] * reps
+                    pinned = [src[i:i + 1].cpu().pin_memory() for i in range(8)]
+                    host_loader = [(pinned[i], torch.tensor([[4096 * i, 0]])) for i in range(8)] * reps
+                    with tempfile.TemporaryDirectory() as td:
+                        for name, ld in (("resident", res_loader), ("host", host_loader)):
+                            extract_slide(model, ld[:8], td, "warm")
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                            extract_slide(model, ld, td, "timed")
+                            torch.cuda.synchronize()
+                            h2d[f"{kind}_{name}"] = len(ld) / (time.perf_counter() - t0)
+                    del pinned, host_loader, res_loader
+                ex["h2d_uint8_regions_per_s"] = h2d["uint8_host"]
+                ex["h2d_fp32_regions_per_s"] = h2d["fp32_host"]
+                ex["h2d_loop_resident_uint8_regions_per_s"] = h2d["uint8_resident"]
+                ex["h2d_loop_resident_fp32_regions_per_s"] = h2d["fp32_resident"]
+                ex["h2d_uint8_over_resident"] = h2d["uint8_host"] / h2d["uint8_resident"]
+                ex["h2d_note"] = ("extract_slide over one-region loader batches, 8 gathered per call, incl. the .pt / coords write: `host` = batches in pinned host "
+                                  "memory (copy stream, two gather buffers), `resident` = the same loop over batches already in HBM")
+            except Exception as e:
+                ex["h2d_error"] = repr(e)[:300]
             del reg8
             model.streams = 1
         # What an event pair adds to ONE launch (why `abmil_fwd_ms` / roofline_abmil.avg_launch_us read ~4 us above the graph-replayed pace of

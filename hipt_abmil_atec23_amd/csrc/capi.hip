@@ -109,7 +109,7 @@ BlockScratch carve_blocks(Carver& c, const hipt_vit_weights* w, int nseq) {
 
 int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, void* out,
            int64_t ldc, int M, int N, int K, int dtype, int flags, hipStream_t st, int rpt = 0, const float* ln_w = nullptr,
-           const float* ln_b = nullptr, float ln_eps = 0.f, int a_row_step = 0) {
+           const float* ln_b = nullptr, float ln_eps = 0.f, int a_row_step = 0, int small_any = 0) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A;
@@ -128,6 +128,7 @@ int linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* 
     p.ln_b = ln_b;
     p.ln_eps = ln_eps;
     p.a_row_step = a_row_step;  // (> 0: A is a bf16 activation image and row r is its row r * a_row_step)
+    p.small_any = small_any;
     return hipt_gemm_launch(p, dtype, ALOAD_PLAIN, flags, st);
 }
 
@@ -177,7 +178,8 @@ static bool blocks_images(const hipt_vit_weights* w, int nseq, int b0, int b1) {
 // xn_ready (round 5): the caller's embedding already left x as the fp32 activation image and LayerNorm-1 of block b0 as the bf16 image s.att
 // (embed32.hip, LNOUT): block b0 then runs like every later block.  Only with img_ok and blocks_images(..) true (checked).
 int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, float* probs, const BlockScratch& s,
-               hipStream_t st, bool emit_last = false, bool* have_xn_out = nullptr, bool img_ok = false, bool* x_img_out = nullptr, bool xn_ready = false) {
+               hipStream_t st, bool emit_last = false, bool* have_xn_out = nullptr, bool img_ok = false, bool* x_img_out = nullptr, bool xn_ready = false,
+               bool force_small = false) {
     const int D = w->dim, M = nseq * w->ntok, dt = w->dtype, dh = D / w->heads;
     const float scale = attn_scale(w);
     int rc;
@@ -185,7 +187,9 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     // A-stationary kernels would put it on two 192-row tiles, the fused MLP on seventeen 16-row tiles that each stream the whole weight
     // image (55 us a block).  Such calls take the per-operator path below, whose Linears run on the small-M GEMM (gemm.hip: a wave per
     // 16 x 32 output tile, 51-204 workgroups): seven launches of a few microseconds per block.
-    const bool small = small_call(w, nseq);
+    // force_small (hipt_vit4k_forward): the small-call kernels for ANY number of rows -- one launch per operator for all the regions of a call
+    const bool small = small_call(w, nseq) || force_small;
+    const int sa = force_small ? 1 : 0;
     const bool seq = hipt_seqgemm_supported(dt, D) && hipt_mlp_supported(dt, D, w->hidden) && !small;
     // timing categories: the kernels of the small second-level ViT (D = 192, a few hundred rows) are booked together,
     // so that the per-kernel categories hold only the ViT-256 launches the roofline is computed on
@@ -194,9 +198,9 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
     // pipelined path: the MLP of block i applies LayerNorm-1 of block i+1 to the rows it finishes and leaves them in
     // s.att as bf16 operands; block i+1's QKV GEMM then skips the fp32 row load + LayerNorm
     // (only the streaming kernels have that epilogue / prologue: every block of the range needs its packed weight images)
-    const bool chain = blocks_chain(w, nseq, b0, b1);
+    const bool chain = !force_small && blocks_chain(w, nseq, b0, b1);
     // activation images: chained streaming blocks, whole 16-row fragments, no probability output
-    const bool img = img_ok && probs == nullptr && blocks_images(w, nseq, b0, b1);
+    const bool img = !force_small && img_ok && probs == nullptr && blocks_images(w, nseq, b0, b1);
     HIPT_CHECK_ARG(!xn_ready || (img && b0 < b1), "run_blocks: image input without the image path");
     bool have_xn = xn_ready;
     // with them, q | k | v leave the QKV GEMM head-major (the attention kernel's K / V staging reads consecutive bytes)
@@ -285,26 +289,26 @@ int run_blocks(const hipt_vit_weights* w, float* x, int nseq, int b0, int b1, fl
             // (the kernel loads gamma / beta 16 bytes at a time: parameters that are views into a flat buffer off that grid keep the
             //  separate LayerNorm launch, which has no alignment requirement)
             const bool ln_al = (((uintptr_t)b.ln1_w | (uintptr_t)b.ln1_b | (uintptr_t)b.ln2_w | (uintptr_t)b.ln2_b) & 15) == 0;
-            const bool ln_in_gemm = small && ln_al && !hipt_generic_only() && hipt_gemm_ln_supported(M, D, ALOAD_PLAIN, 0);
+            const bool ln_in_gemm = small && ln_al && !hipt_generic_only() && hipt_gemm_ln_supported(M, D, ALOAD_PLAIN, 0, force_small);
             if (ln_in_gemm) {
-                PROF(PC_QKV, linear(x, D, b.qkv_w, D, b.qkv_b, nullptr, s.qkv, 3 * D, M, 3 * D, D, dt, 0, st, w->ntok, b.ln1_w, b.ln1_b, w->ln_eps));
+                PROF(PC_QKV, linear(x, D, b.qkv_w, D, b.qkv_b, nullptr, s.qkv, 3 * D, M, 3 * D, D, dt, 0, st, w->ntok, b.ln1_w, b.ln1_b, w->ln_eps, 0, sa));
             } else {
                 PROF(PC_LN, hipt_layernorm_launch(x, D, b.ln1_w, b.ln1_b, s.xn, dt, D, M, D, w->ln_eps, st));
-                PROF(PC_QKV, linear(s.xn, D, b.qkv_w, D, b.qkv_b, nullptr, s.qkv, 3 * D, M, 3 * D, D, dt, 0, st, w->ntok));
+                PROF(PC_QKV, linear(s.xn, D, b.qkv_w, D, b.qkv_b, nullptr, s.qkv, 3 * D, M, 3 * D, D, dt, 0, st, w->ntok, nullptr, nullptr, 0.f, 0, sa));
             }
             PROF(PC_ATTN, hipt_attention_launch(s.qkv, s.att, last_probs ? probs : nullptr, nseq, w->ntok, w->heads, dh, scale, dt, st));
             if (last_probs) break;  // Block.forward(return_attention=True) returns before the residual (:148-149)
-            PROF(PC_PROJ, linear(s.att, D, b.proj_w, D, b.proj_b, x, x, D, M, D, D, dt, HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st, w->ntok));
+            PROF(PC_PROJ, linear(s.att, D, b.proj_w, D, b.proj_b, x, x, D, M, D, D, dt, HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st, w->ntok, nullptr, nullptr, 0.f, 0, sa));
             if (ln_in_gemm) {
                 PROF(PC_FC1, linear(x, D, b.fc1_w, D, b.fc1_b, nullptr, s.hid, w->hidden, M, w->hidden, D, dt, HIPT_EPI_GELU, st, w->ntok, b.ln2_w, b.ln2_b,
-                                    w->ln_eps));
+                                    w->ln_eps, 0, sa));
             } else {
                 PROF(PC_LN, hipt_layernorm_launch(x, D, b.ln2_w, b.ln2_b, s.xn, dt, D, M, D, w->ln_eps, st));
-                PROF(PC_FC1, linear(s.xn, D, b.fc1_w, D, b.fc1_b, nullptr, s.hid, w->hidden, M, w->hidden, D, dt, HIPT_EPI_GELU, st, w->ntok));
+                PROF(PC_FC1, linear(s.xn, D, b.fc1_w, D, b.fc1_b, nullptr, s.hid, w->hidden, M, w->hidden, D, dt, HIPT_EPI_GELU, st, w->ntok, nullptr, nullptr, 0.f, 0, sa));
             }
         }
         PROF(PC_FC2, linear(s.hid, w->hidden, b.fc2_w, w->hidden, b.fc2_b, x, x, D, M, D, w->hidden, dt,
-                            HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st, w->ntok));
+                            HIPT_EPI_RESID | HIPT_EPI_OUT_F32, st, w->ntok, nullptr, nullptr, 0.f, 0, sa));
     }
     if (have_xn_out) *have_xn_out = have_xn;
     if (x_img_out) *x_img_out = x_img;
@@ -465,9 +469,10 @@ int embed256_f32(const hipt_vit_weights* w, const void* img, const hipt_image_la
     return HIPT_OK;
 }
 
-int embed4k(const hipt_vit_weights* w, const void* tokens, int nseq, float* x, hipStream_t st) {
+int embed4k(const hipt_vit_weights* w, const void* tokens, int nseq, float* x, hipStream_t st, int small_any = 0) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
+    p.small_any = small_any;
     p.A = tokens;
     p.lda = w->embed_k;
     p.W = w->embed_w;
@@ -969,19 +974,13 @@ int hipt_vit4k_forward(const hipt_vit_weights* w, const float* tokens_in, int ns
         if ((rc = hipt_f32_to_bf16_launch(tokens_in, tokT, n, st))) return rc;
         tok = tokT;
     }
-    // The regions of a call go through the blocks in groups that are small calls (run_blocks: at most 1 088 token rows, i.e. four
-    // 16 x 16 grids): which kernels a region's 257 rows meet then does not depend on how many regions share the call -- one region
-    // alone, eight gathered by extract_slide and a ragged tail of three write the same bits (the small-call kernels are row
-    // independent bit for bit) -- and eight regions take 2 x 30 launches of ~6 us instead of 24 latency-sized streaming launches.
-    // (a grid of more than 1 087 tokens is no small call for any count: one region per group, the same kernels every time)
-    const int group = w->ntok <= 1088 ? 1088 / w->ntok : 1;
-    const size_t tsz = esz(w->dtype);
-    for (int s0 = 0; s0 < nseq; s0 += group) {
-        const int g = nseq - s0 < group ? nseq - s0 : group;
-        float* xg = x + (size_t)s0 * w->ntok * w->dim;
-        if ((rc = embed4k(w, (const char*)tok + (size_t)s0 * (w->ntok - 1) * w->embed_k * tsz, g, xg, st))) return rc;
-        if ((rc = run_blocks(w, xg, g, 0, w->depth, nullptr, s, st))) return rc;
-    }
+    // ALL the regions of a call go through the small-call kernels together (round 6; `force_small`): one wave per 16 x 32 output tile, rows
+    // independent bit for bit, the attention one workgroup per (region, head) -- which kernels a region's 257 rows meet, and the bits they
+    // write, do not depend on how many regions share the call: one region alone, eight gathered by extract_slide and a ragged tail of three
+    // agree exactly (tests).  Thirty launches per call whatever its size (round 5 walked the regions in groups of four: 30 launches per
+    // group, linear in nseq); the phi GEMM takes the small kernel too, for the same reason.
+    if ((rc = embed4k(w, tok, nseq, x, st, 1))) return rc;
+    if ((rc = run_blocks(w, x, nseq, 0, w->depth, nullptr, s, st, false, nullptr, false, nullptr, false, true))) return rc;
     return hipt_layernorm_launch(x, (int64_t)w->ntok * w->dim, w->norm_w, w->norm_b, out, HIPT_F32, w->dim, nseq, w->dim, w->ln_eps, st);
 }
 

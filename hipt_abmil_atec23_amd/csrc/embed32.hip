@@ -110,7 +110,14 @@ __global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
     // a quarter of a channel in flight: pixel rows 4 j .. 4 j + 3.  fp32: two 16-byte pieces per row; uint8 planar: one 8-byte piece;
     // interleaved: the 24 bytes of the 8 pixels' three channels
     constexpr int RAWN = KIND == 0 ? 8 : (KIND == 1 ? 2 : 6);  // 16-byte registers
-    constexpr int NLD = KIND == 0 ? 8 : (KIND == 1 ? 4 : 12);  // load instructions per quarter (the counted wait of a phase)
+    // load INSTRUCTIONS per quarter = the counted wait of a phase (vmcnt(NLD): "my DMA pieces have landed, the NLD pixel loads behind them may still
+    // fly").  The count must be the compiler's, not the source's: written as three 8-byte loads per row, the interleaved form was merged by hipcc
+    // into one 16-byte + one 8-byte load -- 8 instructions where the wait said 12, so that the four youngest DMA pieces of the next ring unit could
+    // still be in flight behind the barrier: a race on the weight ring that only showed as run-to-run differences when two streams embedded
+    // uint8 regions at once (found in round 6 by the H2D loop's bit-equality test).  The loads are now written in the widths the hardware takes (16 + 8
+    // bytes: nothing left to merge; `volatile` is no way out -- hipcc turns such loads into FLAT loads, which retire out of order), and
+    // tools/audit_embed32_loads.py re-counts them in every build's listing: a mismatch fails the build.
+    constexpr int NLD = KIND == 0 ? 8 : (KIND == 1 ? 4 : 8);
     u32x4 raw[RAWN];
     auto load_quarter = [&](const pix_t* base, auto C_, auto J_) __attribute__((always_inline)) {
         constexpr int c = decltype(C_)::value, j = decltype(J_)::value;
@@ -130,16 +137,19 @@ __global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
                 raw[t >> 1][2 * (t & 1) + 1] = w[1];
             }
         } else {
+            // the 24 bytes of a row's 8 pixels x 3 channels: one 16-byte + one 8-byte load (8-byte aligned: row_stride % 8 == 0)
             const uint8_t* q = (const uint8_t*)base + (int64_t)(4 * j) * p.im.row_stride * 3;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t) {
+                const u32x4 a = *(const u32x4*)(q + (int64_t)t * p.im.row_stride * 3);
+                const u32x2 b = *(const u32x2*)(q + (int64_t)t * p.im.row_stride * 3 + 16);
+                const uint32_t dw[6] = {a[0], a[1], a[2], a[3], b[0], b[1]};
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const u32x2 w = *(const u32x2*)(q + (int64_t)t * p.im.row_stride * 3 + 8 * k);
-                    const int d = 6 * t + 2 * k;  // dword index of the quarter's 24 dwords
-                    raw[d >> 2][d & 3] = w[0];
-                    raw[(d + 1) >> 2][(d + 1) & 3] = w[1];
+                for (int k = 0; k < 6; ++k) {
+                    const int d = 6 * t + k;  // dword index of the quarter's 24 dwords
+                    raw[d >> 2][d & 3] = dw[k];
                 }
+            }
         }
     };
     auto cvt_quarter = [&](auto C_, auto J_) __attribute__((always_inline)) {

@@ -466,7 +466,7 @@ int launch(const GemmParams& p, hipStream_t st) {
                 return HIPT_OK;
             }
         }
-        if (p.M <= SMALL_M && p.K % (4 * Tr<T>::EPC) == 0) {
+        if ((p.M <= SMALL_M || p.small_any) && p.K % (4 * Tr<T>::EPC) == 0) {
             if (p.asc && p.K % (SMALL_RING * 4 * Tr<T>::EPC) == 0) {
                 if constexpr (FLAGS == 0) hipLaunchKernelGGL((gemm_small_kernel<T, 0, true, false, false, true>), sgrid, dim3(64), 0, st, p);
                 else hipLaunchKernelGGL((gemm_small_kernel<T, FLAGS, false>), sgrid, dim3(64), 0, st, p);  // (the guarded ring walks k in ascending order too)
@@ -521,8 +521,8 @@ bool hipt_gemm_arows_supported(int M, int K, int dtype, int aload, int flags) {
     return dtype == HIPT_BF16 && M <= SMALL_M && K == 384 && aload == ALOAD_PLAIN && flags == 0;
 }
 
-bool hipt_gemm_ln_supported(int M, int K, int aload, int flags) {
-    return M <= SMALL_M && (K == 384 || K == 192) && aload == ALOAD_PLAIN && (flags == 0 || flags == HIPT_EPI_GELU);
+bool hipt_gemm_ln_supported(int M, int K, int aload, int flags, bool any_m) {
+    return (M <= SMALL_M || any_m) && (K == 384 || K == 192) && aload == ALOAD_PLAIN && (flags == 0 || flags == HIPT_EPI_GELU);
 }
 
 int hipt_gemm_launch(const GemmParams& p_in, int dtype, int aload, int flags, hipStream_t st) {
@@ -548,7 +548,7 @@ int hipt_gemm_launch(const GemmParams& p_in, int dtype, int aload, int flags, hi
                        "gemm: rows gathered from an activation image take bf16, M <= %d, K = 384, plain loader and epilogue", SMALL_M);
     }
     if (p.ln_w)
-        HIPT_CHECK_ARG(hipt_gemm_ln_supported(p.M, p.K, aload, flags) && p.ln_b && (p.lda * 4) % 16 == 0 && ((uintptr_t)p.ln_w % 16) == 0 &&
+        HIPT_CHECK_ARG(hipt_gemm_ln_supported(p.M, p.K, aload, flags, p.small_any != 0) && p.ln_b && (p.lda * 4) % 16 == 0 && ((uintptr_t)p.ln_w % 16) == 0 &&
                            ((uintptr_t)p.ln_b % 16) == 0,
                        "gemm: the LayerNorm prologue takes M <= %d fp32 rows of K = 384 or 192, plain loader, no or GELU epilogue", SMALL_M);
     if (dtype == HIPT_F32) return dispatch<float>(p, aload, flags, st);

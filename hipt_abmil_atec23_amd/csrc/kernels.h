@@ -35,10 +35,13 @@ struct GemmParams {
     // small-M kernel only: k in ASCENDING 32-byte steps (no pairing, no staggered start) -- the k sets and the order of the tiled kernel's
     // MFMAs, so that an output element is the same bits whichever of the two kernels a call's row count selects (capi.hip: rows_linear)
     int asc;
+    // the small-M kernels whatever M is (round 6): the second-level ViT runs ALL the regions of a call through them in one launch per operator --
+    // they are row independent bit for bit, so a region's features do not depend on how many regions share the call (capi.hip: hipt_vit4k_forward)
+    int small_any;
 };
 bool hipt_gemm_arows_supported(int M, int K, int dtype, int aload, int flags);
 
-bool hipt_gemm_ln_supported(int M, int K, int aload, int flags);
+bool hipt_gemm_ln_supported(int M, int K, int aload, int flags, bool any_m = false);
 int hipt_gemm_launch(const GemmParams& p, int dtype, int aload, int flags, hipStream_t st);
 
 // Patch embedding of ViT-256 straight from the fp32 image (embed32.hip): x[seq, 1 + t, :] = Conv2d_k16_s16(pixels) + bias + pos[1 + t]

@@ -100,6 +100,85 @@ def load_coords(feat_dir: str, slide_id: str) -> np.ndarray:
     raise FileNotFoundError(f"no coordinates for slide {slide_id} under {feat_dir} (coords_files/ or h5_files/)")
 
 
+class _HostFeed:
+    """The H2D hop of the driver loop (extract_features_fp.py:162-166: ``batch = batch.to(device, non_blocking=True)`` from whatever memory
+    the loader hands over; HIPT_4K/hipt_4k.py:69).  Loader batches that live in HOST memory are copied into one of two device gather
+    buffers on a COPY stream while the previous gathered call computes: pinned sources (``DataLoader(pin_memory=True)``) straight from
+    where they lie, pageable ones through a pinned staging buffer of the same shape (one host memcpy, then the same asynchronous copy).
+    Events order the three parties: a gather buffer is refilled only after the call that read it has finished (``free``), a call starts only
+    after its copies have landed (``ready``), a staging buffer is rewritten only after its last copy out has completed.  No extra device
+    copy: the gather buffer IS the tensor the model call reads."""
+
+    SLOTS = 2
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.buf = [None] * self.SLOTS       # device gather buffers [cap, ...]
+        self.stage = [None] * self.SLOTS     # pinned staging twins (allocated only when a pageable batch arrives)
+        self.free = [None] * self.SLOTS      # event: the call that read buf[s] has finished
+        self.staged = [None] * self.SLOTS    # event: the last copy out of stage[s] has completed
+        self.slot = 0
+        self.fill = 0
+        self.read_stream = torch.cuda.Stream(device=device)  # features come back on their own stream, behind THEIR call only
+        self._hbuf = None
+
+    def read_back(self, feats: torch.Tensor, done: "torch.cuda.Event") -> torch.Tensor:
+        """features of a finished call as a host tensor, without waiting for anything enqueued after that call (a `.cpu()` on the compute
+        stream would wait for the NEXT call too, and the host could not feed the one after it meanwhile)"""
+        if self._hbuf is None or self._hbuf.shape[1:] != feats.shape[1:] or self._hbuf.shape[0] < feats.shape[0] or self._hbuf.dtype != feats.dtype:
+            self._hbuf = torch.empty((max(feats.shape[0], 8),) + tuple(feats.shape[1:]), dtype=feats.dtype, pin_memory=True)
+        self.read_stream.wait_event(done)
+        with torch.cuda.stream(self.read_stream):
+            self._hbuf[:feats.shape[0]].copy_(feats, non_blocking=True)
+        feats.record_stream(self.read_stream)
+        self.read_stream.synchronize()
+        return self._hbuf[:feats.shape[0]].clone()
+
+    def begin(self, cap: int, like: torch.Tensor):
+        """start gathering up to `cap` regions shaped like `like` ([r, ...]) into the current slot"""
+        s = self.slot
+        shape = (cap,) + tuple(like.shape[1:])
+        if self.buf[s] is None or self.buf[s].shape != shape or self.buf[s].dtype != like.dtype:
+            self.buf[s] = torch.empty(shape, dtype=like.dtype, device=self.device)
+            self.stage[s] = None
+        if self.free[s] is not None:
+            self.copy_stream.wait_event(self.free[s])  # the compute that read this buffer two calls ago
+        self.fill = 0
+
+    def add(self, r: torch.Tensor):
+        s, o, n = self.slot, self.fill, r.shape[0]
+        dst = self.buf[s][o:o + n]
+        src = r
+        if not r.is_pinned():
+            if self.stage[s] is None:
+                self.stage[s] = torch.empty(self.buf[s].shape, dtype=self.buf[s].dtype, pin_memory=True)
+            if self.staged[s] is not None and o == 0:
+                self.staged[s].synchronize()  # (long complete: its call has been launched and usually finished)
+            src = self.stage[s][o:o + n]
+            src.copy_(r)  # host memcpy: pageable -> pinned
+        with torch.cuda.stream(self.copy_stream):
+            dst.copy_(src, non_blocking=True)
+        self.fill = o + n
+
+    def finish(self):
+        """(the gathered regions as a device tensor the CURRENT stream may read, its slot); switches to the other slot"""
+        s = self.slot
+        ev = torch.cuda.Event()
+        ev.record(self.copy_stream)
+        self.staged[s] = ev
+        torch.cuda.current_stream(self.device).wait_event(ev)
+        out = self.buf[s][:self.fill]
+        self.slot = (s + 1) % self.SLOTS
+        return out, s
+
+    def release(self, s: int):
+        """the call that read slot s has been enqueued on the current stream"""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.free[s] = ev
+
+
 def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], feat_dir: str, slide_id: str, coalesce: int = 8) -> str:
     """The loop of ``compute_w_loader`` (extract_features_fp.py:159-171): ``batches`` yields ``(regions, coords)``;
     regions are whatever ``model`` takes — here ``[R, 3, W, H]`` float or raw ``uint8`` (planar or interleaved), R >= 1.
@@ -112,15 +191,50 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
     files are the ones the one-by-one loop writes -- bit for bit: only regions whose patch count is a multiple of 16 (4096 x 4096:
     256) are gathered, because both calls then take the same kernels (tested); other sizes go one loader batch per call.
     ``coalesce <= 1`` restores the one-by-one loop for everything.  Peak memory of a gathered call: the gathered batch plus one
-    loader batch."""
+    loader batch.
+
+    **Host batches** (round 6; the reference's loader yields CPU tensors and moves each to the device inside the loop,
+    extract_features_fp.py:162-166): when ``model`` is a ``HIPT_4K`` on a HIP device and a loader batch is not there, the batch
+    is copied host -> device on a copy stream into one of two gather buffers while the previous call computes (``_HostFeed``), and the
+    features of call k are read back only after call k + 1 has been enqueued -- the link, the GPU and the host loop overlap.  Same
+    gathered tensor, same kernels, same bits as with resident batches."""
     w = FeatureWriter(feat_dir, slide_id)
     held: list = []  # (regions, coords) waiting for company
+    m256 = getattr(model, "model256", None)  # HIPT_4K: where its first-level ViT's weights live NOW (.to() may have moved it since construction)
+    dev = getattr(m256, "weight_device", None) if m256 is not None else None
+    dev = torch.device(dev) if dev is not None else None
+    feed = [None]        # _HostFeed, made when the first host batch for a HIP model arrives
+    pending: list = []   # [(features on the device, counts, coords)]: read back one call late
+
+    def append_call(feats, counts, coords, done=None):
+        if done is not None:
+            feats = feed[0].read_back(feats, done)
+        o = 0
+        for n, c in zip(counts, coords):  # one append per loader batch, as the reference's loop does
+            w.append(feats[o:o + n], c)
+            o += n
+
+    def drain():
+        while pending:
+            append_call(*pending.pop(0))
 
     def flush():
         if not held:
             return
         counts, coords = [r.shape[0] for r, _ in held], [c for _, c in held]
-        if len(held) == 1:
+        on_host = dev is not None and dev.type == "cuda" and held[0][0].device.type == "cpu"
+        slot = None
+        if on_host:
+            if feed[0] is None:
+                feed[0] = _HostFeed(dev)
+            f = feed[0]
+            # (capacity: `coalesce` regions where batches are gathered, so that a ragged tail re-uses the buffer; else this batch)
+            f.begin(max(sum(counts), coalesce) if gathers_bit_exactly(held[0][0]) else sum(counts), held[0][0])
+            for i in range(len(held)):
+                f.add(held[i][0])
+                held[i] = None
+            regions, slot = f.finish()
+        elif len(held) == 1:
             regions = held[0][0]
         else:
             # gathered in ONE buffer, each loader batch released as soon as it is copied: the peak is the gathered batch plus one
@@ -135,11 +249,18 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
                 del r
         held.clear()
         feats = model(regions)
+        if slot is not None:
+            feed[0].release(slot)
         del regions
-        o = 0
-        for n, c in zip(counts, coords):  # one append per loader batch, as the reference's loop does
-            w.append(feats[o:o + n], c)
-            o += n
+        if on_host:
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+            pending.append((feats, counts, coords, done))  # read back after the NEXT call is enqueued: the GPU never waits for the host
+            while len(pending) > 1:
+                append_call(*pending.pop(0))
+        else:
+            drain()
+            append_call(feats, counts, coords)
 
     def gathers_bit_exactly(regions) -> bool:
         # whole 16-row fragments in every call (patch count a multiple of 16): the gathered call and the one-by-one call take the
@@ -157,6 +278,7 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
             if coalesce <= 1 or not gathers_bit_exactly(regions) or sum(r.shape[0] for r, _ in held) >= coalesce:
                 flush()
         flush()
+        drain()
     return w.close()
 
 

@@ -1320,3 +1320,30 @@ def test_clam_outlier_bounds_both_sides_of_the_fixed_shift(tag, bound):
     assert md(a_raw, g[f"{tag}_A_raw"]) < 1e-2 * max(span, 4.0)   # bf16 operands: the benign family's 4e-2 at |A_raw| ~ 6, scaled with the logits
     assert rel_l2(res["features"], g[f"{tag}_M"]) < 2e-2 and md(logits, g[f"{tag}_logits"]) < 2e-2
     assert np.array_equal(y_hat.cpu().numpy(), g[f"{tag}_Y_hat"])
+
+
+def test_extract_slide_host_batches_pipelined_same_bits(hipt, tmp_path):
+    """The loop WITH its H2D hop (extract_features_fp.py:162-166; feature_store._HostFeed): loader batches in host memory -- pinned (a
+    DataLoader with pin_memory) and pageable, uint8 interleaved and fp32 -- are copied on a copy stream into double-buffered gather buffers
+    while the previous call computes, features read back one call late.  The files are the resident loop's, bit for bit (ragged tail, more
+    calls than buffers, coords aligned)."""
+    from hipt_abmil_atec23_amd.feature_store import extract_slide, load_coords
+    hipt.set_compute_dtype("bf16")
+    try:
+        n = 11  # coalesce 4: calls of 4, 4, 3 -> both gather buffers re-used
+        f32 = [synth.hash_uniform_torch((1, 3, 1024, 1024), 300 + i, device=DEV) for i in range(n)]
+        u8 = [((r * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous() for r in f32]
+        coords = [torch.tensor([[1024 * i, 7 * i]], dtype=torch.int64) for i in range(n)]
+        for kind, regs in (("f32", f32), ("u8", u8)):
+            ref = torch.load(extract_slide(hipt, list(zip(regs, coords)), str(tmp_path), f"res_{kind}", coalesce=4))
+            for mem in ("pinned", "pageable"):
+                host = [r.cpu().pin_memory() if mem == "pinned" else r.cpu() for r in regs]
+                before = N.calls
+                got = torch.load(extract_slide(hipt, list(zip(host, coords)), str(tmp_path), f"{mem}_{kind}", coalesce=4))
+                assert N.calls > before
+                assert torch.equal(got, ref), (kind, mem)
+                assert np.array_equal(load_coords(str(tmp_path), f"{mem}_{kind}"), torch.cat(coords).numpy())
+            one = torch.load(extract_slide(hipt, list(zip([r.cpu() for r in regs], coords)), str(tmp_path), f"one_{kind}", coalesce=1))
+            assert torch.equal(one, ref), kind
+    finally:
+        hipt.set_compute_dtype("fp32")

@@ -95,6 +95,7 @@ def main():
             subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(ROOT, "tools", "power_probe.hip"), "-o", so])
         pp = C.CDLL(so)
         pp.pp_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        pp.pp_flop_per_iter.restype, pp.pp_flop_per_iter.argtypes = C.c_double, [C.c_int]
         ncu = torch.cuda.get_device_properties(0).multi_processor_count
         outb = torch.zeros(2 * 4 * ncu, dtype=torch.int64, device=dev)
         iters = 400000  # 51 M matrix-pipe cycles per launch: ~25 ms
@@ -106,9 +107,9 @@ def main():
                 h = outb.cpu().numpy().reshape(-1, 2).astype(np.float64)
                 ghz = h[:, 0] / h[:, 1] * 0.1
                 return {"in_kernel_ghz_median": float(np.median(ghz)), "in_kernel_ghz_min": float(ghz.min()), "in_kernel_ghz_max": float(ghz.max()),
-                        "cycles_per_128_pipe_cycles": float(np.median(h[:, 0]) / iters)}
+                        "cycles_per_iteration": float(np.median(h[:, 0]) / iters), "pipe_cycles_per_iteration": 128 if shape == 32 else 256}
             hold(f"mfma_{shape}x{shape}x{512 // shape}_bare", lambda: pp.pp_launch(shape, ncu, iters, outb.data_ptr(), torch.cuda.current_stream().cuda_stream),
-                 flop_per_call=ncu * 4 * iters * 131072.0, extra=clock)
+                 flop_per_call=ncu * 4 * iters * pp.pp_flop_per_iter(shape), extra=clock)
 
     # ---- the two dominant kernels alone, 2 048 patches per launch ----
     if "mlp16" in legs or "qkv_attn" in legs:

@@ -2,8 +2,9 @@
 // same process samples the board's hwmon node, so that the power and the clock a loop holds are MEASURED beside each other.
 //   hipcc -O3 --offload-arch=gfx950 -shared -fPIC tools/power_probe.hip -o tools/probe_bin/libpower_probe.so
 // One workgroup of 256 threads per CU (one wave per SIMD), operands in registers (random bf16 in [1, 2) with random signs), eight
-// independent 16x16 accumulators or two 32x32 ones; per iteration 4 x 32x32x16 (32 cycles each) or 8 x 16x16x32 (16 cycles each) = 128 matrix-pipe cycles = 131 072 FLOP
-// per SIMD.  out[2 * wave_global + {0, 1}] = (shader cycles, 100 MHz ticks) around the loop: the in-kernel clock (MI355X_MICROARCH.md,
+// independent 16x16 accumulators or two 32x32 ones; per iteration 4 x 32x32x16 (32 cycles each: 128 matrix-pipe cycles, 131 072 FLOP per SIMD) or
+// 16 x 16x16x32 on sixteen accumulators (16 cycles each: 256 cycles, 262 144 FLOP; with eight accumulators the loop ran at 78 % of the pipe: a
+// dependent 16x16x32 needs more than eight issue slots of distance) -- pp_flop_per_iter() tells the caller.  out[2 * wave_global + {0, 1}] = (shader cycles, 100 MHz ticks) around the loop: the in-kernel clock (MI355X_MICROARCH.md,
 // DVFS give-back item 6).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,7 +20,7 @@ __global__ __launch_bounds__(256, 1) void pp_kernel(int iters, unsigned long lon
     for (int i = 0; i < 4; ++i) b[i] = (((uint32_t)((threadIdx.x + 256 * blockIdx.x) * 2246822519u + i * 3266489917u)) & 0x807f807fu) | 0x3c003c00u;
     for (int i = 0; i < 4; ++i) w[i] = b ^ (uint32_t)(i * 0x00010001u);
     f32x16 a0 = {}, a1 = {};
-    f32x4 c[8] = {};
+    f32x4 c[16] = {};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
         // (a scheduling barrier after every MFMA, as tools/mfma_shape_probe.hip: left alone, hipcc re-orders the 16x16x32 MFMAs into
@@ -33,8 +34,8 @@ __global__ __launch_bounds__(256, 1) void pp_kernel(int iters, unsigned long lon
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[(j >> 1) & 3]), __builtin_bit_cast(bf16x8, b), c[j], 0, 0, 0);
+            for (int j = 0; j < 16; ++j) {
+                c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[(j >> 2) & 3]), __builtin_bit_cast(bf16x8, b), c[j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256, 1) void pp_kernel(int iters, unsigned long lon
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
     for (int e = 0; e < 16; ++e) s += a0[e] + a1[e];
-    for (int i = 0; i < 8; ++i) s += c[i][0] + c[i][1] + c[i][2] + c[i][3];
+    for (int i = 0; i < 16; ++i) s += c[i][0] + c[i][1] + c[i][2] + c[i][3];
     if (lane == 0) {
         out[2 * (blockIdx.x * 4 + wave)] = t1 - t0;
         out[2 * (blockIdx.x * 4 + wave) + 1] = r1 - r0;
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(256, 1) void pp_kernel(int iters, unsigned long lon
     if (s == 123.456f) out[0] = 0;
 }
 
-// shape: 16 or 32; out: device buffer of 2 * 4 * nblocks uint64 (or more).  Enqueues only.  FLOP of a launch = nblocks * 4 * iters * 131072.
+// shape: 16 or 32; out: device buffer of 2 * 4 * nblocks uint64 (or more).  Enqueues only.  FLOP of a launch = nblocks * 4 * iters * pp_flop_per_iter(shape).
+extern "C" double pp_flop_per_iter(int shape) { return shape == 32 ? 131072.0 : 262144.0; }
 extern "C" int pp_launch(int shape, int nblocks, int iters, void* out, void* stream) {
     if (shape == 32) hipLaunchKernelGGL(pp_kernel<32>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, iters, (unsigned long long*)out);
     else hipLaunchKernelGGL(pp_kernel<16>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, iters, (unsigned long long*)out);
