@@ -413,7 +413,7 @@ def main():
     # board power / shader clock over the timed steps: a thread of THIS process reading the card's hwmon node (tools/telemetry.py; sysfs only --
     # no GPU call, no child process), rank 0 only
     sampler = None
-    if not dry and rank == 0:
+    if not dry and rank == 0 and os.environ.get("HIPT_BENCH_NO_POWER", "0") in ("", "0"):
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from telemetry import PowerSampler, pci_bus_id_of
@@ -750,7 +750,7 @@ def main():
                 import tempfile
                 from hipt_abmil_atec23_amd.feature_store import extract_slide
                 h2d = {}
-                for kind, src, reps in (("uint8", reg8[:8], 4), ("fp32", region[:8], 2)):
+                for kind, src, reps in (("uint8", reg8[:8], 12), ("fp32", region[:8], 3)):  # (12 / 3 gathered calls: the first call's copy is the only one nothing hides)
                     res_loader = [(src[i:i + 1], torch.tensor([[4096 * i, 0]])) for i in range(8)] * reps
                     pinned = [src[i:i + 1].cpu().pin_memory() for i in range(8)]
                     host_loader = [(pinned[i], torch.tensor([[4096 * i, 0]])) for i in range(8)] * reps

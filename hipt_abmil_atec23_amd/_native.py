@@ -46,7 +46,7 @@ class ImageLayout(C.Structure):
 
 class ClamWeights(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("s0", C.c_int32), ("s1", C.c_int32), ("s2", C.c_int32),
-                ("n_classes", C.c_int32), ("reserved", C.c_int32),
+                ("n_classes", C.c_int32), ("n_att", C.c_int32),
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("wab", C.c_void_p), ("bab", C.c_void_p),
                 ("wc", C.c_void_p), ("bc", C.c_void_p), ("wcls", C.c_void_p), ("bcls", C.c_void_p),
                 ("logit_bound", C.c_float), ("reserved2", C.c_int32), ("stream_pk", C.c_void_p)]
@@ -107,6 +107,9 @@ SIGNATURES = {
     "hipt_clam_stream_pack": (_i, [_CW, _p, _p]),
     "hipt_clam_ticket_offset": (_sz, [_CW, _i]),
     "hipt_clam_sb_forward": (_i, [_CW, _p, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "hipt_clam_mb_supported": (_i, [_CW]),
+    "hipt_clam_mb_workspace_bytes": (_sz, [_CW, _i]),
+    "hipt_clam_mb_forward": (_i, [_CW, _p, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "hipt_attn_net_gated": (_i, [_CW, _p, _i, _p, _p, _sz, _p]),
     "hipt_clam_gather_h1": (_i, [_CW, _p, _p, _i, _p, _p]),
     "hipt_clam_train_workspace_bytes": (_sz, [_TW, _i]),

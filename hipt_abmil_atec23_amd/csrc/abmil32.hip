@@ -33,6 +33,7 @@
 //     classifier, softmax and argmax: one launch, deterministic bits.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -99,8 +100,9 @@ __device__ __forceinline__ void split3(float v, bf16_t (&o)[3]) {
 }
 
 // one thread per 16 bytes of the image
+// (nb attention branches -- CLAM_MB, wc = [nb][S2] -- fill nb x 256 B of the constant area, branch k at + 256 k)
 __global__ void abmil32_pack_kernel(const bf16_t* __restrict__ w1, const float* __restrict__ b1, const bf16_t* __restrict__ wab,
-                                    const float* __restrict__ bab, const float* __restrict__ wc, int KS, char* __restrict__ out) {
+                                    const float* __restrict__ bab, const float* __restrict__ wc, int KS, char* __restrict__ out, int nb) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int S0 = 16 * KS, nw1 = off_wab(KS) / 16, ng = 36 * 64, total = image_bytes(KS) / 16;
     if (c >= total) return;
@@ -129,8 +131,8 @@ __global__ void abmil32_pack_kernel(const bf16_t* __restrict__ w1, const float* 
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int f = f0 + e, tp = (f >> 5) & 1, hb = (f >> 4) & 1, i = f & 15;
-            if (f < 64) o[e] = wc[32 * tp + acc_col(i, hb)];
+            const int f = f0 + e, tp = (f >> 5) & 1, hb = (f >> 4) & 1, i = f & 15, br = f >> 6;
+            if (br < nb) o[e] = wc[br * S2 + 32 * tp + acc_col(i, hb)];
         }
         v = __builtin_bit_cast(u32x4, o);
     }
@@ -151,14 +153,24 @@ __device__ __forceinline__ u32x4 pack8(const f32x16& a) {
 // (MI355X_MICROARCH.md: 4 cycles a vector instruction, 8 a transcendental; 24 of an MFMA's 32 cycles are free) ----
 // Phase 1 carries the block before: 32 gate pairs x 12 micro-ops (tanh(x) sigmoid(y) w with ONE reciprocal:
 //   acc - (w - E w) / (E (1 + F) + (1 + F)), E = e^{2x}, F = e^{-y}, x clamped to +-15), then the logit, then 16 quarter tiles of pooling.
-constexpr int GU = 12, P1_FIN = 32 * GU, P1_POOL = P1_FIN + 1, P1_NU = P1_POOL + 16;
-constexpr int p1_cost(int u) {
-    if (u < P1_FIN) {
-        const int j = (u % (2 * GU)) / 2;  // (two pairs interleaved, below)
-        return (j == 5 || j == 6 || j == 10) ? 8 : 4;
+// NB > 1 (CLAM_MB, round 6): the gate value u = tanh(x) sigmoid(y) = (E - 1) / (E (1 + F) + (1 + F)) is formed ONCE per pair and feeds one
+//   multiply-add per branch (12 + NB micro-ops a pair); the logits of the NB branches follow; NO pooling here (the pooled sums of NB branches do
+//   not fit the registers: a second kernel pools from the bf16 h1 this one leaves in HBM).
+template <int NB> struct P1 {
+    static constexpr int GU = NB == 1 ? 12 : 12 + NB, FIN = 32 * GU, POOL = FIN + 1, NU = NB == 1 ? POOL + 16 : POOL;
+    static constexpr int cost(int u) {
+        if (u < FIN) {
+            const int j = (u % (2 * GU)) / 2;  // (two pairs interleaved, below)
+            return (j == 5 || j == 6 || j == 10) ? 8 : 4;
+        }
+        return u == FIN ? 56 + 44 * (NB - 1) : 16;
     }
-    return u == P1_FIN ? 56 : 16;
-}
+    static constexpr int total() {
+        int t = 0;
+        for (int u = 0; u < NU; ++u) t += cost(u);
+        return t;
+    }
+};
 // Phase 2 carries its own block's ReLU + bf16 packing: per hidden tile 8 elements, the operand of one k-step, 8 elements, the other operand
 constexpr int RU = 18, P2_NU = 4 * RU;
 constexpr int p2_cost(int u) { return (u % RU == 8 || u % RU == 17) ? 16 : 8; }
@@ -168,11 +180,6 @@ constexpr int dealt(F cost, int nu, int budget, int g) {
     int acc = 0, u = 0;
     while (u < nu && acc + cost(u) <= (g + 1) * budget) acc += cost(u++);
     return u;
-}
-constexpr int p1_total() {
-    int t = 0;
-    for (int u = 0; u < P1_NU; ++u) t += p1_cost(u);
-    return t;
 }
 
 // Phase 1's LDS queue, in order: per slot the fragment request for slot g + PFD, then (first half of a slice) one operation on the
@@ -214,13 +221,18 @@ struct Abmil32Params {
     float* logits;
     float* Y_prob;
     int64_t* Y_hat;
+    // NB > 1 (CLAM_MB): bc = [NB], A_raw = [NB][N]; h1 = ReLU(W1 x + b1) leaves as a bf16 image for the pooling kernel below:
+    // 32-row block b, piece kk (0..7) = 1 KiB at (8 b + kk) * 1024, lane (r, hh) 16 bytes: element j = hidden 16 kk + 8 (j >> 2) + 4 hh + (j & 3) of row 32 b + r
+    void* h1_img;
     unsigned long long* stamps;  // diagnostic builds: [grid][24] s_memrealtime ticks (100 MHz) of wave 0
     int no_traffic;              // diagnostic builds (HIPT_ABMIL_NO_TRAFFIC): every bag request out of range -- the arithmetic alone
 };
 
-template <int KS>  // k-steps of 16 input features: S0 = 16 KS
+template <int KS, int NB = 1>  // k-steps of 16 input features: S0 = 16 KS; NB attention branches (1: CLAM_SB, the whole forward; > 1: CLAM_MB's first pass)
 __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) {
     constexpr int S0 = 16 * KS;
+    constexpr int GU = P1<NB>::GU, P1_FIN = P1<NB>::FIN, P1_POOL = P1<NB>::POOL, P1_NU = P1<NB>::NU;
+    auto p1_cost = [](int u) constexpr { return P1<NB>::cost(u); };
     constexpr int OFF_WAB = off_wab(KS), OFF_CST = off_cst(KS), IMG_BYTES = image_bytes(KS);
     extern __shared__ __attribute__((aligned(16))) char smem[];  // W1 fragments | [Wa;Wb] fragments | b1, gate bias, wc in accumulator order
 
@@ -238,6 +250,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.bag, 0, (int)((int64_t)p.N * S0 * 2), 0x00020000);
     constexpr int OOR = 0x7fff0000;                                     // (beyond any bag the launcher accepts)
     const int vrow = (lane >> 3) * (S0 * 2) + (lane & 7) * 16;          // lane l: row l >> 3 of a group of 8, chunk l & 7 of a 128-byte line
+    const __amdgpu_buffer_rsrc_t h1rs = __builtin_amdgcn_make_buffer_rsrc(p.h1_img, 0, NB > 1 ? p.nblocks * 8192 : 0, 0x00020000);
 
     // ---- stage the weights: the image is the LDS content byte for byte, 1 KiB per LDS-DMA wave instruction ----
     {
@@ -269,21 +282,24 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     const uint32_t fa = lbase + lane * 16, fb = fa + 64 * 1024, fg = fa + OFF_WAB;
     // wc of this lane's 32 gate pairs, in pair order (tile pair tp, register i): kept in registers
     // (through asm reads: a visible LDS access makes hipcc wait for every load in flight, the first block's included)
-    float wcr[32];
-    {
-        const uint32_t a = lbase + OFF_CST + hh * 64;  // [tile pair][lane half][16]: pair tp at + 128 tp
+    float wcr[NB][32];
+    sfor<0, NB>([&](auto K_) __attribute__((always_inline)) {
+        constexpr int k = decltype(K_)::value;
+        const uint32_t a = lbase + OFF_CST + hh * 64;  // [branch][tile pair][lane half][16]: branch k at + 256 k, pair tp at + 128 tp
         f32x4 v[8];
-        DSR128X4_WAIT(v[0], v[1], v[2], v[3], a, 0, 16, 32, 48);
-        DSR128X4_WAIT(v[4], v[5], v[6], v[7], a, 128, 144, 160, 176);
+        DSR128X4_WAIT(v[0], v[1], v[2], v[3], a, 256 * k + 0, 256 * k + 16, 256 * k + 32, 256 * k + 48);
+        DSR128X4_WAIT(v[4], v[5], v[6], v[7], a, 256 * k + 128, 256 * k + 144, 256 * k + 160, 256 * k + 176);
 #pragma unroll
         for (int q4 = 0; q4 < 8; ++q4) {
-            wcr[4 * q4] = v[q4][0];
-            wcr[4 * q4 + 1] = v[q4][1];
-            wcr[4 * q4 + 2] = v[q4][2];
-            wcr[4 * q4 + 3] = v[q4][3];
+            wcr[k][4 * q4] = v[q4][0];
+            wcr[k][4 * q4 + 1] = v[q4][1];
+            wcr[k][4 * q4 + 2] = v[q4][2];
+            wcr[k][4 * q4 + 3] = v[q4][3];
         }
-    }
-    const float bcv = p.bc[0];
+    });
+    float bcv[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) bcv[k] = p.bc[k];
     // the other operand of the bias k-steps: 1, 1, 1, 0, .. in the k-slots of lane half 0
     const u32x4 ones = hh == 0 ? u32x4{0x3f803f80u, 0x00003f80u, 0u, 0u} : u32x4{0u, 0u, 0u, 0u};
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -296,14 +312,30 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     f32x16 Hp[4];        // h1 = ReLU(H) in fp32, kept for the pooling one block later
     u32x4 hf[8];         // h1 in bf16: the B operand of the gate product
     float gs = 0.f, prow = 0.f;
+    float gsk[NB];  // NB > 1: the logits of the branches, in the making
+#pragma unroll
+    for (int k = 0; k < NB; ++k) gsk[k] = 0.f;
 
     // ---- micro-ops (above) ----
     // two gate pairs in flight, their micro-ops alternating: one wave per SIMD, so a dependent chain of vector instructions has nobody
     // to hide its latencies behind (a transcendental's result is not ready for the next instruction) but the other pair
     float ga[2], gb[2], xs[2], ys[2], eE[2], eF[2], nn[2], t1[2], dn[2], rc[2];
     auto finish = [&](int blk) __attribute__((always_inline)) {
-        // the row's logit (the lane halves hold the two halves of its gate units), A_raw, softmax weight against the fixed shift
 #pragma clang fp contract(off)
+        if constexpr (NB > 1) {
+            const int row = blk * 32 + r;
+            const bool valid = row < p.N && blk >= 0;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const unsigned gbits = __builtin_bit_cast(unsigned, gsk[k]);
+                const auto sw = __builtin_amdgcn_permlane32_swap(gbits, gbits, false, false);
+                const unsigned s0 = sw[0], s1 = sw[1];
+                const float g2 = __builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1);
+                if (valid && hh == 0) p.A_raw[(int64_t)k * p.N + row] = g2 + bcv[k];
+            }
+            return;
+        }
+        // the row's logit (the lane halves hold the two halves of its gate units), A_raw, softmax weight against the fixed shift
         // v_permlane32_swap on two copies: one becomes (lower, lower), the other (upper, upper): the same sum, in the same order, in
         // both halves (the pooling of either half uses prow); no LDS crossbar in the MFMA stream
         const unsigned gbits = __builtin_bit_cast(unsigned, gs);
@@ -312,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
         const float g2 = __builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1);
         const int row = blk * 32 + r;
         const bool valid = row < p.N && blk >= 0;
-        if (valid && hh == 0) p.A_raw[row] = g2 + bcv;
+        if (valid && hh == 0) p.A_raw[row] = g2 + bcv[0];
         prow = valid ? __builtin_amdgcn_exp2f(g2 * LOG2E) : 0.f;  // e^(A - bc), in [e^-B, e^B]
         if (hh == 0) lsum += prow;
     };
@@ -333,14 +365,21 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
             if constexpr (j == 6) eF[c] = __builtin_amdgcn_exp2f(ys[c]);
             // (w - E w = -numerator: the negations sit on E and on the product as source modifiers; a "-w" would be a loop invariant that
             //  hipcc hoists into 32 more live registers)
-            if constexpr (j == 7) nn[c] = __builtin_fmaf(-eE[c], wcr[q], wcr[q]);
+            if constexpr (NB == 1) {
+                if constexpr (j == 7) nn[c] = __builtin_fmaf(-eE[c], wcr[0][q], wcr[0][q]);
+                if constexpr (j == 11) gs = __builtin_fmaf(-nn[c], rc[c], q == 0 ? 0.f : gs);  // (pair order: 0, 1, 2, ..)
+            } else {
+                // several branches: u = (E - 1) / (E (1 + F) + (1 + F)) once, then one multiply-add per branch (nn = E - 1, then nn = u)
+                if constexpr (j == 7) nn[c] = eE[c] - 1.0f;
+                if constexpr (j == 11) nn[c] = nn[c] * rc[c];
+                if constexpr (j >= 12) gsk[j - 12] = __builtin_fmaf(nn[c], wcr[j - 12 < NB ? j - 12 : 0][q], q == 0 ? 0.f : gsk[j - 12]);
+            }
             if constexpr (j == 8) t1[c] = eF[c] + 1.0f;
             if constexpr (j == 9) dn[c] = __builtin_fmaf(eE[c], t1[c], t1[c]);
             if constexpr (j == 10) rc[c] = __builtin_amdgcn_rcpf(dn[c]);
-            if constexpr (j == 11) gs = __builtin_fmaf(-nn[c], rc[c], q == 0 ? 0.f : gs);  // (pair order: 0, 1, 2, ..)
         } else if constexpr (u == P1_FIN) {
             finish(blk);
-        } else {
+        } else if constexpr (NB == 1) {
             constexpr int T = (u - P1_POOL) >> 2, q4 = (u - P1_POOL) & 3;  // a quarter of a tile: 4 registers
 #pragma unroll
             for (int i = 4 * q4; i < 4 * q4 + 4; ++i) pool[T][i] = __builtin_fmaf(prow, Hp[T][i], pool[T][i]);
@@ -408,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     auto phase1 = [&](auto PIPE_, int vnext, int vnext2, int blk_prev) __attribute__((always_inline)) {
         constexpr bool PIPE = decltype(PIPE_)::value;
         constexpr int NSL = 4 * (KS + 1);
-        constexpr int BUD = (p1_total() + NSL - 1) / NSL > 24 ? (p1_total() + NSL - 1) / NSL : 24;  // cycles of vector work per slot
+        constexpr int BUD = (P1<NB>::total() + NSL - 1) / NSL > 24 ? (P1<NB>::total() + NSL - 1) / NSL : 24;  // cycles of vector work per slot
         sfor<0, PFD>(rd1);
         sfor<0, NSL>([&](auto G_) __attribute__((always_inline)) {
             constexpr int g = decltype(G_)::value, k = (g >> 2) - 1, T = g & 3;
@@ -464,6 +503,12 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
         phase1(PIPE_, vnext, vnext2, blk - p.nwaves);
         if (s < 4) ASTAMP(3 + 3 * s);
         phase2();
+        if constexpr (NB > 1) {
+            // this block's h1 in bf16 (the gate product's operand registers: complete behind phase 2) -> the image the pooling kernel reads:
+            // eight stores of 1 KiB per wave, consecutive bytes
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) __builtin_amdgcn_raw_buffer_store_b128(hf[kk], h1rs, (blk * 8 + kk) * 1024 + lane * 16, 0, 0);
+        }
         if (s < 4) ASTAMP(4 + 3 * s);
     };
     ASTAMP(2);
@@ -483,7 +528,7 @@ __global__ __launch_bounds__(256, 1) void abmil32_kernel(const Abmil32Params p) 
     }
     ASTAMP(15);
     if (HIPT_STAMPS_ON(p.stamps) && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 24 + 22] = __builtin_amdgcn_s_memtime();
-    if (p.attention_only) return;
+    if (p.attention_only || NB > 1) return;  // (several branches: the pooling kernel below takes over)
 
     // ---- this workgroup's partial: sum over the rows (= lanes) of every wave, then over the 4 waves, through LDS (weights are dead) ----
     __syncthreads();
@@ -749,7 +794,248 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
     return HIPT_OK;
 }
 
+// ---- CLAM_MB, second pass (round 6): M[k] = softmax_N(A_raw[k]) h1 for the NB branches from the bf16 h1 image and the logits the first pass left
+// (models/model_clam.py:233-250).  A wave walks 32-row blocks (block b -> wave b mod #waves): 8 KiB of h1 per block in eight 1 KiB loads, the
+// rows' NB softmax weights e^(A - bc) (the fixed shift of the first pass: |A - bc| <= sum |wc| < 60), 64 x NB multiply-adds per lane; then the
+// workgroup's partial per branch through LDS (the reduction of abmil32_kernel), and the last workgroup to arrive (ticket) adds the partials in
+// a fixed order and applies the K one-row classifiers.  Deterministic bits.
+struct ClamMbPoolParams {
+    const char* h1_img;
+    const float* A_raw;   // [NB][N]
+    const float* bc;      // [NB]
+    int N, nblocks;
+    float* partials;      // [grid][NB][PSTRIDE_F]
+    unsigned* ticket;
+    const float* wcls;    // [NB][S1]
+    const float* bcls;    // [NB]
+    float* M;             // [NB][S1]
+    float* logits;        // [NB]
+};
+
+// sum over the 32 lanes of a lane half (every lane of the half gets it): quads and 16-lane rows by DPP, the two rows by v_permlane16_swap
+__device__ __forceinline__ float half_sum_dpp(float v) {
+#pragma clang fp contract(off)
+#define DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+    DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    DPP_ADD(0x124);  // row_ror:4
+    DPP_ADD(0x128);  // row_ror:8
+#undef DPP_ADD
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    const auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (uint32_t)s16[0]) + __builtin_bit_cast(float, (uint32_t)s16[1]);
+}
+
+// Eight waves per workgroup; the workgroup walks 32-row blocks (b = blockIdx.x, += gridDim.x) and wave w owns PIECE w of every block (1 KiB: the
+// hidden units 16 w .. 16 w + 15 of the block's 32 rows): 8 x NB running sums per lane instead of 64 x NB, so that eight blocks' loads are in
+// flight per wave (the first version walked whole blocks per wave with nothing in flight behind the block in work: 20 us for 26 MB).
+template <int NB>
+__global__ __launch_bounds__(512) void clam_mb_pool_kernel(const ClamMbPoolParams p) {
+    __shared__ float sh[64];
+    __shared__ int flag;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int G = gridDim.x;
+    float acc[NB][8];
+    float ls[NB], bcv[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        ls[k] = 0.f;
+        bcv[k] = p.bc[k];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+    }
+    constexpr int PFD = 8;  // blocks in flight per wave
+    const int nmine = blockIdx.x < p.nblocks ? (p.nblocks - blockIdx.x + G - 1) / G : 0;
+    // (range-checked buffer loads: a block past the end reads as zero without traffic and without a branch -- hipcc drains every load in flight
+    //  at a conditional one)
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.h1_img, 0, p.nblocks * 8192, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)p.A_raw, 0, (int)((int64_t)NB * p.N * 4), 0x00020000);
+    constexpr int OOR = 0x7fff0000;
+    const int lane_off = w * 1024 + lane * 16;
+    auto ld = [&](int i) { return __builtin_amdgcn_raw_buffer_load_b128(hrs, i < nmine ? (blockIdx.x + i * G) * 8192 + lane_off : OOR, 0, 0); };
+    auto lda = [&](int i, int k) {
+        const int row = (blockIdx.x + i * G) * 32 + r;
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, (i < nmine && row < p.N) ? (k * p.N + row) * 4 : OOR, 0, 0));
+    };
+    u32x4 win[PFD];
+    float aw[PFD][NB];
+#pragma unroll
+    for (int d = 0; d < PFD; ++d) {
+        win[d] = ld(d);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) aw[d][k] = lda(d, k);
+    }
+    for (int i0 = 0; i0 < nmine; i0 += PFD) {
+#pragma unroll
+        for (int d = 0; d < PFD; ++d) {
+#pragma clang fp contract(off)
+            const u32x4 h = win[d];
+            const bool valid = i0 + d < nmine && (blockIdx.x + (i0 + d) * G) * 32 + r < p.N;
+            float pk[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const float e = __builtin_amdgcn_exp2f((aw[d][k] - bcv[k]) * LOG2E);
+                pk[k] = valid ? e : 0.f;  // (a row that does not exist weighs nothing)
+                ls[k] += pk[k];
+            }
+            win[d] = ld(i0 + d + PFD);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) aw[d][k] = lda(i0 + d + PFD, k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t wd = h[e >> 1];
+                const float v = __builtin_bit_cast(float, (e & 1) ? (wd & 0xffff0000u) : (wd << 16));
+#pragma unroll
+                for (int k = 0; k < NB; ++k) acc[k][e] = __builtin_fmaf(pk[k], v, acc[k][e]);
+            }
+        }
+    }
+    // ---- this workgroup's partial: per value the sum over the 32 rows of its lane half; element e of lane half hh = hidden 16 w + 8 (e >> 2) + 4 hh + (e & 3) ----
+    float* pw = p.partials + (int64_t)blockIdx.x * NB * PSTRIDE_F;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sme = half_sum_dpp(acc[k][e]);
+            if (r == 0) __hip_atomic_store(&pw[k * PSTRIDE_F + 4 + 16 * w + 8 * (e >> 2) + 4 * hh + (e & 3)], sme, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const float l = half_sum_dpp(ls[k]);  // (every wave walked the same rows: wave 0, lane half 0 speaks for all)
+        if (w == 0 && lane == 0) __hip_atomic_store(&pw[k * PSTRIDE_F + 1], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- hand-off as in abmil32_kernel: sc1 stores, every wave's vmcnt(0), barrier, one agent-scope atomic; the last arriver merges ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const bool last = atomicAdd(p.ticket, 1u) == gridDim.x - 1;
+        flag = last;
+        if (last) __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!flag) return;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)p.partials, 0, G * NB * PSTRIDE_F * 4, 0x00020000);
+    constexpr int SC1 = 16;
+    // thread (part, col): column col of the workgroups g = part, part + 4, .. (G <= 128: 32 of them), ALL its loads in flight at once (the first
+    // version took them eight at a time: sixteen round trips); summed in ascending g, then the four parts in order: deterministic bits
+    __shared__ float cs[NB][4][S1];
+    __shared__ float lsh[NB][8];
+    const int col = tid & 127, part = tid >> 7;
+    float v[NB][32];
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int g = part + 4 * i;
+            v[k][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, g < G ? ((g * NB + k) * PSTRIDE_F + 4 + col) * 4 : OOR, 0, SC1));
+        }
+    float lv[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) lv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, tid < G ? ((tid * NB + k) * PSTRIDE_F + 1) * 4 : OOR, 0, SC1));
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a += v[k][i];
+        cs[k][part][col] = a;
+        const float l = wave_sum_dpp(lv[k]);
+        if (lane == 0) lsh[k][w] = l;
+    }
+    __syncthreads();
+    const int k = tid >> 7;  // thread (k, col) finishes column col of branch k
+    float m = 0.f;
+    if (k < NB) {
+        const float L = ((lsh[k][0] + lsh[k][1]) + (lsh[k][2] + lsh[k][3])) + ((lsh[k][4] + lsh[k][5]) + (lsh[k][6] + lsh[k][7]));
+        m = ((cs[k][0][col] + cs[k][1][col]) + (cs[k][2][col] + cs[k][3][col])) / L;
+        p.M[k * S1 + col] = m;
+    }
+    // logits[k] = wcls[k] . M[k] + bcls[k] (model_clam.py:248-250): the 128 products of branch k sit in waves 2 k and 2 k + 1
+    float prod = k < NB ? m * p.wcls[k * S1 + col] : 0.f;
+    prod = wave_sum_dpp(prod);
+    if (lane == 0) sh[w] = prod;
+    __syncthreads();
+    if (tid < NB) p.logits[tid] = (sh[2 * tid] + sh[2 * tid + 1]) + p.bcls[tid];
+}
+
+template <int KS, int NB>
+int launch_mb(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, void* h1_img, float* partials, unsigned* ticket,
+              float* M, float* logits, hipStream_t st) {
+    constexpr int lds = image_bytes(KS) + 4 * TB_BYTES;
+    auto k = abmil32_kernel<KS, NB>;
+    auto kp = clam_mb_pool_kernel<NB>;
+    static DevOnce once;
+    HIPT_CUR_DEVICE(dev);
+    if (!once.done[dev]) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            hipt_set_error("hipFuncSetAttribute(abmil32 / multi-branch) failed");
+            return HIPT_E_LAUNCH;
+        }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            hipt_set_error("abmil32: cannot query the device");
+            return HIPT_E_LAUNCH;
+        }
+        once.ncu[dev] = prop.multiProcessorCount;
+        once.done[dev] = true;
+    }
+    Abmil32Params p;
+    memset(&p, 0, sizeof(p));
+    p.bag = (const bf16_t*)bag;
+    p.N = N;
+    p.nblocks = (N + 31) / 32;
+    const int maxg = once.ncu[dev] < 256 ? once.ncu[dev] : 256;
+    const int rounds = (p.nblocks + 4 * maxg - 1) / (4 * maxg);
+    const int grid = ((p.nblocks + rounds - 1) / rounds + 3) / 4;
+    p.nwaves = grid * 4;
+    p.image = (const char*)w->stream_pk;
+    p.bc = w->bc;
+    p.A_raw = A_raw;
+    p.h1_img = h1_img;
+    p.attention_only = 1;
+    if (attention_only != 2) {  // (2: the pooling launch alone -- capi.hip books the two launches apart)
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
+        HIPT_CHECK_LAUNCH();
+    }
+    if (attention_only == 1) return HIPT_OK;
+    ClamMbPoolParams q;
+    memset(&q, 0, sizeof(q));
+    q.h1_img = (const char*)h1_img;
+    q.A_raw = A_raw;
+    q.bc = w->bc;
+    q.N = N;
+    q.nblocks = p.nblocks;
+    q.partials = partials;
+    q.ticket = ticket;
+    q.wcls = w->wcls;
+    q.bcls = w->bcls;
+    q.M = M;
+    q.logits = logits;
+    // (the partials of at most 128 workgroups -- hipt_clam_mb_workspace_bytes; a workgroup of eight waves walks at least eight blocks)
+    int gp = (p.nblocks + 7) / 8;
+    gp = gp < 1 ? 1 : (gp > 128 ? 128 : gp);
+    hipLaunchKernelGGL(kp, dim3(gp), dim3(512), 0, st, q);
+    HIPT_CHECK_LAUNCH();
+    return HIPT_OK;
+}
+
 }  // namespace
+
+// CLAM_MB's one-pass inference (K = w->n_att attention branches, 2 <= K <= 4) where the streaming kernel runs: bf16 [384 | 192, 128, 64], the
+// image packed WITH its K rows of wc, the largest of the K logit bounds below 60
+bool hipt_clam_mb_stream_supported(const hipt_clam_weights* w) {
+    return w->n_att >= 2 && w->n_att <= 4 && w->n_classes == w->n_att && hipt_clam_stream_supported(w);
+}
+
+size_t hipt_clam_mb_h1_bytes(int N) { return (size_t)((N + 31) / 32) * 8192; }
+
+int hipt_clam_mb_stream_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, void* h1_img, float* partials,
+                               unsigned* ticket, float* M, float* logits, hipStream_t st) {
+    HIPT_CHECK_ARG((int64_t)N * w->s0 * 2 < (int64_t)0x7fff0000 && (int64_t)((N + 31) / 32) * 8192 < (int64_t)0x7fff0000, "clam stream: bag beyond 2 GiB");
+#define MB_CASE(KS_, NB_) \
+    if (w->s0 == 16 * KS_ && w->n_att == NB_) return launch_mb<KS_, NB_>(w, bag, N, attention_only, A_raw, h1_img, partials, ticket, M, logits, st);
+    MB_CASE(24, 2) MB_CASE(24, 3) MB_CASE(24, 4) MB_CASE(12, 2) MB_CASE(12, 3) MB_CASE(12, 4)
+#undef MB_CASE
+    hipt_set_error("clam stream (multi-branch): unsupported S0=%d / branches=%d", w->s0, w->n_att);
+    return HIPT_E_UNSUPPORTED;
+}
 
 // bf16 [384 | 192, 128, 64] with a usable logit bound: e^B times the row count times |h1| must stay inside fp32's range
 bool hipt_clam_stream_supported(const hipt_clam_weights* w) {
@@ -770,8 +1056,10 @@ int hipt_clam_stream_pack_launch(const hipt_clam_weights* w, void* out, hipStrea
     }
     HIPT_CHECK_ARG(w->w1 && w->b1 && w->wab && w->bab && w->wc && out && ((uintptr_t)out & 15) == 0, "clam stream pack: null / unaligned pointer");
     const int n = (int)(nb / 16);
+    const int nbr = w->n_att > 1 ? w->n_att : 1;  // (CLAM_MB: wc = [n_att][S2])
+    HIPT_CHECK_ARG(nbr <= 16, "clam stream pack: at most 16 attention branches (got %d)", nbr);
     hipLaunchKernelGGL(abmil32_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const bf16_t*)w->w1, w->b1, (const bf16_t*)w->wab, w->bab,
-                       w->wc, w->s0 / 16, (char*)out);
+                       w->wc, w->s0 / 16, (char*)out, nbr);
     HIPT_CHECK_LAUNCH();
     return HIPT_OK;
 }

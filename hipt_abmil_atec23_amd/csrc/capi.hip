@@ -1142,6 +1142,40 @@ int hipt_clam_sb_forward(const hipt_clam_weights* w, const void* bag, int N, int
     return HIPT_OK;
 }
 
+int hipt_clam_mb_supported(const hipt_clam_weights* w) { return w && check_clam(w) == HIPT_OK && hipt_clam_mb_stream_supported(w) ? 1 : 0; }
+
+size_t hipt_clam_mb_workspace_bytes(const hipt_clam_weights* w, int N) {
+    // ticket | partials of <= 128 workgroups x K branches | h1 as a bf16 image
+    return 256 + al256((size_t)128 * 4 * (4 + 128) * 4) + al256(hipt_clam_mb_h1_bytes(N > 0 ? N : 1));
+}
+
+int hipt_clam_mb_forward(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, float* M, float* logits, void* workspace,
+                         size_t ws_bytes, void* stream) {
+    int rc = check_clam(w);
+    if (rc) return rc;
+    HIPT_CHECK_ARG(bag && A_raw && N > 0, "clam_mb_forward: null/empty bag (N=%d)", N);
+    HIPT_CHECK_ARG(attention_only || (M && logits), "clam_mb_forward: null output");
+    HIPT_CHECK_ARG(((uintptr_t)bag & 15) == 0, "clam_mb_forward: bag must be 16-byte aligned");
+    if (!hipt_clam_mb_stream_supported(w)) {
+        hipt_set_error("clam_mb_forward: no one-pass form for this configuration (bf16 [384|192,128,64], 2..4 branches = classes, stream_pk, bound < 60): "
+                       "call hipt_clam_sb_forward per branch");
+        return HIPT_E_UNSUPPORTED;
+    }
+    if (ws_bytes < hipt_clam_mb_workspace_bytes(w, N) || ((uintptr_t)workspace & 255)) {
+        hipt_set_error("clam_mb_forward: workspace %zu B too small / unaligned (need %zu)", ws_bytes, hipt_clam_mb_workspace_bytes(w, N));
+        return HIPT_E_WORKSPACE;
+    }
+    hipStream_t st = S(stream);
+    Carver c(workspace, ws_bytes);
+    unsigned* ticket = (unsigned*)c.take(256);
+    float* partials = (float*)c.take((size_t)128 * 4 * (4 + 128) * 4);
+    void* h1 = c.take(hipt_clam_mb_h1_bytes(N));
+    // (the two launches are booked apart: 'abmil_fused' = the streaming pass, 'abmil_combine' = the pooling pass)
+    PROF(PC_ABMIL, hipt_clam_mb_stream_launch(w, bag, N, 1, A_raw, h1, partials, ticket, M, logits, st));
+    if (!attention_only) PROF(PC_COMBINE, hipt_clam_mb_stream_launch(w, bag, N, 2, A_raw, h1, partials, ticket, M, logits, st));
+    return HIPT_OK;
+}
+
 int hipt_attn_net_gated(const hipt_clam_weights* w, const void* x, int N, float* A, void* workspace, size_t ws_bytes,
                         void* stream) {
     int rc = check_clam(w);

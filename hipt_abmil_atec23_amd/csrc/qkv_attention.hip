@@ -351,7 +351,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                 if constexpr (s == 11) {
                     // ---- ring: the next unit has landed for everyone; request the one after it ----
                     if constexpr ((DBG & 1) == 0) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        // (the first ring barrier of a work unit comes 12 MFMAs behind the previous unit's eight output stores, the wave's youngest
+                        //  vector-memory operations: vmcnt(0) there waited for their write acknowledgements -- HBM latency, every work unit.  vmcnt is in
+                        //  order: all but the youngest eight = the DMA pieces of the next ring unit and the operand loads have landed.  Round 6.)
+                        if constexpr (u == 0 && !CLSONLY) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                     }
                     issue_unit();

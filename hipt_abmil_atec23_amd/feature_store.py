@@ -113,14 +113,18 @@ class _HostFeed:
 
     def __init__(self, device: torch.device):
         self.device = device
-        self.copy_stream = torch.cuda.Stream(device=device)
+        # HIGH-PRIORITY streams: HIP multiplexes a process's streams over a few hardware queues (four by default), and a copy whose stream shares
+        # an in-order hardware queue with a compute stream starts only behind the ~26 ms of kernels already enqueued there -- measured in
+        # bench.py's process (14 streams alive): 33.3 ms per gathered call against 27.3 for the same loop in a fresh process.  Priority
+        # streams get hardware queues of their own.
+        self.copy_stream = torch.cuda.Stream(device=device, priority=-1)
         self.buf = [None] * self.SLOTS       # device gather buffers [cap, ...]
         self.stage = [None] * self.SLOTS     # pinned staging twins (allocated only when a pageable batch arrives)
         self.free = [None] * self.SLOTS      # event: the call that read buf[s] has finished
         self.staged = [None] * self.SLOTS    # event: the last copy out of stage[s] has completed
         self.slot = 0
         self.fill = 0
-        self.read_stream = torch.cuda.Stream(device=device)  # features come back on their own stream, behind THEIR call only
+        self.read_stream = torch.cuda.Stream(device=device, priority=-1)  # features come back on their own stream, behind THEIR call only
         self._hbuf = None
 
     def read_back(self, feats: torch.Tensor, done: "torch.cuda.Event") -> torch.Tensor:
@@ -161,6 +165,9 @@ class _HostFeed:
             dst.copy_(src, non_blocking=True)
         self.fill = o + n
 
+    def capacity(self) -> int:
+        return 0 if self.buf[self.slot] is None else self.buf[self.slot].shape[0]
+
     def finish(self):
         """(the gathered regions as a device tensor the CURRENT stream may read, its slot); switches to the other slot"""
         s = self.slot
@@ -195,11 +202,12 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
 
     **Host batches** (round 6; the reference's loader yields CPU tensors and moves each to the device inside the loop,
     extract_features_fp.py:162-166): when ``model`` is a ``HIPT_4K`` on a HIP device and a loader batch is not there, the batch
-    is copied host -> device on a copy stream into one of two gather buffers while the previous call computes (``_HostFeed``), and the
-    features of call k are read back only after call k + 1 has been enqueued -- the link, the GPU and the host loop overlap.  Same
+    is copied host -> device AS IT ARRIVES, on a copy stream, into one of two gather buffers while the previous call computes (``_HostFeed``),
+    and the features of call k are read back (on a stream of their own) only after call k + 1 has been enqueued -- the link, the GPU and the host loop overlap.  Same
     gathered tensor, same kernels, same bits as with resident batches."""
     w = FeatureWriter(feat_dir, slide_id)
-    held: list = []  # (regions, coords) waiting for company
+    held: list = []  # (regions or None when already staged into the host feed's gather buffer, coords, count) waiting for company
+    shape_key = [None]
     m256 = getattr(model, "model256", None)  # HIPT_4K: where its first-level ViT's weights live NOW (.to() may have moved it since construction)
     dev = getattr(m256, "weight_device", None) if m256 is not None else None
     dev = torch.device(dev) if dev is not None else None
@@ -221,19 +229,11 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
     def flush():
         if not held:
             return
-        counts, coords = [r.shape[0] for r, _ in held], [c for _, c in held]
-        on_host = dev is not None and dev.type == "cuda" and held[0][0].device.type == "cpu"
+        counts, coords = [n for _, _, n in held], [c for _, c, _ in held]
+        staged = held[0][0] is None  # host batches: already on their way into the open gather buffer (stage())
         slot = None
-        if on_host:
-            if feed[0] is None:
-                feed[0] = _HostFeed(dev)
-            f = feed[0]
-            # (capacity: `coalesce` regions where batches are gathered, so that a ragged tail re-uses the buffer; else this batch)
-            f.begin(max(sum(counts), coalesce) if gathers_bit_exactly(held[0][0]) else sum(counts), held[0][0])
-            for i in range(len(held)):
-                f.add(held[i][0])
-                held[i] = None
-            regions, slot = f.finish()
+        if staged:
+            regions, slot = feed[0].finish()
         elif len(held) == 1:
             regions = held[0][0]
         else:
@@ -248,11 +248,12 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
                 held[i] = None
                 del r
         held.clear()
+        shape_key[0] = None
         feats = model(regions)
         if slot is not None:
             feed[0].release(slot)
         del regions
-        if on_host:
+        if staged:
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(dev))
             pending.append((feats, counts, coords, done))  # read back after the NEXT call is enqueued: the GPU never waits for the host
@@ -261,6 +262,20 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
         else:
             drain()
             append_call(feats, counts, coords)
+
+    def stage(regions) -> bool:
+        """a HOST batch for a model on a HIP device: its copy starts NOW, into the open gather buffer (opened here if none is)"""
+        if not (dev is not None and dev.type == "cuda" and regions.device.type == "cpu"):
+            return False
+        if feed[0] is None:
+            feed[0] = _HostFeed(dev)
+        f, n = feed[0], regions.shape[0]
+        if not held:
+            # capacity: what a gathered call can reach (the batch that crosses `coalesce` is not split: < 2 coalesce regions), so that ragged
+            # tails and uneven loader batches re-use the buffer; a shape that is not gathered: this batch alone
+            f.begin(max(n, 2 * coalesce - 1) if (coalesce > 1 and gathers_bit_exactly(regions)) else n, regions)
+        f.add(regions)
+        return True
 
     def gathers_bit_exactly(regions) -> bool:
         # whole 16-row fragments in every call (patch count a multiple of 16): the gathered call and the one-by-one call take the
@@ -272,10 +287,14 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
 
     with torch.no_grad():
         for regions, coords in batches:
-            if held and (regions.shape[1:] != held[0][0].shape[1:] or regions.dtype != held[0][0].dtype or regions.device != held[0][0].device):
+            key = (tuple(regions.shape[1:]), regions.dtype, regions.device)
+            if held and key != shape_key[0]:
                 flush()  # a different shape / type cannot share a call
-            held.append((regions, coords))
-            if coalesce <= 1 or not gathers_bit_exactly(regions) or sum(r.shape[0] for r, _ in held) >= coalesce:
+            if held and held[0][0] is None and feed[0].fill + regions.shape[0] > feed[0].capacity():
+                flush()  # (a host batch that would overrun the open gather buffer: a loader batch larger than `coalesce` behind smaller ones)
+            shape_key[0] = key
+            held.append((None if stage(regions) else regions, coords, regions.shape[0]))
+            if coalesce <= 1 or not gathers_bit_exactly(regions) or sum(n for _, _, n in held) >= coalesce:
                 flush()
         flush()
         drain()

@@ -521,6 +521,7 @@ class CLAM_MB(CLAM_SB):
     ``gate=False`` and CPU tensors take the PyTorch-op sequence."""
 
     _multi = True
+    one_pass = True  # inference takes hipt_clam_mb_forward (one pass over the bag for all branches) where the library has it; False: branch by branch
 
     def __init__(self, gate=True, size_arg="small", dropout=0.0, k_sample=8, n_classes=2,
                  instance_loss_fn=nn.CrossEntropyLoss(), subtyping=False):
@@ -567,7 +568,25 @@ class CLAM_MB(CLAM_SB):
                     w.stream_pk = own["stream_pk"].data_ptr()
                 ws.append(w)
                 keep.append(own)
-            self._packed = (key, ws, keep)
+            # all K branches in ONE pass over the bag (hipt_clam_mb_forward, round 6) where the streaming kernel takes the configuration:
+            # the same shared tensors, wc / bc / the K one-row classifiers stacked, the image packed with its K rows of wc
+            wm, mb = N.ClamWeights(), None
+            wm.dtype, wm.s0, wm.s1, wm.s2 = code, fc1.in_features, fc1.out_features, wa.out_features
+            wm.n_classes = wm.n_att = self.n_classes
+            own = dict(wc=wc_all, bc=bc_all, wcls=Fn.f32c(torch.cat([c.weight for c in self.classifiers], dim=0)),
+                       bcls=Fn.f32c(torch.cat([c.bias for c in self.classifiers], dim=0)))
+            for name, t in {**shared, **own}.items():
+                setattr(wm, name, t.data_ptr())
+            wm.logit_bound = max(max(float(b) for b in bounds), 1e-30)
+            nb = N.lib().hipt_clam_stream_packed_bytes(C_.byref(wm)) if 2 <= self.n_classes <= 4 else 0
+            if nb:
+                own["stream_pk"] = torch.empty(nb, dtype=torch.uint8, device=device)
+                N.call("hipt_clam_stream_pack", C_.byref(wm), N.ptr(own["stream_pk"]), N.stream_ptr(device))
+                wm.stream_pk = own["stream_pk"].data_ptr()
+                if N.lib().hipt_clam_mb_supported(C_.byref(wm)):
+                    mb = wm
+            keep.append(own)
+            self._packed = (key, ws, keep, mb)
         return self._packed[1]
 
     def _multi_infer(self, h, label, instance_eval, return_features, attention_only):
@@ -581,12 +600,23 @@ class CLAM_MB(CLAM_SB):
         bag = Fn.as_compute(h, ws[0].dtype)
         st = N.stream_ptr(dev)
         A_raw = torch.empty((K, n), dtype=torch.float32, device=dev)
+        mb = self._packed[3] if self.one_pass else None
+        S1 = self._sizes[1]
+        if mb is not None:
+            # ONE pass over the bag: gate once per row, K logits, h1 left in bf16 for the pooling kernel (two launches instead of K)
+            scratch = Fn.workspace(dev, N.lib().hipt_clam_mb_workspace_bytes(C_.byref(mb), n), ("clam_mb", st.value), zero=True)
+            if attention_only:
+                N.call("hipt_clam_mb_forward", C_.byref(mb), N.ptr(bag), n, 1, N.ptr(A_raw), None, None, N.ptr(scratch), scratch.numel(), st)
+                return A_raw
+            M = torch.empty((K, S1), dtype=torch.float32, device=dev)
+            logits = torch.empty((1, K), dtype=torch.float32, device=dev)
+            N.call("hipt_clam_mb_forward", C_.byref(mb), N.ptr(bag), n, 0, N.ptr(A_raw), N.ptr(M), N.ptr(logits), N.ptr(scratch), scratch.numel(), st)
+            return self._multi_finish(logits, A_raw, M, ws, bag, n, label, instance_eval, return_features)
         scratch = Fn.workspace(dev, N.lib().hipt_clam_workspace_bytes(C_.byref(ws[0]), n), ("clam", st.value), zero=True)
         if attention_only:
             for k, w in enumerate(ws):
                 N.call("hipt_clam_sb_forward", C_.byref(w), N.ptr(bag), n, 1, N.ptr(A_raw[k]), None, None, None, None, N.ptr(scratch), scratch.numel(), st)
             return A_raw
-        S1 = self._sizes[1]
         M = torch.empty((K, S1), dtype=torch.float32, device=dev)
         logits = torch.empty((1, K), dtype=torch.float32, device=dev)
         junk_p = torch.empty((K,), dtype=torch.float32, device=dev)      # (the one-class softmax / argmax of a branch: 1 and 0)
@@ -594,6 +624,10 @@ class CLAM_MB(CLAM_SB):
         for k, w in enumerate(ws):
             N.call("hipt_clam_sb_forward", C_.byref(w), N.ptr(bag), n, 0, N.ptr(A_raw[k]), N.ptr(M[k]), N.ptr(logits[0, k:k + 1]), N.ptr(junk_p[k:k + 1]),
                    N.ptr(junk_y[k:k + 1]), N.ptr(scratch), scratch.numel(), st)
+        return self._multi_finish(logits, A_raw, M, ws, bag, n, label, instance_eval, return_features)
+
+    def _multi_finish(self, logits, A_raw, M, ws, bag, n, label, instance_eval, return_features):
+        dev, K, S1, st = bag.device, self.n_classes, self._sizes[1], N.stream_ptr(bag.device)
         Y_hat = torch.topk(logits, 1, dim=1)[1]      # :251-252, on K numbers
         Y_prob = F.softmax(logits, dim=1)
         results = {}

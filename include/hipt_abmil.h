@@ -299,7 +299,9 @@ typedef struct hipt_clam_weights {
     int32_t dtype;            /* type of w1 / wab (and of the bag)                              */
     int32_t s0, s1, s2;       /* size_dict entry [S0,S1,S2] (model_clam.py:81)                  */
     int32_t n_classes;        /* bag classifier outputs                                         */
-    int32_t reserved;
+    int32_t n_att;            /* attention branches K: 0 / 1 = one (CLAM_SB; the field was `reserved` up to ABI 4); K > 1 = CLAM_MB
+                                 (hipt_clam_mb_forward): wc = [K,S2], bc = [K], wcls = the K Linear(S1,1) stacked [K,S1], bcls = [K],
+                                 n_classes = K, logit_bound = the largest of the K bounds */
     const void*  w1;  const float* b1;     /* attention_net.0: Linear(S0,S1) (+ReLU)  [S1,S0]     */
     const void*  wab; const float* bab;    /* attention_a.0 / attention_b.0 stacked [2*S2,S1]:
                                               rows [0,S2) = a, rows [S2,2*S2) = b; bias likewise */
@@ -338,6 +340,18 @@ size_t hipt_clam_ticket_offset(const hipt_clam_weights* w, int N);
  * attention_only != 0 skips pooling (only A_raw is written; model_clam.py:151-152). */
 int hipt_clam_sb_forward(const hipt_clam_weights* w, const void* bag, int N, int attention_only,
                          float* A_raw, float* M, float* logits, float* Y_prob, int64_t* Y_hat,
+                         void* workspace, size_t ws_bytes, void* stream);
+
+/* CLAM_MB.forward (model_clam.py:226-264), inference, with ONE pass over the bag for all K = w->n_att attention branches (2 <= K <= 4; W1 and
+ * [Wa; Wb] are shared by the branches, only wc / bc / the classifier rows differ):  A_raw[K, N] = the K logits of every row;
+ * M[K, S1] = softmax_N(A_raw[k]) h1;  logits[K]: logits[k] = wcls[k] . M[k] + bcls[k] (:248-250; Y_prob / Y_hat are K numbers: the caller's).
+ * Two launches: the streaming kernel (MFMA projections, gate once per row, K logits, h1 left in HBM as bf16) and a pooling kernel.
+ * hipt_clam_mb_supported(w) != 0: this configuration has the one-pass form (bf16 [384 | 192, 128, 64], stream_pk packed with n_att = K,
+ * logit_bound < 60); otherwise call hipt_clam_sb_forward once per branch.  attention_only != 0: A_raw only.
+ * workspace >= hipt_clam_mb_workspace_bytes(w, N), 256-byte aligned, its first 256 bytes zero before the first use (the ticket block). */
+int hipt_clam_mb_supported(const hipt_clam_weights* w);
+size_t hipt_clam_mb_workspace_bytes(const hipt_clam_weights* w, int N);
+int hipt_clam_mb_forward(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, float* M, float* logits,
                          void* workspace, size_t ws_bytes, void* stream);
 
 /* Attn_Net_Gated.forward (model_clam.py:59-64) on its own: A[N] from x[N,L]

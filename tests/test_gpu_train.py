@@ -120,6 +120,12 @@ def test_train_step_vs_oracle_other_shapes(size, base, n, ncls, multi, k):
         assert md(gr, ref) < max(TOL, 1e-5 * float(ref.abs().max())), (key, md(gr, ref))
 
 
+def rel_l2(a, b):
+    a = a.detach().float().cpu().numpy().astype(np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
 def test_clam_mb_eval_forward_vs_reference_golden():
     g = golden("clam_mb_hipt_big_n333")
     m = make((192, 128, 64), 193, 3, True, 8, True).eval()
@@ -135,39 +141,79 @@ def test_clam_mb_eval_forward_vs_reference_golden():
 
 
 def test_clam_mb_inference_runs_the_streaming_kernels_100k_bf16():
-    """CLAM_MB in eval mode (models/model_clam.py:226-264) on the kernels CLAM_SB's inference uses: bf16, 100 000 x 192, K = 3 branches
-    -- one pass over the bag per branch on the MFMA streaming kernel (round 4: the fp32 VALU training kernels, 0.47 ms at 60 000 rows).
-    Against the module's own PyTorch-op forward in fp32 at CLAM_SB's bf16 bars (A_raw 4e-2, M rel-L2 2e-3), timed with the library's
-    per-kernel HIP events: three launches of 25 us, <= 90 us together (measured 76; the bag is read once per branch -- a kernel that
-    pools all K branches in one pass needs K x 64 more accumulator registers per wave than the streaming kernel has left)."""
+    """CLAM_MB in eval mode (models/model_clam.py:226-264) on the kernels CLAM_SB's inference uses: bf16, 100 000 x 192, K = 3 branches.
+    Round 6: ONE pass over the bag for all branches (hipt_clam_mb_forward: the streaming kernel forms the gate once per row and K logits and
+    leaves h1 in HBM as bf16; a pooling kernel makes the K pooled vectors and logits) -- two launches, the bag read once -- beside the
+    branch-by-branch form of round 5 (K launches of hipt_clam_sb_forward, `one_pass = False`: 76 us).  Against the module's own PyTorch-op
+    forward in fp32 at CLAM_SB's bf16 bars (A_raw 4e-2, M rel-L2 2e-3), the two forms against each other, timed with the library's HIP events
+    (one event pair around the two launches of a forward)."""
     m = make((192, 128, 64), 193, 3, True, 8, True).eval()
     h = synth.hash_uniform_torch((100_000, 192), 27, device=DEV)
     with torch.no_grad():
         ref = m._torch_forward(h, None, False, True, False)
         m.set_compute_dtype("bf16")
+        m(h)  # (packs the weight images: K + 1 more native calls, once per set of weights)
         before = N.calls
         lg, yp, yh, a_raw, res = m(h, return_features=True)
-        assert N.calls >= before + 3 and lg.grad_fn is None
+        assert N.calls == before + 1 and lg.grad_fn is None  # ONE native call: hipt_clam_mb_forward
         att = m(h, attention_only=True)
+        m.one_pass = False
+        lg3, yp3, yh3, a_raw3, res3 = m(h, return_features=True)
+        m.one_pass = True
         hb = h.bfloat16()
-        for _ in range(3):
-            m(hb)
-        torch.cuda.synchronize()
-        N.profile_enable(True)
-        for _ in range(10):
-            m(hb)
-        torch.cuda.synchronize()
-        prof = N.profile_read()
-        N.profile_enable(False)
+        times = {}
+        for name, one in (("one pass", True), ("branch by branch", False)):
+            m.one_pass = one
+            for _ in range(3):
+                m(hb)
+            torch.cuda.synchronize()
+            N.profile_enable(True)
+            for _ in range(10):
+                m(hb)
+            torch.cuda.synchronize()
+            pr = N.profile_read()
+            times[name] = (pr["abmil_fused"][0] + pr.get("abmil_combine", (0.0, 0))[0], pr["abmil_fused"][1] + pr.get("abmil_combine", (0.0, 0))[1], pr)
+            N.profile_enable(False)
+        m.one_pass = True
     lr, ypr, yhr, ar, rr = ref
     rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
     print(f"CLAM_MB bf16 100000x192, 3 branches vs fp32 PyTorch ops: A_raw max abs {md(a_raw, ar.cpu().numpy()):.2e}, M rel-L2 {rel(res['features'], rr['features']):.2e}, "
-          f"logits max abs {md(lg, lr.cpu().numpy()):.2e}; kernels {prof}")
+          f"logits max abs {md(lg, lr.cpu().numpy()):.2e}; one pass vs branch by branch: A_raw {float((a_raw - a_raw3).abs().max()):.2e}, M rel-L2 "
+          f"{rel(res['features'], res3['features']):.2e}; HIP-event time per forward: {({k: round(v[0] / 10 * 1e3, 1) for k, v in times.items()})} us "
+          f"(one pass: streaming kernel {times['one pass'][2]['abmil_fused'][0] / 10 * 1e3:.1f} + pooling kernel {times['one pass'][2]['abmil_combine'][0] / 10 * 1e3:.1f}, an event pair each)")
     assert a_raw.shape == (3, 100_000) and torch.equal(att, a_raw)
     assert md(a_raw, ar.cpu().numpy()) < 4e-2 and rel(res["features"], rr["features"]) < 2e-3 and md(lg, lr.cpu().numpy()) < 2e-3
-    assert int(yh) == int(yhr) and abs(float(yp.sum()) - 1.0) < 1e-6
-    ms, cnt = prof["abmil_fused"]
-    assert cnt == 30 and ms / 10 * 1e3 <= 90.0, prof
+    assert float((a_raw - a_raw3).abs().max()) < 1e-4 and rel(res["features"], res3["features"]) < 1e-3 and float((lg - lg3).abs().max()) < 1e-3
+    assert int(yh) == int(yhr) == int(yh3) and abs(float(yp.sum()) - 1.0) < 1e-6
+    assert times["one pass"][1] == 20 and times["branch by branch"][1] == 30, times  # (two launches a forward / three)
+    assert times["one pass"][0] / 10 * 1e3 <= 50.0 and times["branch by branch"][0] / 10 * 1e3 <= 90.0, times
+
+
+@pytest.mark.parametrize("n,K,s0", [(1, 2, 192), (31, 3, 192), (33, 4, 192), (257, 3, 384), (8 * 32 * 5 + 7, 2, 384), (70001, 3, 192)])
+def test_clam_mb_one_pass_ragged_bags_and_branch_counts(n, K, s0):
+    """hipt_clam_mb_forward's edges: bags of less than a block, a block +- a row, more blocks than the pooling kernel's prefetch depth, 2 / 3 / 4
+    branches, both bag widths -- against an fp64 evaluation on the bf16-rounded operands (bars as test_clam_stream_kernel_ragged_bags...)."""
+    m = make((s0, 128, 64), 190 + K, K, True, 1, True).eval().set_compute_dtype("bf16")
+    h = synth.hash_uniform_torch((n, s0), 170 + n % 97, device=DEV)
+    with torch.no_grad():
+        m(h)  # (packs)
+        before = N.calls
+        logits, y_prob, y_hat, a_raw, res = m(h, return_features=True)
+    assert N.calls == before + 1
+    p = {k: v.detach().float().cpu().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    r16 = lambda t: torch.from_numpy(t).bfloat16().double().numpy()
+    x = h.bfloat16().double().cpu().numpy()
+    h1 = np.maximum(x @ r16(p["attention_net.0.weight"]).T + p["attention_net.0.bias"], 0)
+    g = np.tanh(r16(h1) @ r16(p["attention_net.2.attention_a.0.weight"]).T + p["attention_net.2.attention_a.0.bias"]) * \
+        (1 / (1 + np.exp(-(r16(h1) @ r16(p["attention_net.2.attention_b.0.weight"]).T + p["attention_net.2.attention_b.0.bias"]))))
+    A = g @ p["attention_net.2.attention_c.weight"].T + p["attention_net.2.attention_c.bias"]  # [n, K]
+    for k in range(K):
+        pw = np.exp(A[:, k] - A[:, k].max())
+        Mk = (pw / pw.sum()) @ r16(h1)   # (the pooling kernel reads h1 as the first pass rounded it to bf16)
+        lk = Mk @ p[f"classifiers.{k}.weight"][0] + p[f"classifiers.{k}.bias"][0]
+        assert md(a_raw[k], A[:, k]) < 4e-2, (n, k)
+        assert rel_l2(res["features"][k], Mk) < 3e-3 and abs(float(logits[0, k]) - lk) < 2e-3, (n, k)
+    assert bool(torch.isfinite(logits).all()) and abs(float(y_prob.sum()) - 1) < 1e-6
 
 
 def test_clam_mb_long_bag_pools_over_many_workgroups():
