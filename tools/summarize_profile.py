@@ -35,7 +35,7 @@ def short(name):
 
 def ours(name):
     return any(k in name for k in ("seqgemm", "mlp_kernel", "mlp_pipe_kernel", "mlp32_kernel", "mlp16_kernel", "mlp16_pack", "qkv_attn", "mlp_co_kernel", "mlp_ws_kernel", "mlp32_pack", "mlp_ws_pack", "embed32", "gemm_kernel", "attn_kernel", "attn64_kernel", "attn_cls_kernel", "gather_cls", "u8_norm", "ln_kernel", "abmil", "mlp_pack",
-                                   "cls_init", "f32_to_bf16", "gate_kernel", "pool_kernel", "add_bf16", "clam_train", "topk_rows", "attn_cls_probs"))
+                                   "cls_init", "f32_to_bf16", "gate_kernel", "gemm_small", "lngemm_small", "clam_mb_pool", "pool_kernel", "add_bf16", "clam_train", "topk_rows", "attn_cls_probs"))
 
 
 stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "**", "*kernel_stats.csv"), recursive=True)
