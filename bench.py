@@ -772,6 +772,15 @@ def main():
                                   "memory (copy stream, two gather buffers), `resident` = the same loop over batches already in HBM")
             except Exception as e:
                 ex["h2d_error"] = repr(e)[:300]
+            # ... and the uint8 loop in a FRESH process (a child: this process keeps the GPU; nothing is exec'd over it), where the copy stream does not
+            # share a hardware queue with a dozen older streams -- what an extraction job looks like (tools/h2d_loop_bench.py)
+            try:
+                # (192 regions, 24 gathered per call: a slide is thousands of regions -- the first call's copy, which nothing hides, is 3 % here)
+                cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "h2d_loop_bench.py"), "24", "24"], capture_output=True, text=True, timeout=240)
+                line = [l for l in cp.stdout.splitlines() if l.startswith("H2D_LOOP ")]
+                ex["h2d_fresh_process"] = json.loads(line[-1][len("H2D_LOOP "):]) if line else {"error": (cp.stderr or cp.stdout)[-300:]}
+            except Exception as e:
+                ex["h2d_fresh_process"] = {"error": repr(e)[:300]}
             del reg8
             model.streams = 1
         # What an event pair adds to ONE launch (why `abmil_fwd_ms` / roofline_abmil.avg_launch_us read ~4 us above the graph-replayed pace of

@@ -208,6 +208,7 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
     w = FeatureWriter(feat_dir, slide_id)
     held: list = []  # (regions or None when already staged into the host feed's gather buffer, coords, count) waiting for company
     shape_key = [None]
+    ncalls = [0]
     m256 = getattr(model, "model256", None)  # HIPT_4K: where its first-level ViT's weights live NOW (.to() may have moved it since construction)
     dev = getattr(m256, "weight_device", None) if m256 is not None else None
     dev = torch.device(dev) if dev is not None else None
@@ -249,6 +250,7 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
                 del r
         held.clear()
         shape_key[0] = None
+        ncalls[0] += 1
         feats = model(regions)
         if slot is not None:
             feed[0].release(slot)
@@ -271,9 +273,9 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
             feed[0] = _HostFeed(dev)
         f, n = feed[0], regions.shape[0]
         if not held:
-            # capacity: what a gathered call can reach (the batch that crosses `coalesce` is not split: < 2 coalesce regions), so that ragged
-            # tails and uneven loader batches re-use the buffer; a shape that is not gathered: this batch alone
-            f.begin(max(n, 2 * coalesce - 1) if (coalesce > 1 and gathers_bit_exactly(regions)) else n, regions)
+            # capacity: what a gathered call reaches with loader batches of this size (the batch that crosses `coalesce` is not split), so that
+            # ragged tails re-use the buffer (a later, larger batch that would overrun it starts a new call); a shape that is not gathered: this batch alone
+            f.begin(coalesce + n - 1 if (coalesce > 1 and gathers_bit_exactly(regions)) else n, regions)
         f.add(regions)
         return True
 
@@ -294,7 +296,11 @@ def extract_slide(model, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], f
                 flush()  # (a host batch that would overrun the open gather buffer: a loader batch larger than `coalesce` behind smaller ones)
             shape_key[0] = key
             held.append((None if stage(regions) else regions, coords, regions.shape[0]))
-            if coalesce <= 1 or not gathers_bit_exactly(regions) or sum(n for _, _, n in held) >= coalesce:
+            # (host batches: the FIRST call of a slide is a short one -- a quarter of `coalesce` -- so that the GPU starts behind 2 regions' copies
+            #  instead of 8; nothing hides the first call's copy, every later one lands under the call before it.  A region's bits do not depend
+            #  on the call it shares.)
+            want = max(1, coalesce // 4) if (held[0][0] is None and ncalls[0] == 0) else coalesce
+            if coalesce <= 1 or not gathers_bit_exactly(regions) or sum(n for _, _, n in held) >= want:
                 flush()
         flush()
         drain()
