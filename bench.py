@@ -705,13 +705,13 @@ def main():
 
         ex = {}
         one = region[:1]
-        # extract_features_fp.py:159-171: batch_size 1.  HIPT_4K's own default for ONE region (patch_streams = 1: one stream; rounds 2-4 split the
-        # patches of a region over two) is what an unmodified reference loop gets; beside it the patches of the region over two streams
-        model.streams, model.patch_streams = 2, 1
-        ex["batch1_regions_per_s"] = 1.0 / timed(lambda: model(one), 10)
-        model.patch_streams = 2
-        ex["batch1_two_patch_streams_regions_per_s"] = 1.0 / timed(lambda: model(one), 10)
+        # extract_features_fp.py:159-171: batch_size 1.  HIPT_4K's own default for ONE region (patch_streams = 2: the patches of the region over two
+        # streams) is what an unmodified reference loop gets; beside it the one-stream form
+        model.streams, model.patch_streams = 2, 2
+        ex["batch1_regions_per_s"] = 1.0 / timed(lambda: model(one), 10)           # (HIPT_4K's default since round 6: the region's patches over two streams)
         model.patch_streams = 1
+        ex["batch1_one_patch_stream_regions_per_s"] = 1.0 / timed(lambda: model(one), 10)
+        model.patch_streams = 2
         if region.shape[0] >= 8:
             # the same one-region loader batches through feature_store.extract_slide's loop, which gathers 8 of them per call
             # (same files bit for bit: tests/test_gpu_parity.py::test_extract_slide_gathered_calls_write_the_same_bits)

@@ -37,10 +37,12 @@ class HIPT_4K(torch.nn.Module):
         # the second stream's kernels fill the CUs the first one's kernel frees in its last, partial round of tiles.
         # Default 2: a batch of R >= 2 regions runs as two groups of regions.
         self.streams = 2
-        # ... and a batch of ONE region (the reference's call pattern) as patch ranges over this many streams (_run_patch_split).  Default 1:
-        # with the proj fold of round 5 one stream is the robust choice -- tools/batch1_bench.py on two boxes of the pool: 1 stream 239 / 240
-        # regions/s, 2 streams 228-233 / 228-233, 3 streams 249 / 221, 4 streams 248-257 / 196-198 (rounds 2-4 split one region over 2).
-        self.patch_streams = 1
+        # ... and a batch of ONE region (the reference's call pattern) as patch ranges over this many streams (_run_patch_split).  Default 2
+        # (round 6): one region is 514 row tiles of the fused MLP = two rounds on 256 CUs + 2 tiles, a third pass over the weights for 0.4 % of the
+        # rows; two half-size streams (257 tiles each) run their leftover tile beside the other stream's full round.  tools/batch1_bench.py on four
+        # boxes of the pool in round 6: 1 stream 224-233 regions/s, 2 streams 236-249 (+6-7 % on every one), 3 / 4 streams 186-203.  (Round 5 measured
+        # 2 streams behind 1 on some boxes, before ViT-4K's launches were cut; the same bits either way: tests.)
+        self.patch_streams = 2
         self._side_streams = {}
         if compute_dtype is not None:
             self.set_compute_dtype(compute_dtype)
