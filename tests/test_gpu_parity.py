@@ -1345,5 +1345,14 @@ def test_extract_slide_host_batches_pipelined_same_bits(hipt, tmp_path):
                 assert np.array_equal(load_coords(str(tmp_path), f"{mem}_{kind}"), torch.cat(coords).numpy())
             one = torch.load(extract_slide(hipt, list(zip([r.cpu() for r in regs], coords)), str(tmp_path), f"one_{kind}", coalesce=1))
             assert torch.equal(one, ref), kind
+        # shapes that are not gathered (6 patches: no whole 16-row fragments) go one loader batch per call, from host memory too; and a slide
+        # whose batches change shape mid-way (a staged gather is closed, the new shape starts its own)
+        small = [synth.hash_uniform_torch((1, 3, 512, 768), 340 + i, device=DEV) for i in range(3)]
+        mixed = small[:2] + f32[:3] + small[2:]
+        mc = [torch.tensor([[i, i]], dtype=torch.int32) for i in range(len(mixed))]
+        ref = torch.load(extract_slide(hipt, list(zip(mixed, mc)), str(tmp_path), "mixed_res", coalesce=4))
+        got = torch.load(extract_slide(hipt, list(zip([r.cpu().pin_memory() for r in mixed], mc)), str(tmp_path), "mixed_host", coalesce=4))
+        assert got.shape == (6, 192) and torch.equal(got, ref)
+        assert load_coords(str(tmp_path), "mixed_host").dtype == np.int32
     finally:
         hipt.set_compute_dtype("fp32")
