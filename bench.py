@@ -585,6 +585,8 @@ def main():
                 out["sustained_mfma"] = ms_
         except Exception as e:
             out["sustained_mfma"] = {"error": repr(e)[:200]}
+    if sampler is not None:
+        sampler.stop()  # (the legs below are host-bound in places: no second Python thread beside them)
 
     # ---- per-kernel roofline leg: same workload, HIP events around every launch, ONE stream ----
     prof = {}
