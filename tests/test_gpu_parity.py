@@ -1356,3 +1356,27 @@ def test_extract_slide_host_batches_pipelined_same_bits(hipt, tmp_path):
         assert load_coords(str(tmp_path), "mixed_host").dtype == np.int32
     finally:
         hipt.set_compute_dtype("fp32")
+
+
+def test_step_bits_do_not_depend_on_stream_concurrency_or_the_run(hipt):
+    """Run-to-run determinism under stream concurrency (round 6: the uint8 embedding's miscounted ring wait showed ONLY as run-to-run differences
+    when two streams embedded at once -- tools/dbg_u8.py, tools/soak_step_determinism.py): six 4096 x 4096 regions over 3 / 2 / 1 streams, fp32 and
+    interleaved uint8 input, repeated: every repeat and every stream count returns the same bits."""
+    hipt.set_compute_dtype("bf16")
+    old = hipt.streams
+    try:
+        x = synth.hash_uniform_torch((6, 3, 4096, 4096), 3, device=DEV)
+        x8 = ((x * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        for name, inp in (("fp32", x), ("uint8", x8)):
+            ref = None
+            for streams in (3, 2, 1):
+                hipt.streams = streams
+                for rep in range(4):
+                    o = hipt(inp)
+                    torch.cuda.synchronize()
+                    if ref is None:
+                        ref = o.clone()
+                    assert torch.equal(o, ref), (name, streams, rep)
+    finally:
+        hipt.streams = old
+        hipt.set_compute_dtype("fp32")
