@@ -746,6 +746,7 @@ int launch(const hipt_clam_weights* w, const void* bag, int N, int attention_onl
     p.logits = logits;
     p.Y_prob = Y_prob;
     p.Y_hat = Y_hat;
+    p.h1_img = nullptr;  // (one branch: nothing leaves but A_raw and the pooled result)
     p.stamps = nullptr;
     p.no_traffic = 0;
 #ifdef HIPT_DEBUG_STAMPS
