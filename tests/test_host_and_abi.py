@@ -544,3 +544,33 @@ def test_feature_writer_h5_branch_with_a_stand_in_h5py(tmp_path, monkeypatch):
     assert d["coords"]["chunks"] == (1, 2) and d["coords"]["maxshape"] == (None, 2)
     os.remove(coords_path(str(tmp_path), "slide_h5"))
     assert np.array_equal(load_coords(str(tmp_path), "slide_h5"), c)  # the reader's .h5 fallback
+
+
+def test_wait_count_audits_catch_a_miscounted_wait(tmp_path):
+    """tools/audit_embed32_loads.py and tools/audit_qkv_wait.py are build gates (csrc/Makefile): the current listings pass, and a listing with a
+    miscounted ring wait -- the round-6 defect: `vmcnt(12)` where hipcc had emitted eight loads -- or with a ninth output store fails."""
+    import re
+    import subprocess
+    import sys
+    build = os.path.join(ROOT, "hipt_abmil_atec23_amd", "csrc", "build")
+    e32, qkv = os.path.join(build, "embed32.s"), os.path.join(build, "qkv_attention.s")
+    if not (os.path.isfile(e32) and os.path.isfile(qkv)):
+        pytest.skip("no device listings (the library was not built in this tree)")
+    run = lambda tool, path: subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), path], capture_output=True, text=True)
+    assert run("audit_embed32_loads.py", e32).returncode == 0
+    assert run("audit_qkv_wait.py", qkv).returncode == 0
+    s = open(e32).read()
+    # the interleaved-uint8 instantiation: every `vmcnt(8)` ring wait becomes the `vmcnt(12)` of the defective source
+    i = s.index("_ZN12_GLOBAL__N_114embed32_kernelILi2ELb1EEEv11EmbedParams: ;")
+    j = s.index("s_endpgm", i)
+    bad = tmp_path / "embed32_bad.s"
+    bad.write_text(s[:i] + s[i:j].replace("s_waitcnt vmcnt(8)", "s_waitcnt vmcnt(12)") + s[j:])
+    r = run("audit_embed32_loads.py", str(bad))
+    assert r.returncode == 1 and "vmcnt(12) before a ring barrier, but 8 loads" in r.stdout
+    q = open(qkv).read()
+    m = re.search(r"\n(\s*buffer_store_dwordx2 [^\n]*)\n", q[q.index("_ZN12_GLOBAL__N_115qkv_attn_kernelILi0ELb0EEEvNS_13QkvAttnParamsE: ;"):])
+    badq = tmp_path / "qkv_bad.s"
+    k = q.index(m.group(1))
+    badq.write_text(q[:k] + m.group(1) + "\n" + q[k:])  # a ninth output store
+    r = run("audit_qkv_wait.py", str(badq))
+    assert r.returncode == 1 and "expected exactly eight" in r.stdout
