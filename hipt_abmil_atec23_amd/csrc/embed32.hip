@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void embed32_kernel(const EmbedParams p) {
     // still be in flight behind the barrier: a race on the weight ring that only showed as run-to-run differences when two streams embedded
     // uint8 regions at once (found in round 6 by the H2D loop's bit-equality test).  The loads are now written in the widths the hardware takes (16 + 8
     // bytes: nothing left to merge; `volatile` is no way out -- hipcc turns such loads into FLAT loads, which retire out of order), and
-    // tools/audit_embed32_loads.py re-counts them in every build's listing: a mismatch fails the build.
+    // tools/audit_ring_waits.py re-counts them in every build's listing: a mismatch fails the build.
     constexpr int NLD = KIND == 0 ? 8 : (KIND == 1 ? 4 : 8);
     u32x4 raw[RAWN];
     auto load_quarter = [&](const pix_t* base, auto C_, auto J_) __attribute__((always_inline)) {

@@ -547,7 +547,7 @@ def test_feature_writer_h5_branch_with_a_stand_in_h5py(tmp_path, monkeypatch):
 
 
 def test_wait_count_audits_catch_a_miscounted_wait(tmp_path):
-    """tools/audit_embed32_loads.py and tools/audit_qkv_wait.py are build gates (csrc/Makefile): the current listings pass, and a listing with a
+    """tools/audit_ring_waits.py (embed32, seqgemm_pipe, mlp16) and tools/audit_qkv_wait.py are build gates (csrc/Makefile): the current listings pass, and a listing with a
     miscounted ring wait -- the round-6 defect: `vmcnt(12)` where hipcc had emitted eight loads -- or with a ninth output store fails."""
     import re
     import subprocess
@@ -557,7 +557,7 @@ def test_wait_count_audits_catch_a_miscounted_wait(tmp_path):
     if not (os.path.isfile(e32) and os.path.isfile(qkv)):
         pytest.skip("no device listings (the library was not built in this tree)")
     run = lambda tool, path: subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), path], capture_output=True, text=True)
-    assert run("audit_embed32_loads.py", e32).returncode == 0
+    assert run("audit_ring_waits.py", e32).returncode == 0
     assert run("audit_qkv_wait.py", qkv).returncode == 0
     s = open(e32).read()
     # the interleaved-uint8 instantiation: every `vmcnt(8)` ring wait becomes the `vmcnt(12)` of the defective source
@@ -565,8 +565,10 @@ def test_wait_count_audits_catch_a_miscounted_wait(tmp_path):
     j = s.index("s_endpgm", i)
     bad = tmp_path / "embed32_bad.s"
     bad.write_text(s[:i] + s[i:j].replace("s_waitcnt vmcnt(8)", "s_waitcnt vmcnt(12)") + s[j:])
-    r = run("audit_embed32_loads.py", str(bad))
-    assert r.returncode == 1 and "vmcnt(12) before a ring barrier, but 8 loads" in r.stdout
+    r = run("audit_ring_waits.py", str(bad))
+    assert r.returncode == 1 and "VIOLATION" in r.stdout and "vmcnt(12) before a ring barrier, but only 8 vector-memory instructions" in r.stdout
+    for f in ("seqgemm_pipe.s", "mlp16.s"):  # the other two ring kernels' waits pass too
+        assert run("audit_ring_waits.py", os.path.join(build, f)).returncode == 0, f
     q = open(qkv).read()
     m = re.search(r"\n(\s*buffer_store_dwordx2 [^\n]*)\n", q[q.index("_ZN12_GLOBAL__N_115qkv_attn_kernelILi0ELb0EEEvNS_13QkvAttnParamsE: ;"):])
     badq = tmp_path / "qkv_bad.s"
