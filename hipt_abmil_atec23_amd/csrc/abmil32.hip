@@ -957,7 +957,7 @@ __global__ __launch_bounds__(512) void clam_mb_pool_kernel(const ClamMbPoolParam
 }
 
 template <int KS, int NB>
-int launch_mb(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, void* h1_img, float* partials, unsigned* ticket,
+int launch_mb(const hipt_clam_weights* w, const void* bag, int N, int passes, float* A_raw, void* h1_img, float* partials, unsigned* ticket,
               float* M, float* logits, hipStream_t st) {
     constexpr int lds = image_bytes(KS) + 4 * TB_BYTES;
     auto k = abmil32_kernel<KS, NB>;
@@ -991,11 +991,11 @@ int launch_mb(const hipt_clam_weights* w, const void* bag, int N, int attention_
     p.A_raw = A_raw;
     p.h1_img = h1_img;
     p.attention_only = 1;
-    if (attention_only != 2) {  // (2: the pooling launch alone -- capi.hip books the two launches apart)
+    if (passes & 1) {  // passes: bit 0 = the streaming pass (A_raw, h1 image), bit 1 = the pooling pass (M, logits) -- capi.hip books them apart
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
         HIPT_CHECK_LAUNCH();
     }
-    if (attention_only == 1) return HIPT_OK;
+    if (!(passes & 2)) return HIPT_OK;
     ClamMbPoolParams q;
     memset(&q, 0, sizeof(q));
     q.h1_img = (const char*)h1_img;
@@ -1027,11 +1027,11 @@ bool hipt_clam_mb_stream_supported(const hipt_clam_weights* w) {
 
 size_t hipt_clam_mb_h1_bytes(int N) { return (size_t)((N + 31) / 32) * 8192; }
 
-int hipt_clam_mb_stream_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, void* h1_img, float* partials,
+int hipt_clam_mb_stream_launch(const hipt_clam_weights* w, const void* bag, int N, int passes, float* A_raw, void* h1_img, float* partials,
                                unsigned* ticket, float* M, float* logits, hipStream_t st) {
     HIPT_CHECK_ARG((int64_t)N * w->s0 * 2 < (int64_t)0x7fff0000 && (int64_t)((N + 31) / 32) * 8192 < (int64_t)0x7fff0000, "clam stream: bag beyond 2 GiB");
 #define MB_CASE(KS_, NB_) \
-    if (w->s0 == 16 * KS_ && w->n_att == NB_) return launch_mb<KS_, NB_>(w, bag, N, attention_only, A_raw, h1_img, partials, ticket, M, logits, st);
+    if (w->s0 == 16 * KS_ && w->n_att == NB_) return launch_mb<KS_, NB_>(w, bag, N, passes, A_raw, h1_img, partials, ticket, M, logits, st);
     MB_CASE(24, 2) MB_CASE(24, 3) MB_CASE(24, 4) MB_CASE(12, 2) MB_CASE(12, 3) MB_CASE(12, 4)
 #undef MB_CASE
     hipt_set_error("clam stream (multi-branch): unsupported S0=%d / branches=%d", w->s0, w->n_att);

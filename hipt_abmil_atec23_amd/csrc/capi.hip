@@ -1171,8 +1171,8 @@ int hipt_clam_mb_forward(const hipt_clam_weights* w, const void* bag, int N, int
     float* partials = (float*)c.take((size_t)128 * 4 * (4 + 128) * 4);
     void* h1 = c.take(hipt_clam_mb_h1_bytes(N));
     // (the two launches are booked apart: 'abmil_fused' = the streaming pass, 'abmil_combine' = the pooling pass)
-    PROF(PC_ABMIL, hipt_clam_mb_stream_launch(w, bag, N, 1, A_raw, h1, partials, ticket, M, logits, st));
-    if (!attention_only) PROF(PC_COMBINE, hipt_clam_mb_stream_launch(w, bag, N, 2, A_raw, h1, partials, ticket, M, logits, st));
+    PROF(PC_ABMIL, hipt_clam_mb_stream_launch(w, bag, N, 1, A_raw, h1, partials, ticket, M, logits, st));  // (passes = 1: the streaming pass)
+    if (!attention_only) PROF(PC_COMBINE, hipt_clam_mb_stream_launch(w, bag, N, 2, A_raw, h1, partials, ticket, M, logits, st));  // (passes = 2: the pooling pass)
     return HIPT_OK;
 }
 

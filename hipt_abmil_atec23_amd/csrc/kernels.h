@@ -194,10 +194,11 @@ int hipt_clam_stream_pack_launch(const hipt_clam_weights* w, void* out, hipStrea
 int hipt_clam_stream_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw,
                             float* partials, int* n_partials, unsigned* ticket, float* M, float* logits, float* Y_prob,
                             int64_t* Y_hat, hipStream_t st);  // n_partials = 0: combine already done in the kernel
-// CLAM_MB in one pass over the bag (abmil32.hip): the streaming kernel with w->n_att branches + the pooling kernel
+// CLAM_MB in one pass over the bag (abmil32.hip): `passes` bit 0 = the streaming kernel with w->n_att branches (A_raw, h1 as a bf16 image),
+// bit 1 = the pooling kernel (M, logits)
 bool hipt_clam_mb_stream_supported(const hipt_clam_weights* w);
 size_t hipt_clam_mb_h1_bytes(int N);
-int hipt_clam_mb_stream_launch(const hipt_clam_weights* w, const void* bag, int N, int attention_only, float* A_raw, void* h1_img, float* partials,
+int hipt_clam_mb_stream_launch(const hipt_clam_weights* w, const void* bag, int N, int passes, float* A_raw, void* h1_img, float* partials,
                                unsigned* ticket, float* M, float* logits, hipStream_t st);
 int hipt_clam_combine_launch(const float* partials, int G, const hipt_clam_weights* w, float* M, float* logits,
                              float* Y_prob, int64_t* Y_hat, hipStream_t st);
