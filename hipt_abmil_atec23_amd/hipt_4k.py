@@ -35,7 +35,8 @@ class HIPT_4K(torch.nn.Module):
         # > 1: a batch of regions is cut into that many parts, each run on its own HIP stream with its own workspace.
         # Every kernel of the path occupies whole CUs (one persistent workgroup each), so the parts do not share CUs:
         # the second stream's kernels fill the CUs the first one's kernel frees in its last, partial round of tiles.
-        # Default 2: a batch of R >= 2 regions runs as two groups of regions.
+        # `streams` is the MOST a call may use; how many it does use depends on its size (`_parts`, round 6): splitting pays only once every part
+        # still fills the chip for many rounds of tiles.  Default 2.
         self.streams = 2
         # ... and a batch of ONE region (the reference's call pattern) as patch ranges over this many streams (_run_patch_split).  Default 2
         # (round 6): one region is 514 row tiles of the fused MLP = two rounds on 256 CUs + 2 tiles, a third pass over the weights for 0.4 % of the
@@ -100,7 +101,7 @@ class HIPT_4K(torch.nn.Module):
             pk256 = m256._packed_for(m256._pos_for(256, 256, 256))
             # fewer regions than streams: the patches are spread over the streams (decided before anything is allocated or packed for
             # the whole-region path: that path's `out` and ViT-4K image are not used there)
-            split = int(self.patch_streams) if nreg == 1 else int(self.streams)
+            split = int(self.patch_streams) if nreg == 1 else 1  # (only a call of ONE region is cut by patches; groups of regions: _parts)
             while split > 1 and nseq < 32 * split:
                 split -= 1  # (small regions: fewer ranges)
             if split > nreg and nseq >= 32 * split:
@@ -123,7 +124,7 @@ class HIPT_4K(torch.nn.Module):
                     N.call("hipt_hipt4k_forward", pk256.ref, pk4k.ref, N.ptr(region[lo:hi]), n, W, H, self.chunk, N.ptr(sub_cls),
                            N.ptr(out[lo:hi]), N.ptr(ws), ws.numel(), N.stream_ptr(d256))
 
-            parts = max(1, min(int(self.streams), nreg))
+            parts = self._parts(nreg)
             if parts == 1:
                 launch(0, nreg, 0)
                 return out, cls256
@@ -198,6 +199,20 @@ class HIPT_4K(torch.nn.Module):
             cur.wait_stream(st)
         out = self.model4k.forward_tokens(cls256.view(nreg, per, -1), w_256, h_256)
         return out, (cls256 if want_cls256 else None)
+
+    def _parts(self, nreg: int) -> int:
+        """Streams a call of `nreg` regions is spread over (at most `self.streams`).  tools/streams_by_regions_bench.py, regions/s by (R, S):
+        R = 2: 270 / 278 (S = 1 / 2); R = 4: 300 / 298; R = 6: 310 / 308 / 284 (S = 3); R = 8: 314 / 309 / 291; R = 12: 308 / 316 / 303;
+        R = 16: 314 / 319 / 312; R = 24: 313 / 318 / 317 (bench.py's step, with CLAM_SB between the calls: 324 / 325 / 328).  Two or three regions: one
+        stream each pays (a region alone is two rounds of tiles + 2 tiles: the other stream fills the third round); from 4 to 11 regions ONE stream
+        is best -- parts of 2-4 regions mostly pay each other's launch tails; from 12 on, a stream per six regions.  A region's bits do not
+        depend on the partition (tests)."""
+        smax = max(1, int(self.streams))
+        if nreg <= 3:
+            return min(smax, nreg, 2)
+        if nreg < 12:
+            return 1
+        return max(1, min(smax, nreg // 6))
 
     def forward(self, x):
         """[R,3,W',H'] float -> [R,192] ViT-4K [CLS] features (hipt_4k.py:48-76; the reference takes R = 1).
