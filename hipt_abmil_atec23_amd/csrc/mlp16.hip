@@ -846,6 +846,8 @@ int hipt_mlp16_launch_dbg(const MlpParams& p_in, hipStream_t st) {
     // rounds: one or two regions per call) it is cut into 16-row tiles on 8x the CUs -- same pass over the weights, a fraction of
     // the row phases; in a long one the leftover tiles stay whole on their few CUs, which leaves the others to the next kernel
     // of another stream (HIPT_4K spreads its regions over streams: +1.4 % regions/s at 8 regions per stream).
+    // (round 6, one box, tools/streams_by_regions_bench.py: cutting the leftover tiles of LONG launches too is 1.0-1.9 % slower at every call size from 4 to
+    //  24 regions, on one stream and on several: 128 workgroups each pay a pass over the weights for 16 rows)
     const int tiles = (p.M + TMR - 1) / TMR;
     const int rem = tiles % ncu;
     // (and a launch of at most an eighth of a round -- the [CLS] rows of the pruned last block: 2 tiles at one region per call, 16 at
