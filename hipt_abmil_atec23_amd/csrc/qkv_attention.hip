@@ -92,6 +92,35 @@ __device__ __forceinline__ u32x4 pack8(const f32x16& a) {
     return o;
 }
 
+// The counted LDS wait of the GEMM loop: how many LDS operations the kernel has issued AFTER fragment g's read by the time step g needs it
+// (the queue is in order).  Program order of the loop: PF fragment reads up front; step t = (unit u, s): [s == 8: four bias reads]
+// [read of fragment t + PF] [wait for fragment t] [MFMA] [u > 0, 1 <= s <= 4: quarter s - 1 of unit u - 1's tile: one write for a V^T
+// tile, one after quarters 1 and 3 for a K^T tile, none for Q^T].  (a 4-bit counter: a smaller count only waits for more)
+template <int NU_, int PF_>
+constexpr int qkv_younger(int g) {
+    int n = 0;
+    bool seen = false;
+    for (int f = 0; f < PF_; ++f) {
+        if (seen) ++n;
+        if (f == g) seen = true;
+    }
+    for (int t = 0; t <= g; ++t) {
+        const int u = t / 24, s = t % 24;
+        if (s == 8 && seen) n += 4;
+        if (t + PF_ < 24 * NU_) {
+            if (seen) ++n;
+            if (t + PF_ == g) seen = true;
+        }
+        if (t == g) break;
+        if (u > 0 && s >= 1 && s <= 4) {
+            const int pu = u - 1;
+            const int wr = pu < 2 ? ((s == 2 || s == 4) ? 1 : 0) : (pu < 4 ? 1 : 0);
+            if (seen) n += wr;
+        }
+    }
+    return n > 15 ? 15 : n;
+}
+
 struct QkvAttnParams {
     const char* xn;        // bf16 activation image [M, 384]: LayerNorm-1(x)
     const char* wpk;       // the weight image (hipt_qkv_attn_pack_launch)
@@ -294,11 +323,46 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         u32x4 qop[2][2];
         QSTAMP_BEGIN();
         // ================= GEMM phase: six ring units = 144 MFMA steps, fragment reads PF steps ahead =================
+        // A unit's tile is finished (+ bias, packed, K^T / V^T to their LDS images, Q^T to its operand registers) UNDER the first MFMAs of the
+        // next unit, a quarter of the tile behind each of its steps 1 .. 4 (two accumulator tiles alternate): done between the units, both
+        // waves of a SIMD left the matrix pipe idle for the MFMA's latency + ~30 vector instructions, six times per work unit.
         {
             u32x4 wf[8];
             f32x4 bq[4];
-            f32x16 acc;
+            f32x16 acc[2];
             uint32_t sa = fa + cslot * UNIT, sn = sa;  // fragment base of the unit being consumed / of the next one
+            const uint32_t ka = fa + OFF_K + w * 4096;  // this wave's K^T tile: the two A-operand fragments (k-steps) of the score product per unit
+            // V^T tile: row-major [key][32 dims], dims 8 q + 4 hh ..+3 from registers 4 q ..+3
+            // (the four 16-byte chunks of a 64-byte row are rotated by (key >> 1) & 3: sixteen consecutive keys then write to
+            //  eight bank groups instead of two -- 2-way instead of 8-way conflicts; the transposed reads stay conflict-free)
+            const uint32_t vwb = lbase + OFF_V + (32 * w + r) * 64 + 8 * hh;
+            const int rot16 = ((r >> 1) & 3) * 16;
+            auto epi = [&](auto U_, auto Q_) __attribute__((always_inline)) {  // quarter q (registers 4 q ..+3) of unit pu's tile
+                constexpr int pu = decltype(U_)::value, q = decltype(Q_)::value;
+                f32x16& a = acc[pu & 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[4 * q + i] += bq[q][i];
+                if constexpr (pu < 2) {          // K^T tile
+                    if constexpr (q == 1) {
+                        const u32x4 k0 = pack8<0>(a);
+                        const uint32_t ka_ = ka;
+                        DSW128(ka_, k0, (pu * 2 + 0) * 1024);
+                    } else if constexpr (q == 3) {
+                        const u32x4 k1 = pack8<1>(a);
+                        const uint32_t ka_ = ka;
+                        DSW128(ka_, k1, (pu * 2 + 1) * 1024);
+                    }
+                } else if constexpr (pu < 4) {   // V^T tile
+                    u32x2 o;
+                    o[0] = pack_bf16x2(a[4 * q], a[4 * q + 1]);
+                    o[1] = pack_bf16x2(a[4 * q + 2], a[4 * q + 3]);
+                    const uint32_t va_ = vwb + ((q * 16 + rot16) & 48);
+                    DSW64(va_, o, (pu - 2) * VSUB);
+                } else {                         // Q^T tile: stays in registers as the score product's B operand
+                    if constexpr (q == 1) qop[pu - 4][0] = pack8<0>(a);
+                    else if constexpr (q == 3) qop[pu - 4][1] = pack8<1>(a);
+                }
+            };
             if constexpr (CLSONLY) XOP_FENCE(0);
             else XOP_FENCE(8);  // (the eight youngest vector-memory operations are the previous patch's output stores: let them fly)
             sfor<0, PF>([&](auto G_) __attribute__((always_inline)) {
@@ -310,11 +374,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
             });
             sfor<0, NG>([&](auto G_) __attribute__((always_inline)) {
                 constexpr int g = decltype(G_)::value, u = g / 24, s = g % 24;
-                // LDS operations younger than fragment g at its wait: the PF fragments behind it, and -- during the first PF
-                // steps of a unit -- the bias reads of this unit and the K / V writes of the unit before (in-order queue)
-                constexpr int wprev = u == 0 ? 0 : (u <= 2 ? 2 : (u <= 4 ? 4 : 0));
-                constexpr int ahead = g + PF < NG ? PF : NG - 1 - g;
-                if constexpr (s == 0) {
+                if constexpr (s == 8) {  // this unit's bias (the registers were last used by the tile before, at steps 1 .. 4)
                     const uint32_t ba = lbase + OFF_BIAS + ((hs * 6 + u) * 2 + hh) * 64;
                     f32x4 &b0v = bq[0], &b1v = bq[1], &b2v = bq[2], &b3v = bq[3];
                     DSR128(b0v, ba, 0);
@@ -332,22 +392,25 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                         DSR128(d, a, (s + PF - 24) * 1024);
                     }
                 }
+                // counted wait: the LDS operations younger than fragment g (in-order queue) = qkv_younger (the fragments behind it, bias reads, tile writes)
                 if constexpr ((DBG & 2) != 0) {
                     LGKM(0);
-                } else if constexpr (s < PF) {
-                    LGKM((ahead + 4 + wprev < 15 ? ahead + 4 + wprev : 15));  // (a 4-bit counter: a smaller count only waits for more)
                 } else {
-                    LGKM(ahead);
+                    LGKM((qkv_younger<NU, PF>(g)));
                 }
                 if constexpr ((DBG & 8) != 0) {
-                    if constexpr (s == 0) acc = Z16;
-                    acc[s & 15] += __builtin_bit_cast(float, wf[g & 7][0]);
+                    if constexpr (s == 0) acc[u & 1] = Z16;
+                    acc[u & 1][s & 15] += __builtin_bit_cast(float, wf[g & 7][0]);
                 } else if constexpr (s == 0) {
-                    acc = mfma32(wf[g & 7], xop[s], Z16);
+                    acc[u & 1] = mfma32(wf[g & 7], xop[s], Z16);
                 } else {
-                    acc = mfma32(wf[g & 7], xop[s], acc);
+                    acc[u & 1] = mfma32(wf[g & 7], xop[s], acc[u & 1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (u > 0 && s >= 1 && s <= 4) {
+                    epi(std::integral_constant<int, u - 1>{}, std::integral_constant<int, s - 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr (s == 11) {
                     // ---- ring: the next unit has landed for everyone; request the one after it ----
                     if constexpr ((DBG & 1) == 0) {
@@ -369,43 +432,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                     }
                 }
                 if constexpr (s == 23) {
-                    // ---- unit done: + bias, then K^T / V^T tiles to their LDS images, Q^T to its operand registers ----
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[i] += bq[0][i];
-                        acc[4 + i] += bq[1][i];
-                        acc[8 + i] += bq[2][i];
-                        acc[12 + i] += bq[3][i];
-                    }
-                    if constexpr (u < 2) {          // K^T tile u: the two A-operand fragments (k-steps) of the score product
-                        const u32x4 k0 = pack8<0>(acc), k1 = pack8<1>(acc);
-                        const uint32_t ka = fa + OFF_K + w * 4096;
-                        DSW128(ka, k0, (u * 2 + 0) * 1024);
-                        DSW128(ka, k1, (u * 2 + 1) * 1024);
-                    } else if constexpr (u < 4) {   // V^T tile: row-major [key][32 dims], dims 8 q + 4 hh ..+3 from registers 4 q ..+3
-                        // (the four 16-byte chunks of a 64-byte row are rotated by (key >> 1) & 3: sixteen consecutive keys then write to
-                        //  eight bank groups instead of two -- 2-way instead of 8-way conflicts; the transposed reads stay conflict-free)
-                        const int rot = (r >> 1) & 3;
-                        const uint32_t vw = lbase + OFF_V + (u - 2) * VSUB + (32 * w + r) * 64 + 8 * hh;
-                        const uint32_t vw0 = vw + ((0 + rot) & 3) * 16, vw1 = vw + ((1 + rot) & 3) * 16, vw2 = vw + ((2 + rot) & 3) * 16, vw3 = vw + ((3 + rot) & 3) * 16;
-                        u32x2 o0, o1, o2, o3;
-                        o0[0] = pack_bf16x2(acc[0], acc[1]);   o0[1] = pack_bf16x2(acc[2], acc[3]);
-                        o1[0] = pack_bf16x2(acc[4], acc[5]);   o1[1] = pack_bf16x2(acc[6], acc[7]);
-                        o2[0] = pack_bf16x2(acc[8], acc[9]);   o2[1] = pack_bf16x2(acc[10], acc[11]);
-                        o3[0] = pack_bf16x2(acc[12], acc[13]); o3[1] = pack_bf16x2(acc[14], acc[15]);
-                        DSW64(vw0, o0, 0);
-                        DSW64(vw1, o1, 0);
-                        DSW64(vw2, o2, 0);
-                        DSW64(vw3, o3, 0);
-                    } else {                        // Q^T tile: stays in registers as the score product's B operand
-                        qop[u - 4][0] = pack8<0>(acc);
-                        qop[u - 4][1] = pack8<1>(acc);
-                    }
                     sa = sn;
                     cslot = cslot == 2 ? 0 : cslot + 1;
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             });
+            // the last unit's tile (V in the [CLS]-pruned block, Q otherwise)
+            sfor<0, 4>([&](auto Q_) __attribute__((always_inline)) { epi(std::integral_constant<int, NU - 1>{}, Q_); });
+            __builtin_amdgcn_sched_barrier(0);
         }
         QSTAMP(0);
         // (the operands of the next work unit: requested here, landing under the [CLS] query; fenced at the head of the next unit)
