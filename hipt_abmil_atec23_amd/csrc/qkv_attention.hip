@@ -510,13 +510,16 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                              : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
                              : "v"(ko), "v"(k8));
                 Sc[0] = mfma32(a0, qc[0], Z16);
-                Sc[1] = mfma32(c0, qc[0], Z16);
                 Sc[0] = mfma32(a1, qc[1], Sc[0]);
-                Sc[1] = mfma32(c1, qc[1], Sc[1]);
                 Sc[0] = mfma32(a2, qc[2], Sc[0]);
-                Sc[1] = mfma32(c2, qc[2], Sc[1]);
                 Sc[0] = mfma32(a3, qc[3], Sc[0]);
-                Sc[1] = mfma32(c3, qc[3], Sc[1]);
+                Sc[1] = Z16;
+                if (w == 0) {  // (tile 8 = the [CLS] key: wave 0's share only -- for the others its probability is 0 and these MFMAs were 6 of a unit's 202)
+                    Sc[1] = mfma32(c0, qc[0], Z16);
+                    Sc[1] = mfma32(c1, qc[1], Sc[1]);
+                    Sc[1] = mfma32(c2, qc[2], Sc[1]);
+                    Sc[1] = mfma32(c3, qc[3], Sc[1]);
+                }
             }
             // the [CLS] key (register 0 of lane half 0 of tile 8) belongs to wave 0's share
             const float s8 = (w == 0 && hh == 0) ? Sc[1][0] : -INFINITY;
@@ -553,8 +556,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                 Oc[1] = mfma32(u32x4{d0[0], d0[1], d1[0], d1[1]}, pc0, Z16);
                 Oc[0] = mfma32(u32x4{b0v[0], b0v[1], b1v[0], b1v[1]}, pc1, Oc[0]);
                 Oc[1] = mfma32(u32x4{e0[0], e0[1], e1[0], e1[1]}, pc1, Oc[1]);
-                Oc[0] = mfma32(u32x4{c0[0], c0[1], c1[0], c1[1]}, pc8, Oc[0]);
-                Oc[1] = mfma32(u32x4{f0[0], f0[1], f1[0], f1[1]}, pc8, Oc[1]);
+                if (w == 0) {
+                    Oc[0] = mfma32(u32x4{c0[0], c0[1], c1[0], c1[1]}, pc8, Oc[0]);
+                    Oc[1] = mfma32(u32x4{f0[0], f0[1], f1[0], f1[1]}, pc8, Oc[1]);
+                }
             }
             if (r == 0) {  // query 0: lane 0 holds dims 8 q + 0..3, lane 32 dims 8 q + 4..7 of each d tile
                 const uint32_t pa = lbase + OFF_CLSP + (pq * 8 + w) * CLSP_W;
