@@ -112,8 +112,18 @@ __global__ void mlp16_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* _
         const int gg = frag >> 2, f = frag & 3, O = 2 * gg + (f >> 1), t = f & 1;
         row = w2 + (int64_t)(16 * O + r) * hidden + Hb + 32 * t + 4 * g;
     }
-    const u32x2 lo = *(const u32x2*)row, hi = *(const u32x2*)(row + 16);
-    out[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    // The image carries W1 / 8 and 8 W2 (exact: powers of two; b1 / 8 is made where the kernel stages the bias): fc1 then yields h / 8, whose square the
+    // GELU clamps at 1 with the multiply's own clamp bit instead of a v_min at 64 (mlp_common.h, gelu1s), its output g / 8 meets 8 W2 -- every
+    // product, sum and rounding of the unscaled computation, bit for bit, one vector instruction per hidden element less.
+    const float sc = is_a ? 0.125f : 8.0f;
+    u32x4 ov;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bf16_t* q = row + 16 * h;
+        ov[2 * h] = pack_bf16x2((float)q[0] * sc, (float)q[1] * sc);
+        ov[2 * h + 1] = pack_bf16x2((float)q[2] * sc, (float)q[3] * sc);
+    }
+    out[i] = ov;
 }
 
 // IMG / XIN: fragment-blocked activation images (kernels.h, "activation images") -- IMG: y1 is read and x / xn_out are written as
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
             gam1[D + i] = p.ln_next_b[i];
         }
     }
-    for (int i = tid; i < p.hidden; i += 256) b1s[i] = p.b1[i];
+    for (int i = tid; i < p.hidden; i += 256) b1s[i] = p.b1[i] * 0.125f;  // (the image holds W1 / 8: mlp16_pack_kernel)
     // (the tile queue resets itself: a launch makes grid + ntiles fetches, the one that draws the last number stores 0 -- nobody
     //  fetches after it -- so that a caller running a chain of these kernels zeroes the counter once, not once per launch)
     const int last_fetch = p.ntiles + (int)gridDim.x - 1;
@@ -307,8 +317,8 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
             constexpr int tl = u >> 2, mm = (u >> 1) & 1, pr = u & 1;
             float v0 = acc1[gh][tl][mm][2 * pr], v1 = acc1[gh][tl][mm][2 * pr + 1];
             if constexpr ((DBG & 2) == 0) {
-                v0 = gelu1(v0);
-                v1 = gelu1(v1);
+                v0 = gelu1s(v0);
+                v1 = gelu1s(v1);
             }
             hf[gh][tl >> 1][mm][(tl & 1) * 2 + pr] = pack_bf16x2(v0, v1);
         };

@@ -44,6 +44,19 @@ __device__ __forceinline__ float gelu1(float x) {
     return x * __builtin_amdgcn_rcpf(d);
 }
 
+// gelu1 on pre-scaled data: xs = x / 8 in, gelu(x) / 8 out (mlp16.hip: its weight image holds W1 / 8 and 8 W2).  (x / 8)^2 clamped at 1 IS x^2 clamped
+// at 64 -- and the clamp to [0, 1] is an output modifier of the multiply (v_mul_f32 ... clamp), not an instruction; the coefficients carry
+// the powers of two, so every intermediate is the unscaled one times an exact power of two: the same bits as gelu1(x) / 8, 8 instead of
+// 9 vector instructions per element.
+__device__ __forceinline__ float gelu1s(float xs) {
+#pragma clang fp contract(off)
+    const float t = __builtin_fminf(__builtin_fmaxf(xs * xs, 0.0f), 1.0f);
+    float q = __builtin_fmaf(t, 1.014264505e-03f * 32768.0f, -1.067757332e-01f * 512.0f);
+    q = __builtin_fmaf(q, t, -2.301121329e+00f * 8.0f);
+    const float d = __builtin_amdgcn_exp2f(xs * q) + 1.0f;
+    return xs * __builtin_amdgcn_rcpf(d);
+}
+
 template <int NCH>
 __device__ __forceinline__ void ln_rows(f32x4 (&v)[NCH][2], const float* gam, const float* bet, int K, float eps, int g,
                                         u32x4 (&out)[NCH]) {
