@@ -59,6 +59,8 @@ __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b
 #define PSTAMP_CLK(k) (void)stamp_clk
 #endif
 
+#define DSR128A(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(addr), "n"(off))
+
 enum { KA = 0, KB = 1, KP = 2 };  // phase kind: fc1 half / fc2 half / proj unit (FOLD: H = unit 0..5, operand = the attention rows in X)
 
 // Ring unit `pos` of a tile pass: positions A0(0) A1(0) B0(0) | A0(c) B1(c-1) A1(c) B0(c) ... | B1(n-1)
@@ -280,11 +282,13 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
         int ln;  // (b1[.. + 4 g ..]: the lane group from a fresh lane id -- two instructions -- rather than from a register kept, and spilled)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
         const uint32_t a = (uint32_t)(uintptr_t)(LDS_AS char*)b1s + ((ln >> 4) << 4) + offd * 4;
+        // (straight into the accumulator file: the bias is the C operand of the phase's first MFMAs, and every MFMA destination of this 512-register
+        //  kernel lives there -- read into arch registers it cost 16 v_accvgpr_write per fc1 phase)
         f32x4 &q0 = bq[0], &q1 = bq[1], &q2 = bq[2], &q3 = bq[3];
-        DSR128(q0, a, oc + 0);
-        DSR128(q1, a, oc + 64);
-        DSR128(q2, a, oc + 128);
-        DSR128(q3, a, oc + 192);
+        DSR128A(q0, a, oc + 0);
+        DSR128A(q1, a, oc + 64);
+        DSR128A(q2, a, oc + 128);
+        DSR128A(q3, a, oc + 192);
     };
 
     for (int seq = 0; tile < p.ntiles; ++seq) {
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
                         // the bias read a phase ago has landed only NOW (the wait above): re-define it here, so that no copy of
                         // it (hipcc moves it to the accumulator file) can be placed before this point
                         f32x4 &q0 = bq[0], &q1 = bq[1], &q2 = bq[2], &q3 = bq[3];
-                        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+                        asm volatile("" : "+a"(q0), "+a"(q1), "+a"(q2), "+a"(q3));
 #pragma unroll
                         for (int U = 0; U < 4; ++U)
 #pragma unroll
