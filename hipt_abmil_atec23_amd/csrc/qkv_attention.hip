@@ -93,7 +93,7 @@ __device__ __forceinline__ u32x4 pack8(const f32x16& a) {
 }
 
 // The counted LDS wait of the GEMM loop: how many LDS operations the kernel has issued AFTER fragment g's read by the time step g needs it
-// (the queue is in order).  Program order of the loop: PF fragment reads up front; step t = (unit u, s): [s == 8: four bias reads]
+// (the queue is in order).  Program order of the loop: (four bias reads of unit 0,) PF fragment reads up front; step t = (unit u, s): [s == 8, not in the last unit: four bias reads, of unit u + 1]
 // [read of fragment t + PF] [wait for fragment t] [MFMA] [u > 0, 1 <= s <= 4: quarter s - 1 of unit u - 1's tile: one write for a V^T
 // tile, one after quarters 1 and 3 for a K^T tile, none for Q^T].  (a 4-bit counter: a smaller count only waits for more)
 template <int NU_, int PF_>
@@ -106,7 +106,7 @@ constexpr int qkv_younger(int g) {
     }
     for (int t = 0; t <= g; ++t) {
         const int u = t / 24, s = t % 24;
-        if (s == 8 && seen) n += 4;
+        if (s == 8 && u + 1 < NU_ && seen) n += 4;
         if (t + PF_ < 24 * NU_) {
             if (seen) ++n;
             if (t + PF_ == g) seen = true;
@@ -339,9 +339,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
             const int rot16 = ((r >> 1) & 3) * 16;
             auto epi = [&](auto U_, auto Q_) __attribute__((always_inline)) {  // quarter q (registers 4 q ..+3) of unit pu's tile
                 constexpr int pu = decltype(U_)::value, q = decltype(Q_)::value;
-                f32x16& a = acc[pu & 1];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[4 * q + i] += bq[q][i];
+                f32x16& a = acc[pu & 1];  // (the bias is already in it: the unit's first MFMA started from it)
                 if constexpr (pu < 2) {          // K^T tile
                     if constexpr (q == 1) {
                         const u32x4 k0 = pack8<0>(a);
@@ -363,8 +361,17 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                     else if constexpr (q == 3) qop[pu - 4][1] = pack8<1>(a);
                 }
             };
+            auto bias_rd = [&](int u) __attribute__((always_inline)) {  // unit u's bias, the C operand of its first MFMA (accumulator order)
+                const uint32_t ba = lbase + OFF_BIAS + ((hs * 6 + u) * 2 + hh) * 64;
+                f32x4 &b0v = bq[0], &b1v = bq[1], &b2v = bq[2], &b3v = bq[3];
+                DSR128(b0v, ba, 0);
+                DSR128(b1v, ba, 16);
+                DSR128(b2v, ba, 32);
+                DSR128(b3v, ba, 48);
+            };
             if constexpr (CLSONLY) XOP_FENCE(0);
             else XOP_FENCE(8);  // (the eight youngest vector-memory operations are the previous patch's output stores: let them fly)
+            bias_rd(0);  // (older than every fragment read: landed by the first counted wait)
             sfor<0, PF>([&](auto G_) __attribute__((always_inline)) {
                 constexpr int g = decltype(G_)::value;
                 u32x4& d = wf[g & 7];
@@ -374,14 +381,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
             });
             sfor<0, NG>([&](auto G_) __attribute__((always_inline)) {
                 constexpr int g = decltype(G_)::value, u = g / 24, s = g % 24;
-                if constexpr (s == 8) {  // this unit's bias (the registers were last used by the tile before, at steps 1 .. 4)
-                    const uint32_t ba = lbase + OFF_BIAS + ((hs * 6 + u) * 2 + hh) * 64;
-                    f32x4 &b0v = bq[0], &b1v = bq[1], &b2v = bq[2], &b3v = bq[3];
-                    DSR128(b0v, ba, 0);
-                    DSR128(b1v, ba, 16);
-                    DSR128(b2v, ba, 32);
-                    DSR128(b3v, ba, 48);
-                }
+                if constexpr (s == 8 && u + 1 < NU) bias_rd(u + 1);  // the next unit's bias (this unit's went into its first MFMA)
                 if constexpr (g + PF < NG && (DBG & 2) == 0) {
                     u32x4& d = wf[(g + PF) & 7];
                     if constexpr (s + PF < 24) {
@@ -402,7 +402,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
                     if constexpr (s == 0) acc[u & 1] = Z16;
                     acc[u & 1][s & 15] += __builtin_bit_cast(float, wf[g & 7][0]);
                 } else if constexpr (s == 0) {
-                    acc[u & 1] = mfma32(wf[g & 7], xop[s], Z16);
+                    const f32x16 b16 = __builtin_shufflevector(__builtin_shufflevector(bq[0], bq[1], 0, 1, 2, 3, 4, 5, 6, 7),
+                                                               __builtin_shufflevector(bq[2], bq[3], 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11,
+                                                               12, 13, 14, 15);
+                    acc[u & 1] = mfma32(wf[g & 7], xop[s], b16);
                 } else {
                     acc[u & 1] = mfma32(wf[g & 7], xop[s], acc[u & 1]);
                 }
