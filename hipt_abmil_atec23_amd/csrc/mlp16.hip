@@ -507,7 +507,6 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
                 int g_;
                 lane_off(nrows, true, XIN, xo, g_);
                 lane_off(nrows, false, IMG, yo, g_);
-                g2base = (uint32_t)(uintptr_t)(LDS_AS char*)gam + 16 * g_;
                 if constexpr (FOLD) {
                     // the attention rows as the proj product's B operand: lane (g, i) = row i, chunk 4 ks + g (8 columns = 16 bytes) of k-step ks.
                     // Image: fragment base + chunk * 256 + 16 i (1 KiB per wave instruction); row-major: row * 768 + 16 chunk.
@@ -613,6 +612,12 @@ __global__ __launch_bounds__(256, 1) void mlp16_kernel(const MlpParams p) {
                 }
                 rstd[mm] = 1.0f / sqrtf(row_sum(qs2[0] + qs2[1]) * (1.0f / D) + p.ln_eps);
             });
+            {   // (re-derived here from a fresh lane id: computed with the other offsets at the head of the row phase it lived across the six proj phases,
+                //  and hipcc spilled it there and reloaded it here -- a scratch load, whose vmcnt(0) also waits for the weight stream)
+                int ln;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+                g2base = (uint32_t)(uintptr_t)(LDS_AS char*)gam + 16 * (ln >> 4);
+            }
             sfor<0, NKS>([&](auto S_) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
                 constexpr int ks = decltype(S_)::value;
