@@ -174,7 +174,9 @@ size_t hipt_vit_packed_bytes(const hipt_vit_weights* w, int what);
  * tiles: LayerNorm-chained blocks have no proj launch and no y1 tensor; hipt_vit_packed_bytes(HIPT_PACK_MLP) includes them),
  * 0 = this dtype / shape has no packed form (the generic kernel reads the row-major matrices).  An image packed as format 2
  * (the same without the proj units) by an older binding still runs, with proj as its own kernel.  (1 was the 32x32x16 form
- * of ABI versions before round 5: an image in that format is no longer run -- its model takes the generic kernels.) */
+ * of ABI versions before round 5: an image in that format is no longer run -- its model takes the generic kernels.)
+ * The BYTES of an image are private to the library build that wrote them (since late round 6 the fused-MLP image holds W1 / 8 and
+ * 8 * W2, exact power-of-two scalings its kernel undoes): pack with the library that will run the image, never carry one across builds. */
 int hipt_vit_mlp_pack_format(const hipt_vit_weights* w);
 int hipt_vit_pack_weights(const hipt_vit_weights* w, int block, int what, void* out, void* stream);
 /* Scratch of the whole-forward calls below (residual stream + block scratch + bf16 input copy). */
